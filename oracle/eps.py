@@ -1,0 +1,387 @@
+"""CPU restatement of ``EPSSolve`` with the Krylov-Schur solver (symmetric and
+non-symmetric variants) as the reference runs it on the CPU.
+
+TEST INFRASTRUCTURE ONLY (see ``oracle/__init__.py``).
+
+Follows ``src/eps/impls/krylov/krylovschur/ks-symm.c:30-111``,
+``krylovschur.c:73-288``, ``src/eps/impls/krylov/epskrylov.c:39-74,252-327,347-376``,
+``src/eps/interface/epssolve.c:63-146,334-462,506-710``,
+``epssetup.c:466-490`` and ``epsdefault.c:136-338``.
+"""
+import numpy as np
+
+from . import ds as dsmod
+from .bv import BV, SelfComm, EPSILON
+
+ITERATING = 0
+CONVERGED_TOL = 2
+DIVERGED_ITS = -3
+DIVERGED_BREAKDOWN = -4
+
+
+def splitmix64_uniform(g, seed=0x12345678):
+    """Counter-based start vector: value in [-1,1) from the *global* row index,
+    so that it is identical for every partition of the rows."""
+    z = (np.asarray(g, dtype=np.uint64) ^ np.uint64(seed)) + np.uint64(0x9E3779B97F4A7C15)
+    z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+    z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+    z = z ^ (z >> np.uint64(31))
+    u = (z >> np.uint64(11)).astype(np.float64) * (1.0 / 9007199254740992.0)
+    return 2.0 * u - 1.0
+
+
+class EPS:
+    """Standard eigenproblem ``A x = lambda x`` solved by Krylov-Schur.
+
+    ``matvec(x, y)`` computes y = A x on the local rows (the ``STApply`` ->
+    ``STApply_Shift`` -> ``MatMult`` hop of stsolve.c:44-72 / shift.c:27-41 with
+    sigma = 0).
+    """
+
+    def __init__(self, matvec, n_local, N=None, hermitian=True, nev=1, ncv=0, mpd=0,
+                 tol=1e-8, max_it=0, which=None, keep=0.5, lock=True, comm=None,
+                 row0=0, v0=None, monitor=None):
+        self.matvec = matvec
+        self.n = int(n_local)
+        self.N = int(N if N is not None else n_local)
+        self.hermitian = hermitian
+        self.nev, self.ncv, self.mpd = nev, ncv, mpd
+        self.tol = tol                               # default 1e-8: epssetup.c:184
+        self.max_it = max_it
+        self.which = which
+        self.keep = keep
+        self.lock = lock
+        self.comm = comm if comm is not None else SelfComm()
+        self.row0 = row0
+        self.v0 = v0
+        self.monitor = monitor
+        self.reason = ITERATING
+        self.its = 0
+        self.nconv = 0
+        self.nmatvec = 0
+
+    # -- setup: EPSSetUp_KrylovSchur (krylovschur.c:73-167) ----------------
+    def setup(self):
+        nev = self.nev
+        if self.ncv:                                  # EPSSetDimensions_Default epssetup.c:466-490
+            if self.ncv < nev + 1 and not (self.ncv == nev and self.ncv == self.N):
+                raise ValueError("The value of ncv must be at least nev+1")
+        elif self.mpd:
+            self.ncv = min(self.N, nev + self.mpd)
+        else:
+            if nev < 500:
+                self.ncv = min(self.N, max(2 * nev, nev + 15))
+            else:
+                self.mpd = 500
+                self.ncv = min(self.N, nev + self.mpd)
+        if not self.mpd:
+            self.mpd = self.ncv
+        if self.ncv > self.nev + self.mpd:
+            raise ValueError("The value of ncv must not be larger than nev+mpd")
+        if not self.max_it:
+            self.max_it = max(100, 2 * self.N // self.ncv)   # krylovschur.c:89
+        if not self.which:
+            self.which = "largest_magnitude"                 # epsdefault.c:243-253
+        if not self.keep:
+            self.keep = 0.5                                  # krylovschur.c:103
+        ncv = self.ncv
+        self.V = BV(self.n, ncv + 1, N=self.N, comm=self.comm)   # EPSAllocateSolution(eps,1)
+        self.eigr = np.zeros(ncv + 1)
+        self.eigi = np.zeros(ncv + 1)
+        self.errest = np.zeros(ncv + 1)
+        self.perm = np.arange(ncv + 1)
+        cmpf = dsmod.COMPARE[self.which]
+        if self.hermitian:
+            self.ds = dsmod.DSHEP(ncv + 1, cmpf)
+        else:
+            self.ds = dsmod.DSNHEP(ncv + 1, cmpf)
+
+    # -- helpers --------------------------------------------------------------
+    def _apply(self, x, y):
+        self.nmatvec += 1
+        self.matvec(x, y)
+
+    def _random_column(self, j):
+        g = np.arange(self.row0, self.row0 + self.n, dtype=np.uint64)
+        return splitmix64_uniform(g, seed=0x12345678 + 7919 * (j + 1) + self.its)
+
+    def _get_start_vector(self, i):
+        """``EPSGetStartVector`` (epssolve.c:675-710).  Returns breakdown flag."""
+        V = self.V
+        if i > 0 or self.v0 is None:
+            if i == 0:
+                g = np.arange(self.row0, self.row0 + self.n, dtype=np.uint64)
+                V.col(0)[:] = splitmix64_uniform(g)
+            else:
+                V.col(i)[:] = self._random_column(i)
+        else:
+            V.col(0)[:] = self.v0
+        norm, lindep = V.orthogonalize_column(i)
+        if lindep or norm == 0.0:
+            if i == 0:
+                raise ArithmeticError("Initial vector is zero or belongs to the deflation space")
+            return True
+        V.scale_column(i, 1.0 / norm)
+        return False
+
+    def _full_lanczos(self, alpha, beta, k, m):
+        """``EPSFullLanczos`` (epskrylov.c:347-376).  Returns (M, breakdown)."""
+        V = self.V
+        V.set_active_columns(0, m)
+        M = m
+        breakdown = False
+        for j in range(k, m):
+            self._apply(V.col(j), V.col(j + 1))
+            nrm, breakdown = V.orthonormalize_column(j + 1, False)
+            beta[j] = nrm
+            if breakdown:
+                M = j + 1
+                break
+        nc = V.nc
+        ld = nc + V.m
+        a = V.get_buffer()
+        for j in range(k, M):
+            alpha[j] = a[nc + j + (j + 1) * ld]
+        return M, breakdown
+
+    def _basic_arnoldi(self, H, k, m):
+        """``EPSBasicArnoldi`` (epskrylov.c:39-74).  Returns (M, beta, breakdown)."""
+        V = self.V
+        V.set_active_columns(0, m)
+        M = m
+        beta = 0.0
+        breakdown = False
+        for j in range(k, m):
+            self._apply(V.col(j), V.col(j + 1))
+            beta, breakdown = V.orthonormalize_column(j + 1, False)
+            if breakdown:
+                M = j + 1
+                break
+        nc = V.nc
+        ld = nc + V.m
+        a = V.get_buffer()
+        for j in range(k, M):
+            H[:j + 2, j] = a[nc + (j + 1) * ld: nc + (j + 1) * ld + j + 2]
+        return M, beta, breakdown
+
+    def _krylov_convergence(self, kini, nits, beta):
+        """``EPSKrylovConvergence`` (epskrylov.c:252-327) with the relative test
+        ``EPSConvergedRelative`` (epsdefault.c:258-266); trivial region, no true
+        residual."""
+        marker = -1
+        k = kini
+        while k < kini + nits:
+            re, im = self.eigr[k], self.eigi[k]
+            newk, resnorm = self.ds.vectors_rnorm(k)
+            resnorm *= beta
+            self.errest[k] = resnorm / dsmod.abs_eig(re, im)
+            if marker == -1 and self.errest[k] >= self.tol:
+                marker = k
+            if newk == k + 1:
+                self.errest[k + 1] = self.errest[k]
+                k += 1
+            if marker != -1:
+                break
+            k += 1
+        if marker != -1:
+            k = marker
+        return k
+
+    def _stopping(self, k):
+        """``EPSStoppingBasic`` (epsdefault.c:324-338)."""
+        if k >= self.nev:
+            return CONVERGED_TOL
+        if self.its >= self.max_it:
+            return DIVERGED_ITS
+        return ITERATING
+
+    # -- solvers -----------------------------------------------------------------
+    def _solve_symm(self):
+        """``EPSSolve_KrylovSchur_Symm`` (ks-symm.c:30-111)."""
+        ds, V = self.ds, self.V
+        ld = ds.ld
+        self._get_start_vector(0)
+        l = 0
+        while self.reason == ITERATING:
+            self.its += 1
+            nv = min(self.nconv + self.mpd, self.ncv)
+            a = ds.T[:ld]
+            b = ds.T[ld:2 * ld]
+            nv, breakdown = self._full_lanczos(a, b, self.nconv + l, nv)
+            beta = b[nv - 1]
+            ds.set_dimensions(nv, self.nconv, self.nconv + l)
+            ds.set_state(dsmod.STATE_INTERMEDIATE if l == 0 else dsmod.STATE_RAW)
+            V.set_active_columns(self.nconv, nv)
+
+            ds.solve(self.eigr)
+            ds.sort(self.eigr)
+            ds.update_extra_row()
+
+            k = self._krylov_convergence(self.nconv, nv - self.nconv, beta)
+            self.reason = self._stopping(k)
+            nconv = k
+
+            if self.reason != ITERATING or breakdown:
+                l = 0
+            else:
+                l = max(1, int((nv - k) * self.keep))
+            if not self.lock and l > 0:
+                l += k
+                k = 0
+            if self.reason == ITERATING:
+                if breakdown:
+                    if k < self.nev:
+                        if self._get_start_vector(k):
+                            self.reason = DIVERGED_BREAKDOWN
+                else:
+                    ds.truncate(k + l)
+            Q = ds.get_mat_Q()
+            V.mult_in_place(Q, self.nconv, k + l)
+            if self.reason == ITERATING and not breakdown:
+                V.copy_column(nv, k + l)
+            self.nconv = k
+            if self.monitor:
+                self.monitor(self.its, nconv, self.eigr, self.eigi, self.errest, nv)
+
+    def _solve_default(self):
+        """``EPSSolve_KrylovSchur_Default`` (krylovschur.c:169-288), Ritz extraction."""
+        ds, V = self.ds, self.V
+        self._get_start_vector(0)
+        l = 0
+        while self.reason == ITERATING:
+            self.its += 1
+            nv = min(self.nconv + self.mpd, self.ncv)
+            S = ds.A
+            nv, beta, breakdown = self._basic_arnoldi(S, self.nconv + l, nv)
+            ds.set_dimensions(nv, self.nconv, self.nconv + l)
+            ds.set_state(dsmod.STATE_INTERMEDIATE if l == 0 else dsmod.STATE_RAW)
+            V.set_active_columns(self.nconv, nv)
+
+            ds.solve(self.eigr, self.eigi)
+            ds.sort(self.eigr, self.eigi)
+
+            k = self._krylov_convergence(self.nconv, nv - self.nconv, beta)
+            self.reason = self._stopping(k)
+            nconv = k
+
+            if self.reason != ITERATING or breakdown:
+                l = 0
+            else:
+                l = max(1, int((nv - k) * self.keep))
+                if S[k + l, k + l - 1] != 0.0:
+                    if k + l < nv - 1:
+                        l = l + 1
+                    else:
+                        l = l - 1
+            if not self.lock and l > 0:
+                l += k
+                k = 0
+            if self.reason == ITERATING:
+                if breakdown:
+                    if k < self.nev:
+                        if self._get_start_vector(k):
+                            self.reason = DIVERGED_BREAKDOWN
+                else:
+                    Q = ds.Q
+                    for i in range(k, k + l):
+                        S[k + l, i] = Q[nv - 1, i] * beta
+            Qm = ds.get_mat("Q")
+            V.mult_in_place(Qm, self.nconv, k + l)
+            if self.reason == ITERATING and not breakdown:
+                V.copy_column(nv, k + l)
+            self.nconv = k
+            if self.monitor:
+                self.monitor(self.its, nconv, self.eigr, self.eigi, self.errest, nv)
+        ds.set_dimensions(self.nconv, 0, 0)
+        ds.set_state(dsmod.STATE_RAW)
+
+    def solve(self):
+        """``EPSSolve`` (epssolve.c:63-146)."""
+        self.setup()
+        self.nconv = 0
+        self.its = 0
+        self.reason = ITERATING
+        if self.hermitian:
+            self._solve_symm()
+        else:
+            self._solve_default()
+        self._vectors_done = False
+        # reorder conjugate eigenvalues, positive imaginary part first (:106-120)
+        i = 0
+        while i < self.nconv - 1:
+            if self.eigi[i] != 0:
+                if self.eigi[i] < 0:
+                    self.eigi[i] = -self.eigi[i]
+                    self.eigi[i + 1] = -self.eigi[i + 1]
+                    self.compute_vectors()
+                    self.V.scale_column(i + 1, -1.0)
+                i += 1
+            i += 1
+        self.perm = np.arange(self.ncv + 1)
+        dsmod.sort_eigenvalues(dsmod.COMPARE[self.which], self.nconv, self.eigr, self.eigi,
+                               self.perm)
+        return self
+
+    # -- post-solve ------------------------------------------------------------------
+    def compute_vectors(self):
+        """``EPSComputeVectors`` -> ``EPSComputeVectors_Hermitian`` (no-op for a
+        standard HEP, epsdefault.c:40-74) or ``EPSComputeVectors_Schur``
+        (epsdefault.c:136-205)."""
+        if self._vectors_done:
+            return
+        self._vectors_done = True
+        if self.hermitian:
+            return
+        n = self.ds.n
+        if n == 0:
+            return
+        self.ds.vectors_all()
+        Z = self.ds.get_mat("X")
+        self.V.set_active_columns(0, n)
+        self.V.mult_in_place(Z, 0, n)
+
+    def get_eigenvalue(self, i):
+        """``EPSGetEigenvalue`` (epssolve.c:370-390)."""
+        k = self.perm[i]
+        return self.eigr[k], self.eigi[k]
+
+    def get_eigenvector(self, i):
+        """``EPSGetEigenvector`` (epssolve.c:425-462): returns (xr, xi)."""
+        self.compute_vectors()
+        k = self.perm[i]
+        if self.eigi[k] > 0:
+            return self.V.col(k).copy(), self.V.col(k + 1).copy()
+        if self.eigi[k] < 0:
+            return self.V.col(k - 1).copy(), -self.V.col(k).copy()
+        return self.V.col(k).copy(), np.zeros(self.n)
+
+    def compute_error(self, i, relative=True):
+        """``EPSComputeError`` (epssolve.c:580-649) with
+        ``EPSComputeResidualNorm_Private`` (:506-556)."""
+        kr, ki = self.get_eigenvalue(i)
+        xr, xi = self.get_eigenvector(i)
+        u = np.zeros(self.n)
+
+        def nrm2(v):
+            return float(np.sqrt(self.comm.allreduce_sum(np.array([v @ v]))[0]))
+
+        if ki == 0 or abs(ki) < abs(kr * EPSILON):
+            self.matvec(xr, u)
+            if abs(kr) > EPSILON:
+                u -= kr * xr
+            err = nrm2(u)
+        else:
+            self.matvec(xr, u)
+            if dsmod.abs_eig(kr, ki) > EPSILON:
+                u -= kr * xr
+                u += ki * xi
+            nr = nrm2(u)
+            self.matvec(xi, u)
+            if dsmod.abs_eig(kr, ki) > EPSILON:
+                u -= kr * xi
+                u -= ki * xr
+            ni = nrm2(u)
+            err = dsmod.abs_eig(nr, ni)
+        if relative:
+            err /= dsmod.abs_eig(kr, ki)
+        return err
