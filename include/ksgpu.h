@@ -1,0 +1,173 @@
+/*
+ * ksgpu.h -- C ABI of libksgpu, the MI355X (gfx950) device library behind the
+ * Krylov-Schur hot path: basis-vector (BV) kernels and the CSR operator.
+ *
+ * Every entry point takes plain pointers and sizes and returns an int error
+ * code (0 = success, see KSG_ERR_*); ksg_last_error() gives the message of the
+ * last failure on the calling thread.  Device pointers are raw HIP device
+ * addresses.  All work is enqueued on the context's stream and is in program
+ * order; entry points that return host data (dotvec, norm, dot) have completed
+ * when they return.  One host thread per context; collective entry points must
+ * be called by every rank in the same order.
+ *
+ * Each declaration cites the interface of the reference (SLEPc 3.7.3-dev, paths
+ * relative to the reference root) that it stands in for.
+ */
+#ifndef KSGPU_H
+#define KSGPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define KSG_OK             0
+#define KSG_ERR_ARG        1   /* bad argument (range, NULL, alignment)            */
+#define KSG_ERR_HIP        2   /* a HIP runtime call failed                        */
+#define KSG_ERR_MEM        3   /* host or device allocation failed                 */
+#define KSG_ERR_COMM       4   /* communicator / RCCL failure                      */
+#define KSG_ERR_UNSUPPORTED 5
+
+/* norm types: values of PETSc's NormType as used by BVNorm (bvglobal.c:520-545) */
+#define KSG_NORM_1         0
+#define KSG_NORM_2         1
+#define KSG_NORM_FROBENIUS 2
+#define KSG_NORM_INFINITY  3
+
+typedef struct ksg_ctx_s *ksg_ctx;
+typedef struct ksg_bv_s  *ksg_bv;
+typedef struct ksg_mat_s *ksg_mat;
+
+/* ------------------------------------------------------------------ context */
+
+/* Binds to HIP device `device`, creates the compute and communication streams
+ * and the small pinned/device reduction buffers.  Stands in for the per-process
+ * set-up PETSc does for VECCUDA (SlepcInitialize, src/sys/slepcinit.c:249). */
+int ksg_ctx_create(int device, ksg_ctx *ctx);
+int ksg_ctx_destroy(ksg_ctx ctx);
+/* Blocks until everything enqueued on the context has finished. */
+int ksg_ctx_sync(ksg_ctx ctx);
+/* The HIP stream (hipStream_t) all kernels are launched on. */
+void *ksg_ctx_stream(ksg_ctx ctx);
+const char *ksg_last_error(void);
+
+/* Communicator.  The reference reduces with MPI_Allreduce on PetscObjectComm(bv)
+ * (bvblas.c:260,305; sveccuda.cu:341); here rank r of `nranks` joins an RCCL
+ * communicator built from a 128-byte unique id that rank 0 obtained from
+ * ksg_comm_unique_id() and distributed out of band. */
+int ksg_comm_unique_id(void *id128);
+int ksg_ctx_comm_init_rccl(ksg_ctx ctx, int rank, int nranks, const void *id128);
+/* Alternative transport: the caller supplies the two collectives (used with
+ * torch.distributed, and by the CPU tests).  `buf` is a device pointer when
+ * `on_device` was 1 at registration, otherwise a host pointer. */
+typedef int (*ksg_allreduce_fn)(void *user, double *buf, int count, int op /*0 sum, 1 max*/);
+typedef int (*ksg_exchange_fn)(void *user, const double *sendbuf, const int64_t *sendoff,
+                               double *recvbuf, const int64_t *recvoff);
+int ksg_ctx_comm_init_callbacks(ksg_ctx ctx, int rank, int nranks, int on_device,
+                                ksg_allreduce_fn allreduce, ksg_exchange_fn exchange, void *user);
+int ksg_ctx_comm_rank(ksg_ctx ctx, int *rank, int *nranks);
+
+/* --------------------------------------------------------- device vectors */
+/* The PETSc Vec operations that hot-path host code invokes on BV columns
+ * (VecCopy bvbasic.c:1645, VecAXPY epssolve.c:531, VecNorm epssolve.c:533,
+ * VecDot bvglobal.c:477, VecScale/VecSet epsdefault.c:374,398). */
+int ksg_vec_alloc(ksg_ctx ctx, int64_t n, double **x);
+int ksg_vec_free(ksg_ctx ctx, double *x);
+int ksg_vec_upload(ksg_ctx ctx, double *x_dev, const double *x_host, int64_t n);
+int ksg_vec_download(ksg_ctx ctx, double *x_host, const double *x_dev, int64_t n);
+int ksg_vec_copy(ksg_ctx ctx, const double *x, double *y, int64_t n);
+int ksg_vec_set(ksg_ctx ctx, double *x, double alpha, int64_t n);
+int ksg_vec_scale(ksg_ctx ctx, double *x, double alpha, int64_t n);
+int ksg_vec_axpy(ksg_ctx ctx, double *y, double alpha, const double *x, int64_t n);
+int ksg_vec_dot(ksg_ctx ctx, const double *x, const double *y, int64_t n, double *result); /* collective */
+int ksg_vec_norm2(ksg_ctx ctx, const double *x, int64_t n, double *result);                 /* collective */
+/* x[i] = 2*u(splitmix64(seed ^ (row0+i))) - 1: start vector that depends only on
+ * the global row index (stands in for BVSetRandomColumn, bvops.c:462-479). */
+int ksg_vec_fill_hash(ksg_ctx ctx, double *x, int64_t n, int64_t row0, uint64_t seed);
+
+/* ---------------------------------------------------------------- BV */
+/* Storage as in BVSVEC (svec.c:417-520): column-major, constraints first,
+ * element (r, column j) at base[(nc+j)*ld + r]; ld >= n is padded so that every
+ * column starts on a 256-byte boundary.  Ops act on the active columns [l,k)
+ * (BVSetActiveColumns, bvbasic.c:405-425); l may be -nc. */
+int ksg_bv_create(ksg_ctx ctx, int64_t n_local, int64_t N, int m, ksg_bv *bv);   /* BVCreate_Svec svec.c:417 */
+int ksg_bv_destroy(ksg_bv bv);                                                  /* BVDestroy_Svec svec.c:404 */
+int ksg_bv_resize(ksg_bv bv, int m, int copy);                                  /* BVResize_Svec svec.c:280 */
+int ksg_bv_set_active(ksg_bv bv, int l, int k);
+int ksg_bv_sizes(ksg_bv bv, int64_t *n_local, int64_t *N, int *m, int64_t *ld);
+/* Device address of column j (BVGetColumn_Svec, svec.c:312-324: pv+(nc+j)*n). */
+double *ksg_bv_column(ksg_bv bv, int j);
+/* q[i] = sum_r X[r,l+i]*y[r], i<k-l, summed over ranks; q is a HOST array
+ * (BVDotVec_Svec svec.c:122 -> BVDotVec_BLAS_Private bvblas.c:242). */
+int ksg_bv_dotvec(ksg_bv X, const double *y_dev, double *q_host);
+int ksg_bv_dotvec_local(ksg_bv X, const double *y_dev, double *q_host);          /* svec.c:145 */
+/* y = beta*y + alpha*X(:,l:k)*q; q is a HOST array of k-l coefficients
+ * (BVMultVec_Svec svec.c:51 -> BVMultVec_BLAS_Private bvblas.c:65). */
+int ksg_bv_multvec(ksg_bv X, double alpha, double beta, double *y_dev, const double *q_host);
+/* V(:,s:e) = V(:,l:k)*Q(l:k,s:e) (or Q^T when trans); Q is a HOST column-major
+ * array with leading dimension ldq, indexed absolutely
+ * (BVMultInPlace_Svec svec.c:68 -> BVMultInPlace_BLAS_Private bvblas.c:83). */
+int ksg_bv_multinplace(ksg_bv V, const double *Q_host, int ldq, int s, int e, int trans);
+/* j<0: scale active block, else column j (BVScale_Svec svec.c:165). */
+int ksg_bv_scale(ksg_bv bv, int j, double alpha);
+/* j<0: norm of the active block, else of column j; collective
+ * (BVNorm_Svec svec.c:182 -> BVNorm_LAPACK_Private bvblas.c:290). */
+int ksg_bv_norm(ksg_bv bv, int j, int type, double *val);
+int ksg_bv_norm_local(ksg_bv bv, int j, int type, double *val);                  /* svec.c:199 */
+/* W(:,lw:kw) = V(:,lv:kv) (BVCopy_Svec svec.c:263). */
+int ksg_bv_copy(ksg_bv V, ksg_bv W);
+/* V(:,i) = V(:,j) (BVCopyColumn bvbasic.c:1628: VecCopy on two column views). */
+int ksg_bv_copy_column(ksg_bv V, int j, int i);
+/* Y = beta*Y + alpha*X*Q, Q host array ldq x *, NULL = identity pattern (AXPY)
+ * (BVMult_Svec svec.c:27). */
+int ksg_bv_mult(ksg_bv Y, double alpha, double beta, ksg_bv X, const double *Q_host, int ldq);
+/* M(ly:ky, lx:kx) = Y^T X, M host array with leading dimension ldm; collective
+ * (BVDot_Svec svec.c:102). */
+int ksg_bv_dot(ksg_bv X, ksg_bv Y, double *M_host, int ldm);
+/* W(:,lw+j) = A*V(:,lv+j), column by column (BVMatMult_Svec svec.c:216,250-256). */
+int ksg_bv_matmult(ksg_bv V, ksg_mat A, ksg_bv W);
+
+/* ---------------------------------------------------------------- Mat */
+/* Local row block [row0,row0+n_local) of an N x N CSR ("AIJ") matrix: rowptr has
+ * n_local+1 entries starting at 0, colidx holds GLOBAL column indices.  All
+ * three arrays are host arrays and are copied.  With more than one rank the
+ * matrix is split into the diagonal block and the ghost block and the gather
+ * lists of the halo exchange are built (collective), as MatMPIAIJ does inside
+ * PETSc.  Stands in for MatCreateAIJ + MatSetValues + MatAssembly as used by
+ * the examples (ex2.c:50-66). */
+int ksg_mat_create_csr(ksg_ctx ctx, int64_t n_local, int64_t N, int64_t row0,
+                       const int64_t *rowptr, const int32_t *colidx, const double *val,
+                       ksg_mat *A);
+int ksg_mat_destroy(ksg_mat A);
+/* y = A*x on device vectors of n_local entries; collective when nranks > 1
+ * (MatMult as called by STApply_Shift, shift.c:38). */
+int ksg_mat_mult(ksg_mat A, const double *x_dev, double *y_dev);
+int ksg_mat_sizes(ksg_mat A, int64_t *n_local, int64_t *N, int64_t *row0, int64_t *nnz_local);
+/* Kernel-selection report: number of row tiles handled by the row-per-thread
+ * stream path, the grouped (several lanes per row) path and the long-row path,
+ * and the number of ghost entries received per multiply. */
+int ksg_mat_info(ksg_mat A, int64_t info[4]);
+
+/* --------------------------------------------------------- statistics */
+/* Events, named after the reference's PetscLog events (bvfunc.c:78-93,
+ * stfunc.c:75-82). */
+enum {
+  KSG_EV_DOTVEC = 0, KSG_EV_MULTVEC, KSG_EV_MULTINPLACE, KSG_EV_SCALE, KSG_EV_NORM,
+  KSG_EV_COPY, KSG_EV_MATMULT, KSG_EV_MULT, KSG_EV_DOT, KSG_EV_VECOPS, KSG_EV_COUNT
+};
+typedef struct {
+  int64_t calls[KSG_EV_COUNT];
+  double  bytes[KSG_EV_COUNT];   /* algorithmic bytes moved (model of the byte counts) */
+  double  flops[KSG_EV_COUNT];
+  double  ms[KSG_EV_COUNT];      /* device time from HIP events; 0 unless timing is on */
+} ksg_stats;
+int ksg_stats_enable_timing(ksg_ctx ctx, int on);
+int ksg_stats_get(ksg_ctx ctx, ksg_stats *out);
+int ksg_stats_reset(ksg_ctx ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,209 @@
+/* Communicator of libksgpu: RCCL (loaded at run time, so that single-GPU users
+ * need no RCCL at all) or caller-supplied collectives.
+ *
+ * The reference does every reduction with a host MPI_Allreduce after staging the
+ * data through the host (sveccuda.cu:336-341, bvblas.c:252-260); here the
+ * coefficients stay in device memory, are reduced by RCCL on the compute stream
+ * and only then copied to the pinned host mirror the host logic reads. */
+#include <dlfcn.h>
+
+#include "ksg_internal.h"
+
+/* the few RCCL declarations needed (ABI of rccl.h, NCCL 2.x) */
+typedef struct { char internal[128]; } k_ncclUniqueId;
+typedef void *k_ncclComm_t;
+enum { k_ncclSum = 0, k_ncclMax = 2, k_ncclDouble = 8 };
+
+struct rccl_api {
+  void *handle;
+  int (*GetUniqueId)(k_ncclUniqueId *);
+  int (*CommInitRank)(k_ncclComm_t *, int, k_ncclUniqueId, int);
+  int (*CommDestroy)(k_ncclComm_t);
+  int (*AllReduce)(const void *, void *, size_t, int, int, k_ncclComm_t, hipStream_t);
+  int (*Send)(const void *, size_t, int, int, k_ncclComm_t, hipStream_t);
+  int (*Recv)(void *, size_t, int, int, k_ncclComm_t, hipStream_t);
+  int (*GroupStart)(void);
+  int (*GroupEnd)(void);
+  const char *(*GetErrorString)(int);
+};
+static rccl_api g_rccl = {0};
+
+static int load_rccl(void) {
+  if (g_rccl.handle) return KSG_OK;
+  const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", NULL};
+  void *h = NULL;
+  for (int i = 0; names[i] && !h; i++) h = dlopen(names[i], RTLD_NOW | RTLD_GLOBAL);
+  if (!h) KSG_FAIL(KSG_ERR_COMM, "cannot load RCCL: %s", dlerror());
+#define SYM(field, name) do { *(void **)(&g_rccl.field) = dlsym(h, name); \
+    if (!g_rccl.field) KSG_FAIL(KSG_ERR_COMM, "RCCL symbol %s missing", name); } while (0)
+  SYM(GetUniqueId, "ncclGetUniqueId");
+  SYM(CommInitRank, "ncclCommInitRank");
+  SYM(CommDestroy, "ncclCommDestroy");
+  SYM(AllReduce, "ncclAllReduce");
+  SYM(Send, "ncclSend");
+  SYM(Recv, "ncclRecv");
+  SYM(GroupStart, "ncclGroupStart");
+  SYM(GroupEnd, "ncclGroupEnd");
+  SYM(GetErrorString, "ncclGetErrorString");
+#undef SYM
+  g_rccl.handle = h;
+  return KSG_OK;
+}
+
+#define KSG_NCCL(call) do { int r_ = (call); if (r_ != 0) { \
+    ksg_set_error("%s:%d: %s failed: %s", __FILE__, __LINE__, #call, g_rccl.GetErrorString(r_)); \
+    return KSG_ERR_COMM; } } while (0)
+
+extern "C" int ksg_comm_unique_id(void *id128) {
+  if (!id128) KSG_FAIL(KSG_ERR_ARG, "NULL id buffer");
+  KSG_CHK(load_rccl());
+  k_ncclUniqueId id;
+  KSG_NCCL(g_rccl.GetUniqueId(&id));
+  memcpy(id128, id.internal, 128);
+  return KSG_OK;
+}
+
+extern "C" int ksg_ctx_comm_init_rccl(ksg_ctx c, int rank, int nranks, const void *id128) {
+  if (!c || !id128 || nranks < 1 || rank < 0 || rank >= nranks)
+    KSG_FAIL(KSG_ERR_ARG, "ksg_ctx_comm_init_rccl: bad arguments");
+  if (c->comm_kind != KSG_COMM_NONE) KSG_FAIL(KSG_ERR_ARG, "communicator already set");
+  KSG_CHK(load_rccl());
+  KSG_HIP(hipSetDevice(c->device));
+  k_ncclUniqueId id;
+  memcpy(id.internal, id128, 128);
+  k_ncclComm_t comm = NULL;
+  KSG_NCCL(g_rccl.CommInitRank(&comm, nranks, id, rank));
+  c->rccl_comm = comm;
+  c->comm_kind = KSG_COMM_RCCL;
+  c->rank = rank;
+  c->nranks = nranks;
+  return KSG_OK;
+}
+
+extern "C" int ksg_ctx_comm_init_callbacks(ksg_ctx c, int rank, int nranks, int on_device,
+                                           ksg_allreduce_fn allreduce, ksg_exchange_fn exchange,
+                                           void *user) {
+  if (!c || nranks < 1 || rank < 0 || rank >= nranks || !allreduce || !exchange)
+    KSG_FAIL(KSG_ERR_ARG, "ksg_ctx_comm_init_callbacks: bad arguments");
+  if (c->comm_kind != KSG_COMM_NONE) KSG_FAIL(KSG_ERR_ARG, "communicator already set");
+  c->comm_kind = KSG_COMM_CALLBACKS;
+  c->rank = rank;
+  c->nranks = nranks;
+  c->cb_on_device = on_device ? 1 : 0;
+  c->cb_allreduce = allreduce;
+  c->cb_exchange = exchange;
+  c->cb_user = user;
+  return KSG_OK;
+}
+
+extern "C" int ksg_ctx_comm_rank(ksg_ctx c, int *rank, int *nranks) {
+  if (!c) KSG_FAIL(KSG_ERR_ARG, "NULL context");
+  if (rank) *rank = c->rank;
+  if (nranks) *nranks = c->nranks;
+  return KSG_OK;
+}
+
+int ksg_comm_destroy(ksg_ctx c) {
+  if (c->comm_kind == KSG_COMM_RCCL && c->rccl_comm) g_rccl.CommDestroy(c->rccl_comm);
+  c->rccl_comm = NULL;
+  c->comm_kind = KSG_COMM_NONE;
+  return KSG_OK;
+}
+
+/* Reduce `count` doubles that a kernel left in d_buf (on the compute stream)
+ * over all ranks and deliver them to the host array h_out.  Completed on
+ * return. */
+int ksg_comm_allreduce(ksg_ctx c, double *d_buf, double *h_out, int count, int op) {
+  if (count > KSG_RED_MAX) KSG_FAIL(KSG_ERR_ARG, "reduction of %d values exceeds %d", count, KSG_RED_MAX);
+  if (c->comm_kind == KSG_COMM_RCCL && c->nranks > 1) {
+    KSG_NCCL(g_rccl.AllReduce(d_buf, d_buf, (size_t)count, k_ncclDouble,
+                              op ? k_ncclMax : k_ncclSum, c->rccl_comm, c->stream));
+  } else if (c->comm_kind == KSG_COMM_CALLBACKS && c->nranks > 1 && c->cb_on_device) {
+    KSG_HIP(hipStreamSynchronize(c->stream));
+    if (c->cb_allreduce(c->cb_user, d_buf, count, op))
+      KSG_FAIL(KSG_ERR_COMM, "allreduce callback failed");
+  }
+  KSG_HIP(hipMemcpyAsync(c->h_red, d_buf, (size_t)count * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  KSG_HIP(hipStreamSynchronize(c->stream));
+  if (c->comm_kind == KSG_COMM_CALLBACKS && c->nranks > 1 && !c->cb_on_device) {
+    if (c->cb_allreduce(c->cb_user, c->h_red, count, op))
+      KSG_FAIL(KSG_ERR_COMM, "allreduce callback failed");
+  }
+  memcpy(h_out, c->h_red, (size_t)count * sizeof(double));
+  return KSG_OK;
+}
+
+/* Host-side reduction used while a matrix is being set up. */
+int ksg_comm_allreduce_host(ksg_ctx c, double *h_buf, int count, int op) {
+  if (c->nranks <= 1) return KSG_OK;
+  if (count > KSG_RED_MAX) KSG_FAIL(KSG_ERR_ARG, "reduction of %d values exceeds %d", count, KSG_RED_MAX);
+  if (c->comm_kind == KSG_COMM_CALLBACKS && !c->cb_on_device) {
+    if (c->cb_allreduce(c->cb_user, h_buf, count, op)) KSG_FAIL(KSG_ERR_COMM, "allreduce callback failed");
+    return KSG_OK;
+  }
+  KSG_HIP(hipMemcpyAsync(c->d_red, h_buf, (size_t)count * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  KSG_CHK(ksg_comm_allreduce(c, c->d_red, h_buf, count, op));
+  return KSG_OK;
+}
+
+/* All-to-all-v of doubles between device buffers, on `stream`. */
+static int exchange_device(ksg_ctx c, const double *send, const int64_t *sendoff, double *recv,
+                           const int64_t *recvoff, hipStream_t stream) {
+  if (c->comm_kind == KSG_COMM_RCCL) {
+    KSG_NCCL(g_rccl.GroupStart());
+    for (int p = 0; p < c->nranks; p++) {
+      int64_t ns = sendoff[p + 1] - sendoff[p], nr = recvoff[p + 1] - recvoff[p];
+      if (ns > 0) KSG_NCCL(g_rccl.Send(send + sendoff[p], (size_t)ns, k_ncclDouble, p, c->rccl_comm, stream));
+      if (nr > 0) KSG_NCCL(g_rccl.Recv(recv + recvoff[p], (size_t)nr, k_ncclDouble, p, c->rccl_comm, stream));
+    }
+    KSG_NCCL(g_rccl.GroupEnd());
+    return KSG_OK;
+  }
+  /* device-pointer callbacks: make the packed data visible, then hand over */
+  KSG_HIP(hipStreamSynchronize(stream));
+  if (c->cb_exchange(c->cb_user, send, sendoff, recv, recvoff))
+    KSG_FAIL(KSG_ERR_COMM, "exchange callback failed");
+  return KSG_OK;
+}
+
+/* Halo exchange of one multiply: A->d_send has been packed on the comm stream. */
+int ksg_comm_exchange(ksg_ctx c, ksg_mat A) {
+  if (c->nranks <= 1) return KSG_OK;
+  if (c->comm_kind == KSG_COMM_CALLBACKS && !c->cb_on_device) {
+    if (A->nsend)
+      KSG_HIP(hipMemcpyAsync(A->h_send, A->d_send, (size_t)A->nsend * sizeof(double), hipMemcpyDeviceToHost, c->comm_stream));
+    KSG_HIP(hipStreamSynchronize(c->comm_stream));
+    if (c->cb_exchange(c->cb_user, A->h_send, A->sendoff.data(), A->h_ghost, A->recvoff.data()))
+      KSG_FAIL(KSG_ERR_COMM, "exchange callback failed");
+    if (A->nghost)
+      KSG_HIP(hipMemcpyAsync(A->d_ghost, A->h_ghost, (size_t)A->nghost * sizeof(double), hipMemcpyHostToDevice, c->comm_stream));
+    return KSG_OK;
+  }
+  return exchange_device(c, A->d_send, A->sendoff.data(), A->d_ghost, A->recvoff.data(), c->comm_stream);
+}
+
+/* Set-up time exchange of host arrays (index lists encoded as doubles). */
+int ksg_comm_exchange_host(ksg_ctx c, const double *send, const int64_t *sendoff, double *recv,
+                           const int64_t *recvoff) {
+  int P = c->nranks;
+  if (P <= 1) return KSG_OK;
+  if (c->comm_kind == KSG_COMM_CALLBACKS && !c->cb_on_device) {
+    if (c->cb_exchange(c->cb_user, send, sendoff, recv, recvoff))
+      KSG_FAIL(KSG_ERR_COMM, "exchange callback failed");
+    return KSG_OK;
+  }
+  int64_t ns = sendoff[P], nr = recvoff[P];
+  double *ds = NULL, *dr = NULL;
+  KSG_HIP(hipMalloc(&ds, (size_t)(ns > 0 ? ns : 1) * sizeof(double)));
+  KSG_HIP(hipMalloc(&dr, (size_t)(nr > 0 ? nr : 1) * sizeof(double)));
+  if (ns) KSG_HIP(hipMemcpyAsync(ds, send, (size_t)ns * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  int rc = exchange_device(c, ds, sendoff, dr, recvoff, c->stream);
+  if (!rc && nr) {
+    hipError_t e = hipMemcpyAsync(recv, dr, (size_t)nr * sizeof(double), hipMemcpyDeviceToHost, c->stream);
+    if (e != hipSuccess) { ksg_set_error("halo set-up copy failed: %s", hipGetErrorString(e)); rc = KSG_ERR_HIP; }
+  }
+  hipStreamSynchronize(c->stream);
+  hipFree(ds);
+  hipFree(dr);
+  return rc;
+}

@@ -1,0 +1,157 @@
+/* Context, error reporting, workspaces and per-event statistics of libksgpu. */
+#include <stdarg.h>
+#include <stdlib.h>
+
+#include "ksg_internal.h"
+
+static thread_local char g_err[512] = "";
+
+void ksg_set_error(const char *fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+extern "C" const char *ksg_last_error(void) { return g_err; }
+
+extern "C" int ksg_ctx_create(int device, ksg_ctx *out) {
+  if (!out) KSG_FAIL(KSG_ERR_ARG, "ksg_ctx_create: NULL output");
+  int ndev = 0;
+  KSG_HIP(hipGetDeviceCount(&ndev));
+  if (device < 0 || device >= ndev)
+    KSG_FAIL(KSG_ERR_ARG, "ksg_ctx_create: device %d out of range (%d visible)", device, ndev);
+  KSG_HIP(hipSetDevice(device));
+  ksg_ctx c = new (std::nothrow) ksg_ctx_s();
+  if (!c) KSG_FAIL(KSG_ERR_MEM, "ksg_ctx_create: out of host memory");
+  c->device = device;
+  c->comm_kind = KSG_COMM_NONE;
+  c->rank = 0;
+  c->nranks = 1;
+  c->rccl_comm = NULL;
+  c->d_partial = NULL; c->partial_cap = 0;
+  c->d_q = NULL; c->q_cap = 0;
+  c->d_work = NULL; c->work_cap = 0;
+  c->timing = 0;
+  memset(&c->stats, 0, sizeof(c->stats));
+  KSG_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  KSG_HIP(hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking));
+  KSG_HIP(hipEventCreateWithFlags(&c->ev_x_ready, hipEventDisableTiming));
+  KSG_HIP(hipEventCreateWithFlags(&c->ev_halo_done, hipEventDisableTiming));
+  KSG_HIP(hipMalloc(&c->d_red, KSG_RED_MAX * sizeof(double)));
+  KSG_HIP(hipHostMalloc(&c->h_red, KSG_RED_MAX * sizeof(double), hipHostMallocDefault));
+  *out = c;
+  return KSG_OK;
+}
+
+extern "C" int ksg_ctx_sync(ksg_ctx c) {
+  if (!c) KSG_FAIL(KSG_ERR_ARG, "ksg_ctx_sync: NULL context");
+  KSG_HIP(hipSetDevice(c->device));
+  KSG_HIP(hipStreamSynchronize(c->comm_stream));
+  KSG_HIP(hipStreamSynchronize(c->stream));
+  return KSG_OK;
+}
+
+extern "C" void *ksg_ctx_stream(ksg_ctx c) { return c ? (void *)c->stream : NULL; }
+
+int ksg_comm_destroy(ksg_ctx c);
+
+extern "C" int ksg_ctx_destroy(ksg_ctx c) {
+  if (!c) return KSG_OK;
+  hipSetDevice(c->device);
+  hipStreamSynchronize(c->comm_stream);
+  hipStreamSynchronize(c->stream);
+  ksg_comm_destroy(c);
+  for (auto &t : c->pending) { hipEventDestroy(t.e0); hipEventDestroy(t.e1); }
+  for (auto &e : c->event_pool) hipEventDestroy(e);
+  if (c->d_partial) hipFree(c->d_partial);
+  if (c->d_q) hipFree(c->d_q);
+  if (c->d_work) hipFree(c->d_work);
+  hipFree(c->d_red);
+  hipHostFree(c->h_red);
+  hipEventDestroy(c->ev_x_ready);
+  hipEventDestroy(c->ev_halo_done);
+  hipStreamDestroy(c->comm_stream);
+  hipStreamDestroy(c->stream);
+  delete c;
+  return KSG_OK;
+}
+
+static int ensure(ksg_ctx c, double **p, size_t *cap, size_t doubles) {
+  if (*cap >= doubles) return KSG_OK;
+  KSG_HIP(hipStreamSynchronize(c->stream));
+  if (*p) KSG_HIP(hipFree(*p));
+  *p = NULL; *cap = 0;
+  size_t want = doubles + doubles / 4 + 1024;
+  hipError_t e = hipMalloc(p, want * sizeof(double));
+  if (e != hipSuccess) KSG_FAIL(KSG_ERR_MEM, "device workspace of %zu bytes: %s", want * sizeof(double), hipGetErrorString(e));
+  *cap = want;
+  return KSG_OK;
+}
+int ksg_ensure_partial(ksg_ctx c, size_t d) { return ensure(c, &c->d_partial, &c->partial_cap, d); }
+int ksg_ensure_q(ksg_ctx c, size_t d) { return ensure(c, &c->d_q, &c->q_cap, d); }
+int ksg_ensure_work(ksg_ctx c, size_t d) { return ensure(c, &c->d_work, &c->work_cap, d); }
+
+/* ---- statistics ------------------------------------------------------- */
+static int get_event(ksg_ctx c, hipEvent_t *e) {
+  if (!c->event_pool.empty()) { *e = c->event_pool.back(); c->event_pool.pop_back(); return KSG_OK; }
+  KSG_HIP(hipEventCreate(e));
+  return KSG_OK;
+}
+
+static int drain_timers(ksg_ctx c) {
+  for (auto &t : c->pending) {
+    float ms = 0.f;
+    KSG_HIP(hipEventSynchronize(t.e1));
+    KSG_HIP(hipEventElapsedTime(&ms, t.e0, t.e1));
+    c->stats.ms[t.ev] += ms;
+    c->event_pool.push_back(t.e0);
+    c->event_pool.push_back(t.e1);
+  }
+  c->pending.clear();
+  return KSG_OK;
+}
+
+int ksg_op_begin(ksg_ctx c, int ev) {
+  KSG_HIP(hipSetDevice(c->device));
+  if (c->timing) {
+    ksg_timer t; t.ev = ev;
+    KSG_CHK(get_event(c, &t.e0));
+    KSG_CHK(get_event(c, &t.e1));
+    KSG_HIP(hipEventRecord(t.e0, c->stream));
+    c->pending.push_back(t);
+  }
+  return KSG_OK;
+}
+
+int ksg_op_end(ksg_ctx c, int ev, double bytes, double flops) {
+  c->stats.calls[ev] += 1;
+  c->stats.bytes[ev] += bytes;
+  c->stats.flops[ev] += flops;
+  if (c->timing) {
+    KSG_HIP(hipEventRecord(c->pending.back().e1, c->stream));
+    if (c->pending.size() > 4096) KSG_CHK(drain_timers(c));
+  }
+  return KSG_OK;
+}
+
+extern "C" int ksg_stats_enable_timing(ksg_ctx c, int on) {
+  if (!c) KSG_FAIL(KSG_ERR_ARG, "NULL context");
+  if (!on) KSG_CHK(drain_timers(c));
+  c->timing = on ? 1 : 0;
+  return KSG_OK;
+}
+
+extern "C" int ksg_stats_get(ksg_ctx c, ksg_stats *out) {
+  if (!c || !out) KSG_FAIL(KSG_ERR_ARG, "NULL argument");
+  KSG_CHK(drain_timers(c));
+  *out = c->stats;
+  return KSG_OK;
+}
+
+extern "C" int ksg_stats_reset(ksg_ctx c) {
+  if (!c) KSG_FAIL(KSG_ERR_ARG, "NULL context");
+  KSG_CHK(drain_timers(c));
+  memset(&c->stats, 0, sizeof(c->stats));
+  return KSG_OK;
+}

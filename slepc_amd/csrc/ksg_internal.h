@@ -1,0 +1,121 @@
+/* Internal declarations shared by the translation units of libksgpu. */
+#ifndef KSG_INTERNAL_H
+#define KSG_INTERNAL_H
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include <vector>
+
+#include "ksgpu.h"
+
+#define KSG_BLOCK      256          /* threads per workgroup (4 wave64)            */
+#define KSG_MAXGRID    2048         /* 256 CUs x 8 workgroups: grid-stride beyond   */
+#define KSG_QMAX       128          /* coefficients passed by value to one launch   */
+#define KSG_RED_MAX    8192         /* doubles in the reduction buffers             */
+
+void ksg_set_error(const char *fmt, ...);
+
+#define KSG_FAIL(code, ...) do { ksg_set_error(__VA_ARGS__); return (code); } while (0)
+#define KSG_HIP(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { \
+    ksg_set_error("%s:%d: %s failed: %s", __FILE__, __LINE__, #call, hipGetErrorString(e_)); \
+    return KSG_ERR_HIP; } } while (0)
+#define KSG_CHK(call) do { int r_ = (call); if (r_) return r_; } while (0)
+
+enum { KSG_COMM_NONE = 0, KSG_COMM_RCCL = 1, KSG_COMM_CALLBACKS = 2 };
+
+struct ksg_timer { hipEvent_t e0, e1; int ev; };
+
+struct ksg_ctx_s {
+  int device;
+  hipStream_t stream;        /* compute */
+  hipStream_t comm_stream;   /* halo pack + exchange */
+  hipEvent_t ev_x_ready, ev_halo_done;
+  double *d_red;             /* device reduction buffer, KSG_RED_MAX doubles */
+  double *h_red;             /* pinned host mirror */
+  double *d_partial;         /* per-workgroup partial sums */
+  size_t partial_cap;        /* doubles */
+  double *d_q;               /* device copy of small host matrices (Q for multinplace) */
+  size_t q_cap;
+  double *d_work;            /* scratch panel for out-of-place fallbacks */
+  size_t work_cap;
+  /* communicator */
+  int comm_kind, rank, nranks, cb_on_device;
+  void *rccl_comm;
+  ksg_allreduce_fn cb_allreduce;
+  ksg_exchange_fn cb_exchange;
+  void *cb_user;
+  /* statistics */
+  ksg_stats stats;
+  int timing;
+  std::vector<ksg_timer> pending;
+  std::vector<hipEvent_t> event_pool;
+};
+
+struct ksg_bv_s {
+  ksg_ctx ctx;
+  int64_t n, N, ld;
+  int m, nc, l, k;
+  double *d;
+};
+
+/* one CSR block on the device, with its row tiles */
+struct ksg_csr_dev {
+  int64_t nrows, nnz;
+  int64_t *rowptr;   /* nrows+1 */
+  int32_t *colidx;
+  double *val;
+  int32_t *tiles;    /* ntiles+1 row boundaries */
+  int64_t ntiles;
+  int64_t n_stream, n_group, n_long;
+};
+
+struct ksg_mat_s {
+  ksg_ctx ctx;
+  int64_t n, N, row0, nnz;
+  ksg_csr_dev diag;          /* columns local (col - row0)                     */
+  /* ghost block: only rows that have ghost entries */
+  int64_t no_rows;           /* number of such rows                            */
+  int32_t *o_rows;           /* their local row indices                        */
+  int64_t *o_rowptr;
+  int32_t *o_colidx;         /* index into the ghost buffer                    */
+  double *o_val;
+  int64_t o_nnz;
+  /* halo plan */
+  int64_t nghost, nsend;
+  double *d_ghost, *d_send;  /* device staging buffers                         */
+  double *h_ghost, *h_send;  /* pinned host staging (callback transport)       */
+  int32_t *d_send_idx;       /* local indices to gather into d_send            */
+  std::vector<int64_t> sendoff, recvoff;   /* nranks+1 each                    */
+};
+
+/* statistics / timing brackets */
+int ksg_op_begin(ksg_ctx ctx, int ev);
+int ksg_op_end(ksg_ctx ctx, int ev, double bytes, double flops);
+
+/* communicator primitives (ksg_comm.hip) */
+int ksg_comm_allreduce(ksg_ctx ctx, double *d_buf, double *h_out, int count, int op);
+int ksg_comm_exchange(ksg_ctx ctx, ksg_mat A);
+int ksg_comm_allreduce_host(ksg_ctx ctx, double *h_buf, int count, int op);
+int ksg_comm_exchange_host(ksg_ctx ctx, const double *send, const int64_t *sendoff,
+                           double *recv, const int64_t *recvoff);
+
+/* workspace helpers */
+int ksg_ensure_partial(ksg_ctx ctx, size_t doubles);
+int ksg_ensure_q(ksg_ctx ctx, size_t doubles);
+int ksg_ensure_work(ksg_ctx ctx, size_t doubles);
+
+/* reductions used by several files: sum over `nb` partials per column */
+int ksg_launch_dotvec(ksg_ctx ctx, const double *X, int64_t ld, int k, const double *y,
+                      int64_t n, double *d_out);
+int ksg_launch_sumsq(ksg_ctx ctx, const double *X, int64_t ld, int ncols, int64_t n, double *d_out);
+
+static inline int ksg_grid_for(int64_t work_items) {
+  int64_t g = (work_items + KSG_BLOCK - 1) / KSG_BLOCK;
+  if (g < 1) g = 1;
+  if (g > KSG_MAXGRID) g = KSG_MAXGRID;
+  return (int)g;
+}
+
+#endif

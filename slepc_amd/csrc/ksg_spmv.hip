@@ -1,0 +1,375 @@
+/* CSR operator: y = A x, the MatMult that STApply_Shift issues once per Krylov
+ * step (src/sys/classes/st/impls/shift/shift.c:38).  In the reference this is
+ * PETSc's MatMult_SeqAIJ / MatMult_MPIAIJ (or cuSPARSE); here it is a
+ * hand-written gfx950 kernel family selected per row tile by nnz/row:
+ *
+ *   stream tile  : up to KSG_TILE_ROWS consecutive rows whose entries fit one LDS
+ *                  tile.  The workgroup streams val/colidx of the whole tile
+ *                  with coalesced loads, gathers x through L2, parks the
+ *                  products in LDS, then
+ *                    - many short rows: one lane per row sums its products in
+ *                      storage order (bit-identical to a sequential CSR loop);
+ *                    - few longer rows: a power-of-two group of lanes per row
+ *                      sums strided and combines with wave shuffles;
+ *   long row     : a row longer than one LDS tile gets the whole workgroup.
+ *
+ * With several ranks the matrix is split like PETSc's MPIAIJ into the diagonal
+ * block (local columns) and the ghost block; the ghost values are gathered,
+ * exchanged on the communication stream while the diagonal block is multiplied
+ * on the compute stream, and then the ghost block is added. */
+#include <algorithm>
+
+#include "ksg_internal.h"
+
+#define KSG_TILE_NNZ  2048     /* products held in LDS per workgroup (16 KiB)   */
+#define KSG_TILE_ROWS 256      /* rows per stream tile = threads per workgroup  */
+
+__device__ __forceinline__ double wave_sum_width(double v, int width) {
+  for (int off = width >> 1; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return v;
+}
+
+__global__ __launch_bounds__(KSG_BLOCK) void k_spmv_tiles(const int32_t *__restrict__ tiles,
+                                                           const int64_t *__restrict__ rowptr,
+                                                           const int32_t *__restrict__ colidx,
+                                                           const double *__restrict__ val,
+                                                           const double *__restrict__ x,
+                                                           double *__restrict__ y) {
+  __shared__ double prod[KSG_TILE_NNZ];
+  __shared__ double red[KSG_BLOCK / 64];
+  const int r0 = tiles[blockIdx.x], r1 = tiles[blockIdx.x + 1];
+  const int nrows = r1 - r0;
+  const int64_t p0 = rowptr[r0], p1 = rowptr[r1];
+  const int64_t nnz = p1 - p0;
+
+  if (nnz > KSG_TILE_NNZ) {
+    /* long row (nrows == 1): the whole workgroup strides over it */
+    double a = 0.0;
+    for (int64_t p = p0 + threadIdx.x; p < p1; p += KSG_BLOCK) a = fma(val[p], x[colidx[p]], a);
+    a = wave_sum_width(a, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = a;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      double s = red[0];
+#pragma unroll
+      for (int w = 1; w < KSG_BLOCK / 64; w++) s += red[w];
+      y[r0] = s;
+    }
+    return;
+  }
+
+  /* stream the tile's entries: coalesced val/colidx, x gathered through L2 */
+  for (int t = threadIdx.x; t < (int)nnz; t += KSG_BLOCK) prod[t] = val[p0 + t] * x[colidx[p0 + t]];
+  __syncthreads();
+
+  if (nrows > KSG_BLOCK / 2) {
+    /* one lane per row, products added in storage order */
+    if ((int)threadIdx.x < nrows) {
+      const int r = r0 + threadIdx.x;
+      const int b = (int)(rowptr[r] - p0), e = (int)(rowptr[r + 1] - p0);
+      double s = 0.0;
+      for (int t = b; t < e; t++) s += prod[t];
+      y[r] = s;
+    }
+  } else {
+    /* G lanes per row, G = largest power of two with nrows*G <= 256 (at most 64) */
+    int G = 2;
+    while (G < 64 && nrows * (G << 1) <= KSG_BLOCK) G <<= 1;
+    const int lr = threadIdx.x / G, g = threadIdx.x % G;
+    double s = 0.0;
+    if (lr < nrows) {
+      const int r = r0 + lr;
+      const int b = (int)(rowptr[r] - p0), e = (int)(rowptr[r + 1] - p0);
+      for (int t = b + g; t < e; t += G) s += prod[t];
+    }
+    s = wave_sum_width(s, G);
+    if (lr < nrows && g == 0) y[r0 + lr] = s;
+  }
+}
+
+/* ghost block: y[rows[i]] += sum of its ghost entries (few rows, thread per row) */
+__global__ __launch_bounds__(KSG_BLOCK) void k_spmv_ghost_add(int64_t nrows, const int32_t *__restrict__ rows,
+                                                               const int64_t *__restrict__ rowptr,
+                                                               const int32_t *__restrict__ colidx,
+                                                               const double *__restrict__ val,
+                                                               const double *__restrict__ xg,
+                                                               double *__restrict__ y) {
+  const int64_t stride = (int64_t)gridDim.x * KSG_BLOCK;
+  for (int64_t i = (int64_t)blockIdx.x * KSG_BLOCK + threadIdx.x; i < nrows; i += stride) {
+    double s = 0.0;
+    for (int64_t p = rowptr[i]; p < rowptr[i + 1]; p++) s = fma(val[p], xg[colidx[p]], s);
+    y[rows[i]] += s;
+  }
+}
+
+__global__ __launch_bounds__(KSG_BLOCK) void k_gather(const double *__restrict__ x, const int32_t *__restrict__ idx,
+                                                       double *__restrict__ out, int64_t n) {
+  const int64_t stride = (int64_t)gridDim.x * KSG_BLOCK;
+  for (int64_t i = (int64_t)blockIdx.x * KSG_BLOCK + threadIdx.x; i < n; i += stride) out[i] = x[idx[i]];
+}
+
+/* ------------------------------------------------------------------------ */
+/* host side: tiling, upload, halo plan                                       */
+/* ------------------------------------------------------------------------ */
+static void build_tiles(int64_t nrows, const int64_t *rowptr, std::vector<int32_t> &tiles,
+                        int64_t *n_stream, int64_t *n_group, int64_t *n_long) {
+  tiles.clear();
+  tiles.push_back(0);
+  *n_stream = *n_group = *n_long = 0;
+  int64_t r = 0;
+  while (r < nrows) {
+    int64_t e = r;
+    const int64_t base = rowptr[r];
+    while (e < nrows && e - r < KSG_TILE_ROWS && rowptr[e + 1] - base <= KSG_TILE_NNZ) e++;
+    if (e == r) { e = r + 1; (*n_long)++; }          /* a single row longer than the tile */
+    else if (e - r > KSG_BLOCK / 2) (*n_stream)++;
+    else (*n_group)++;
+    tiles.push_back((int32_t)e);
+    r = e;
+  }
+}
+
+template <class T>
+static int upload(T **dst, const T *src, size_t count) {
+  *dst = NULL;
+  hipError_t e = hipMalloc((void **)dst, (count ? count : 1) * sizeof(T));
+  if (e != hipSuccess) KSG_FAIL(KSG_ERR_MEM, "matrix upload: %zu bytes: %s", count * sizeof(T), hipGetErrorString(e));
+  if (count) KSG_HIP(hipMemcpy(*dst, src, count * sizeof(T), hipMemcpyHostToDevice));
+  return KSG_OK;
+}
+
+static int csr_to_device(ksg_csr_dev *D, int64_t nrows, const int64_t *rowptr, const int32_t *colidx,
+                         const double *val) {
+  D->nrows = nrows;
+  D->nnz = rowptr[nrows];
+  std::vector<int32_t> tiles;
+  build_tiles(nrows, rowptr, tiles, &D->n_stream, &D->n_group, &D->n_long);
+  D->ntiles = (int64_t)tiles.size() - 1;
+  KSG_CHK(upload(&D->rowptr, rowptr, (size_t)nrows + 1));
+  KSG_CHK(upload(&D->colidx, colidx, (size_t)D->nnz));
+  KSG_CHK(upload(&D->val, val, (size_t)D->nnz));
+  KSG_CHK(upload(&D->tiles, tiles.data(), tiles.size()));
+  return KSG_OK;
+}
+
+static void csr_free(ksg_csr_dev *D) {
+  if (D->rowptr) hipFree(D->rowptr);
+  if (D->colidx) hipFree(D->colidx);
+  if (D->val) hipFree(D->val);
+  if (D->tiles) hipFree(D->tiles);
+  memset(D, 0, sizeof(*D));
+}
+
+static int validate_csr(int64_t n, int64_t N, const int64_t *rowptr, const int32_t *colidx) {
+  if (rowptr[0] != 0) KSG_FAIL(KSG_ERR_ARG, "ksg_mat_create_csr: rowptr[0] must be 0");
+  for (int64_t i = 0; i < n; i++)
+    if (rowptr[i + 1] < rowptr[i]) KSG_FAIL(KSG_ERR_ARG, "ksg_mat_create_csr: rowptr decreases at row %lld", (long long)i);
+  const int64_t nnz = rowptr[n];
+  for (int64_t p = 0; p < nnz; p++)
+    if (colidx[p] < 0 || (int64_t)colidx[p] >= N)
+      KSG_FAIL(KSG_ERR_ARG, "ksg_mat_create_csr: column index %d out of range at entry %lld", colidx[p], (long long)p);
+  return KSG_OK;
+}
+
+extern "C" int ksg_mat_create_csr(ksg_ctx c, int64_t n, int64_t N, int64_t row0, const int64_t *rowptr,
+                                  const int32_t *colidx, const double *val, ksg_mat *out) {
+  if (!c || !out || !rowptr || n < 0 || N < n || row0 < 0 || row0 + n > N)
+    KSG_FAIL(KSG_ERR_ARG, "ksg_mat_create_csr: bad arguments");
+  if (N > (int64_t)INT32_MAX) KSG_FAIL(KSG_ERR_UNSUPPORTED, "ksg_mat_create_csr: N exceeds 32-bit column indices");
+  if (rowptr[n] > 0 && (!colidx || !val)) KSG_FAIL(KSG_ERR_ARG, "ksg_mat_create_csr: NULL arrays");
+  KSG_CHK(validate_csr(n, N, rowptr, colidx));
+  KSG_HIP(hipSetDevice(c->device));
+  ksg_mat A = new (std::nothrow) ksg_mat_s();
+  if (!A) KSG_FAIL(KSG_ERR_MEM, "ksg_mat_create_csr: out of host memory");
+  A->ctx = c; A->n = n; A->N = N; A->row0 = row0; A->nnz = rowptr[n];
+  memset(&A->diag, 0, sizeof(A->diag));
+  A->no_rows = 0; A->o_rows = NULL; A->o_rowptr = NULL; A->o_colidx = NULL; A->o_val = NULL; A->o_nnz = 0;
+  A->nghost = A->nsend = 0;
+  A->d_ghost = A->d_send = A->h_ghost = A->h_send = NULL; A->d_send_idx = NULL;
+  const int P = c->nranks;
+  int rc = KSG_OK;
+
+  if (P == 1) {
+    if (row0 != 0 || n != N) { delete A; KSG_FAIL(KSG_ERR_ARG, "ksg_mat_create_csr: one rank must own all rows"); }
+    rc = csr_to_device(&A->diag, n, rowptr, colidx, val);
+    if (rc) { csr_free(&A->diag); delete A; return rc; }
+    *out = A;
+    return KSG_OK;
+  }
+
+  /* ---- several ranks: ownership ranges (allgather through a zero-padded sum) ---- */
+  std::vector<double> starts((size_t)P + 1, 0.0);
+  starts[c->rank] = (double)row0;
+  if (c->rank == P - 1) starts[P] = (double)(row0 + n);
+  rc = ksg_comm_allreduce_host(c, starts.data(), P + 1, 0);
+  if (rc) { delete A; return rc; }
+  std::vector<int64_t> rs((size_t)P + 1);
+  for (int p = 0; p <= P; p++) rs[p] = (int64_t)starts[p];
+  if (rs[0] != 0 || rs[P] != N) { delete A; KSG_FAIL(KSG_ERR_ARG, "ksg_mat_create_csr: row blocks do not tile [0,N)"); }
+  for (int p = 0; p < P; p++) if (rs[p + 1] < rs[p]) { delete A; KSG_FAIL(KSG_ERR_ARG, "ksg_mat_create_csr: row blocks are not ordered by rank"); }
+
+  /* ---- split into diagonal and ghost block ---- */
+  const int64_t nnz = rowptr[n];
+  const int64_t lo = row0, hi = row0 + n;
+  std::vector<int64_t> d_rp((size_t)n + 1, 0), o_rp;
+  std::vector<int32_t> d_ci, o_ci, o_rows;
+  std::vector<double> d_v, o_v;
+  d_ci.reserve((size_t)nnz); d_v.reserve((size_t)nnz);
+  std::vector<int32_t> ghosts;                    /* global indices, later sorted unique */
+  o_rp.push_back(0);
+  for (int64_t i = 0; i < n; i++) {
+    bool has = false;
+    for (int64_t p = rowptr[i]; p < rowptr[i + 1]; p++) {
+      const int64_t cg = colidx[p];
+      if (cg >= lo && cg < hi) { d_ci.push_back((int32_t)(cg - lo)); d_v.push_back(val[p]); }
+      else { o_ci.push_back((int32_t)cg); o_v.push_back(val[p]); ghosts.push_back((int32_t)cg); has = true; }
+    }
+    d_rp[i + 1] = (int64_t)d_ci.size();
+    if (has) { o_rows.push_back((int32_t)i); o_rp.push_back((int64_t)o_ci.size()); }
+  }
+  std::sort(ghosts.begin(), ghosts.end());
+  ghosts.erase(std::unique(ghosts.begin(), ghosts.end()), ghosts.end());
+  for (size_t p = 0; p < o_ci.size(); p++)
+    o_ci[p] = (int32_t)(std::lower_bound(ghosts.begin(), ghosts.end(), o_ci[p]) - ghosts.begin());
+  A->nghost = (int64_t)ghosts.size();
+
+  /* ---- who owns my ghosts: receive offsets (ghosts are sorted, so grouped by owner) ---- */
+  A->recvoff.assign((size_t)P + 1, 0);
+  {
+    size_t g = 0;
+    for (int p = 0; p < P; p++) {
+      A->recvoff[p] = (int64_t)g;
+      while (g < ghosts.size() && (int64_t)ghosts[g] < rs[p + 1]) g++;
+    }
+    A->recvoff[P] = (int64_t)ghosts.size();
+  }
+  /* ---- counts matrix (all-to-all of counts through a sum) ---- */
+  if ((size_t)P * P > KSG_RED_MAX) { delete A; KSG_FAIL(KSG_ERR_UNSUPPORTED, "ksg_mat_create_csr: too many ranks"); }
+  std::vector<double> counts((size_t)P * P, 0.0);
+  for (int p = 0; p < P; p++) counts[(size_t)c->rank * P + p] = (double)(A->recvoff[p + 1] - A->recvoff[p]);
+  rc = ksg_comm_allreduce_host(c, counts.data(), P * P, 0);
+  if (rc) { delete A; return rc; }
+  A->sendoff.assign((size_t)P + 1, 0);
+  for (int p = 0; p < P; p++) A->sendoff[p + 1] = A->sendoff[p] + (int64_t)counts[(size_t)p * P + c->rank];
+  A->nsend = A->sendoff[P];
+
+  /* ---- tell the owners which of their entries I need (indices travel as doubles) ---- */
+  std::vector<double> want((size_t)std::max<int64_t>(A->nghost, 1)), asked((size_t)std::max<int64_t>(A->nsend, 1));
+  for (int64_t g = 0; g < A->nghost; g++) want[g] = (double)ghosts[g];
+  rc = ksg_comm_exchange_host(c, want.data(), A->recvoff.data(), asked.data(), A->sendoff.data());
+  if (rc) { delete A; return rc; }
+  std::vector<int32_t> send_idx((size_t)std::max<int64_t>(A->nsend, 1));
+  for (int64_t i = 0; i < A->nsend; i++) {
+    const int64_t gidx = (int64_t)asked[i];
+    if (gidx < lo || gidx >= hi) { delete A; KSG_FAIL(KSG_ERR_COMM, "halo plan: rank asked for row %lld that is not mine", (long long)gidx); }
+    send_idx[i] = (int32_t)(gidx - lo);
+  }
+
+  /* ---- upload ---- */
+  rc = csr_to_device(&A->diag, n, d_rp.data(), d_ci.data(), d_v.data());
+  A->no_rows = (int64_t)o_rows.size();
+  A->o_nnz = (int64_t)o_ci.size();
+  if (!rc) rc = upload(&A->o_rows, o_rows.data(), o_rows.size());
+  if (!rc) rc = upload(&A->o_rowptr, o_rp.data(), o_rp.size());
+  if (!rc) rc = upload(&A->o_colidx, o_ci.data(), o_ci.size());
+  if (!rc) rc = upload(&A->o_val, o_v.data(), o_v.size());
+  if (!rc) rc = upload(&A->d_send_idx, send_idx.data(), (size_t)A->nsend);
+  if (!rc) { hipError_t e = hipMalloc(&A->d_ghost, (size_t)std::max<int64_t>(A->nghost, 1) * sizeof(double)); if (e != hipSuccess) rc = KSG_ERR_MEM; }
+  if (!rc) { hipError_t e = hipMalloc(&A->d_send, (size_t)std::max<int64_t>(A->nsend, 1) * sizeof(double)); if (e != hipSuccess) rc = KSG_ERR_MEM; }
+  if (!rc && c->comm_kind == KSG_COMM_CALLBACKS && !c->cb_on_device) {
+    if (hipHostMalloc(&A->h_ghost, (size_t)std::max<int64_t>(A->nghost, 1) * sizeof(double), hipHostMallocDefault) != hipSuccess) rc = KSG_ERR_MEM;
+    if (!rc && hipHostMalloc(&A->h_send, (size_t)std::max<int64_t>(A->nsend, 1) * sizeof(double), hipHostMallocDefault) != hipSuccess) rc = KSG_ERR_MEM;
+  }
+  if (rc) { ksg_mat_destroy(A); if (rc == KSG_ERR_MEM) ksg_set_error("ksg_mat_create_csr: out of device memory"); return rc; }
+  *out = A;
+  return KSG_OK;
+}
+
+extern "C" int ksg_mat_destroy(ksg_mat A) {
+  if (!A) return KSG_OK;
+  hipSetDevice(A->ctx->device);
+  hipStreamSynchronize(A->ctx->comm_stream);
+  hipStreamSynchronize(A->ctx->stream);
+  csr_free(&A->diag);
+  if (A->o_rows) hipFree(A->o_rows);
+  if (A->o_rowptr) hipFree(A->o_rowptr);
+  if (A->o_colidx) hipFree(A->o_colidx);
+  if (A->o_val) hipFree(A->o_val);
+  if (A->d_send_idx) hipFree(A->d_send_idx);
+  if (A->d_ghost) hipFree(A->d_ghost);
+  if (A->d_send) hipFree(A->d_send);
+  if (A->h_ghost) hipHostFree(A->h_ghost);
+  if (A->h_send) hipHostFree(A->h_send);
+  delete A;
+  return KSG_OK;
+}
+
+extern "C" int ksg_mat_sizes(ksg_mat A, int64_t *n, int64_t *N, int64_t *row0, int64_t *nnz) {
+  if (!A) KSG_FAIL(KSG_ERR_ARG, "ksg_mat_sizes: NULL matrix");
+  if (n) *n = A->n;
+  if (N) *N = A->N;
+  if (row0) *row0 = A->row0;
+  if (nnz) *nnz = A->nnz;
+  return KSG_OK;
+}
+
+extern "C" int ksg_mat_info(ksg_mat A, int64_t info[4]) {
+  if (!A || !info) KSG_FAIL(KSG_ERR_ARG, "ksg_mat_info: NULL argument");
+  info[0] = A->diag.n_stream; info[1] = A->diag.n_group; info[2] = A->diag.n_long; info[3] = A->nghost;
+  return KSG_OK;
+}
+
+/* y = A x without statistics brackets (shared with ksg_bv_matmult) */
+static int mat_mult_raw(ksg_mat A, const double *x, double *y) {
+  ksg_ctx c = A->ctx;
+  if (A->n == 0 && c->nranks == 1) return KSG_OK;
+  const bool halo = c->nranks > 1;
+  if (halo) {
+    /* gather + exchange on the communication stream, behind the producer of x */
+    KSG_HIP(hipEventRecord(c->ev_x_ready, c->stream));
+    KSG_HIP(hipStreamWaitEvent(c->comm_stream, c->ev_x_ready, 0));
+    if (A->nsend)
+      hipLaunchKernelGGL(k_gather, dim3(ksg_grid_for(A->nsend)), dim3(KSG_BLOCK), 0, c->comm_stream, x, A->d_send_idx, A->d_send, A->nsend);
+  }
+  if (A->diag.ntiles)
+    hipLaunchKernelGGL(k_spmv_tiles, dim3((unsigned)A->diag.ntiles), dim3(KSG_BLOCK), 0, c->stream,
+                       A->diag.tiles, A->diag.rowptr, A->diag.colidx, A->diag.val, x, y);
+  KSG_HIP(hipGetLastError());
+  if (halo) {
+    KSG_CHK(ksg_comm_exchange(c, A));
+    KSG_HIP(hipEventRecord(c->ev_halo_done, c->comm_stream));
+    KSG_HIP(hipStreamWaitEvent(c->stream, c->ev_halo_done, 0));
+    if (A->no_rows)
+      hipLaunchKernelGGL(k_spmv_ghost_add, dim3(ksg_grid_for(A->no_rows)), dim3(KSG_BLOCK), 0, c->stream,
+                         A->no_rows, A->o_rows, A->o_rowptr, A->o_colidx, A->o_val, A->d_ghost, y);
+    KSG_HIP(hipGetLastError());
+  }
+  return KSG_OK;
+}
+
+static inline double spmv_bytes(ksg_mat A) {
+  return 12.0 * (double)A->nnz + 8.0 * (double)(A->n + 1) + 8.0 * (double)(A->n + A->nghost) + 8.0 * (double)A->n;
+}
+
+extern "C" int ksg_mat_mult(ksg_mat A, const double *x, double *y) {
+  if (!A) KSG_FAIL(KSG_ERR_ARG, "ksg_mat_mult: NULL matrix");
+  if (A->n && (!x || !y)) KSG_FAIL(KSG_ERR_ARG, "ksg_mat_mult: NULL vector");
+  if (x == y) KSG_FAIL(KSG_ERR_ARG, "ksg_mat_mult: x and y must be different vectors");
+  ksg_ctx c = A->ctx;
+  KSG_CHK(ksg_op_begin(c, KSG_EV_MATMULT));
+  KSG_CHK(mat_mult_raw(A, x, y));
+  return ksg_op_end(c, KSG_EV_MATMULT, spmv_bytes(A), 2.0 * (double)A->nnz);
+}
+
+extern "C" int ksg_bv_matmult(ksg_bv V, ksg_mat A, ksg_bv W) {
+  if (!V || !W || !A) KSG_FAIL(KSG_ERR_ARG, "ksg_bv_matmult: NULL argument");
+  if (V == W) KSG_FAIL(KSG_ERR_ARG, "ksg_bv_matmult: V and W must differ");
+  if (V->n != A->n || W->n != A->n || V->k - V->l != W->k - W->l || V->l < 0 || W->l < 0)
+    KSG_FAIL(KSG_ERR_ARG, "ksg_bv_matmult: size mismatch");
+  ksg_ctx c = V->ctx;
+  const int nc = V->k - V->l;
+  KSG_CHK(ksg_op_begin(c, KSG_EV_MATMULT));
+  for (int j = 0; j < nc; j++)
+    KSG_CHK(mat_mult_raw(A, V->d + (int64_t)(V->nc + V->l + j) * V->ld, W->d + (int64_t)(W->nc + W->l + j) * W->ld));
+  return ksg_op_end(c, KSG_EV_MATMULT, nc * spmv_bytes(A), 2.0 * nc * (double)A->nnz);
+}

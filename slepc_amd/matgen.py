@@ -1,0 +1,153 @@
+"""Synthetic operators of the benchmark configurations, generated as row blocks
+of CSR (int64 row pointers, int32 global column indices sorted within each row,
+float64 values) -- the layout ``ksg_mat_create_csr`` takes.
+
+These follow the matrix-filling loops of the reference's example programs
+(``src/eps/examples/tutorials/ex1.c:54-58``, ``ex2.c:56-63``, ``ex19.c:70-86``,
+``ex5.c:150-193``) but are vectorised with numpy so that the 16.7M-row and
+134M-row cases are practical; every generator takes the range of rows
+``[row0, row1)`` owned by the caller, like ``MatGetOwnershipRange`` does there.
+"""
+import numpy as np
+
+
+def _finish(n_local, rows, cols, vals):
+    """Sorts entries by (row, col) and builds the row pointer."""
+    order = np.lexsort((cols, rows))
+    rows, cols, vals = rows[order], cols[order], vals[order]
+    rowptr = np.zeros(n_local + 1, dtype=np.int64)
+    np.cumsum(np.bincount(rows, minlength=n_local), out=rowptr[1:])
+    return rowptr, cols.astype(np.int32), vals.astype(np.float64)
+
+
+def _stencil(n_local, offsets):
+    """offsets: list of (global column array, mask array, value), given in
+    ascending column order.  Builds the CSR without a sort."""
+    counts = np.zeros(n_local, dtype=np.int64)
+    for _, mask, _ in offsets:
+        counts += mask
+    rowptr = np.zeros(n_local + 1, dtype=np.int64)
+    np.cumsum(counts, out=rowptr[1:])
+    nnz = int(rowptr[-1])
+    colidx = np.empty(nnz, dtype=np.int32)
+    val = np.empty(nnz, dtype=np.float64)
+    pos = rowptr[:-1].copy()
+    for col, mask, v in offsets:
+        p = pos[mask]
+        colidx[p] = col[mask]
+        val[p] = v
+        pos += mask
+    return rowptr, colidx, val
+
+
+def laplacian1d(n, row0=0, row1=None):
+    """1-D Laplacian tridiag(-1, 2, -1) of order n (ex1.c:54-58)."""
+    row1 = n if row1 is None else row1
+    i = np.arange(row0, row1, dtype=np.int64)
+    return _stencil(row1 - row0, [(i - 1, i > 0, -1.0), (i, np.ones_like(i, dtype=bool), 2.0),
+                                  (i + 1, i < n - 1, -1.0)])
+
+
+def laplacian2d(n, m=None, row0=0, row1=None):
+    """2-D 5-point Laplacian on an n x m grid, II = i*n + j (ex2.c:56-63)."""
+    m = n if m is None else m
+    N = n * m
+    row1 = N if row1 is None else row1
+    II = np.arange(row0, row1, dtype=np.int64)
+    i = II // n
+    j = II - i * n
+    return _stencil(row1 - row0, [(II - n, i > 0, -1.0), (II - 1, j > 0, -1.0),
+                                  (II, np.ones_like(II, dtype=bool), 4.0),
+                                  (II + 1, j < n - 1, -1.0), (II + n, i < m - 1, -1.0)])
+
+
+def laplacian3d(mx, my=None, mz=None, row0=0, row1=None):
+    """3-D 7-point Laplacian, natural ordering idx = i + mx*(j + my*k)
+    (ex19.c:70-86)."""
+    my = mx if my is None else my
+    mz = mx if mz is None else mz
+    N = mx * my * mz
+    row1 = N if row1 is None else row1
+    idx = np.arange(row0, row1, dtype=np.int64)
+    i = idx % mx
+    j = (idx // mx) % my
+    k = idx // (mx * my)
+    one = np.ones_like(idx, dtype=bool)
+    return _stencil(row1 - row0, [(idx - mx * my, k > 0, -1.0), (idx - mx, j > 0, -1.0),
+                                  (idx - 1, i > 0, -1.0), (idx, one, 6.0),
+                                  (idx + 1, i < mx - 1, -1.0), (idx + mx, j < my - 1, -1.0),
+                                  (idx + mx * my, k < mz - 1, -1.0)])
+
+
+def markov(m, row0=0, row1=None):
+    """Markov-chain random walk on a triangular grid, N = m(m+1)/2
+    (MatMarkovModel, ex5.c:150-193)."""
+    N = m * (m + 1) // 2
+    row1 = N if row1 is None else row1
+    cst = 0.5 / float(m - 1)
+    # (i, j) of every row, 1-based, rows numbered ix-1 in the order of the loops
+    jmax_all = m - np.arange(1, m + 1, dtype=np.int64) + 1
+    starts = np.concatenate(([0], np.cumsum(jmax_all)))            # first ix-1 of each i
+    r = np.arange(row0, row1, dtype=np.int64)
+    i = np.searchsorted(starts, r, side="right")                    # 1-based i
+    j = r - starts[i - 1] + 1
+    jmax = m - i + 1
+    ix = r + 1
+    pd = cst * (i + j - 1).astype(np.float64)
+    pu = 0.5 - cst * (i + j - 3).astype(np.float64)
+    notlast = j != jmax
+    rows = [r[notlast], r[notlast], r[j > 1], r[i > 1]]
+    cols = [ix[notlast], (ix + jmax - 1)[notlast], (ix - 2)[j > 1], (ix - jmax - 2)[i > 1]]
+    vals = [np.where(i == 1, 2 * pd, pd)[notlast], np.where(j == 1, 2 * pd, pd)[notlast],
+            pu[j > 1], pu[i > 1]]
+    rows = np.concatenate(rows) - row0
+    return _finish(row1 - row0, rows, np.concatenate(cols), np.concatenate(vals))
+
+
+def rmat_laplacian(scale, edge_factor=8, a=0.57, b=0.19, c=0.19, seed=0x5EED, row0=0, row1=None,
+                   chunk=1 << 24):
+    """Graph Laplacian D - A of a symmetrised R-MAT graph with 2**scale vertices:
+    power-law row lengths, unit weights, duplicates and self-loops removed."""
+    N = 1 << scale
+    row1 = N if row1 is None else row1
+    ne = edge_factor * N
+    rng = np.random.Generator(np.random.Philox(key=seed))
+    src_l, dst_l = [], []
+    done = 0
+    while done < ne:
+        cnt = min(chunk, ne - done)
+        src = np.zeros(cnt, dtype=np.int64)
+        dst = np.zeros(cnt, dtype=np.int64)
+        for _ in range(scale):
+            u = rng.random(cnt)
+            right = u >= a + c          # quadrant b or d: column bit set
+            down = ((u >= a) & (u < a + c)) | (u >= a + b + c)   # quadrant c or d: row bit set
+            src = (src << 1) | down
+            dst = (dst << 1) | right
+        keep = src != dst
+        src, dst = src[keep], dst[keep]
+        s2 = np.concatenate((src, dst))
+        d2 = np.concatenate((dst, src))
+        mine = (s2 >= row0) & (s2 < row1)
+        src_l.append(s2[mine])
+        dst_l.append(d2[mine])
+        done += cnt
+    src = np.concatenate(src_l)
+    dst = np.concatenate(dst_l)
+    key = np.unique(src * N + dst)
+    src = key // N
+    dst = key - src * N
+    n_local = row1 - row0
+    deg = np.bincount(src - row0, minlength=n_local).astype(np.float64)
+    rows = np.concatenate((src - row0, np.arange(n_local, dtype=np.int64)))
+    cols = np.concatenate((dst, np.arange(row0, row1, dtype=np.int64)))
+    vals = np.concatenate((-np.ones(src.size), deg))
+    return _finish(n_local, rows, cols, vals)
+
+
+def split_rows(N, nranks, rank):
+    """Contiguous row blocks as PETSc's default layout (PetscSplitOwnership):
+    the first N % nranks ranks get one extra row."""
+    base, extra = divmod(N, nranks)
+    row0 = rank * base + min(rank, extra)
+    return row0, row0 + base + (1 if rank < extra else 0)

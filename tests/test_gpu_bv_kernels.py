@@ -1,0 +1,169 @@
+"""Parity of the HIP BV kernels (through the C ABI) against the CPU oracle.
+
+Floating-point bar: every result within 1e-12 relative to the magnitude of the
+data (different summation order than BLAS, fp64 throughout); integer-valued
+inputs must come out exact.
+"""
+import numpy as np
+import pytest
+
+from oracle import bv as obv
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-12
+
+
+def _mk(ctx, n, m, seed=0):
+    from slepc_amd import ksgpu
+    rng = np.random.default_rng(seed)
+    A = rng.standard_normal((n, m))
+    G = ksgpu.DeviceBV(ctx, n, m)
+    G.from_numpy(A)
+    O = obv.BV(n, m)
+    O.array[:, :] = A
+    return G, O, rng
+
+
+def _close(a, b, scale=None):
+    a, b = np.asarray(a), np.asarray(b)
+    s = scale if scale is not None else max(1.0, float(np.abs(b).max()) if b.size else 1.0)
+    return np.abs(a - b).max() <= RTOL * s if a.size else True
+
+
+@pytest.mark.parametrize("n,m,l,k", [(1000, 5, 0, 5), (4097, 33, 0, 33), (100003, 65, 3, 65),
+                                      (1, 3, 0, 3), (63, 17, 2, 9), (200000, 20, 0, 17), (7, 1, 0, 1)])
+def test_dotvec(gpu_ctx, n, m, l, k):
+    G, O, rng = _mk(gpu_ctx, n, m)
+    y = rng.standard_normal(n)
+    yd = gpu_ctx.vec_alloc(n)
+    gpu_ctx.upload(yd, y)
+    G.set_active(l, k)
+    O.set_active_columns(l, k)
+    q = G.dotvec(yd)
+    qo = np.zeros(k - l)
+    O.op_dotvec(y, qo)
+    assert _close(q, qo, scale=np.sqrt(n) * 10)
+    # a column of the BV itself as y (the Gram-Schmidt case)
+    q2 = G.dotvec(G.column(k - 1))
+    O.op_dotvec(O.col(k - 1), qo)
+    assert _close(q2, qo, scale=n)
+    gpu_ctx.vec_free(yd)
+    G.destroy()
+
+
+@pytest.mark.parametrize("n,m,l,k,alpha,beta", [(1000, 5, 0, 5, -1.0, 1.0), (4097, 33, 0, 32, 1.0, 0.0),
+                                                 (100003, 65, 3, 64, -1.0, 1.0), (1, 3, 0, 3, 2.0, 0.5),
+                                                 (50001, 140, 0, 139, -0.5, 2.0), (63, 4, 1, 1, 3.0, 2.0)])
+def test_multvec(gpu_ctx, n, m, l, k, alpha, beta):
+    G, O, rng = _mk(gpu_ctx, n, m, seed=1)
+    q = rng.standard_normal(max(k - l, 1))
+    G.set_active(l, k)
+    O.set_active_columns(l, k)
+    j = m - 1
+    ycol = O.col(j).copy()
+    if beta == 0.0:
+        G.set_column(j, np.full(n, np.nan))     # beta = 0 must not read y
+    G.multvec(alpha, beta, G.column(j), q)
+    O.op_multvec(alpha, beta, ycol, q[:k - l])
+    assert _close(G.get_column(j), ycol, scale=10 * np.sqrt(max(k - l, 1)))
+    G.destroy()
+
+
+@pytest.mark.parametrize("n,m,l,k,s,e", [(1000, 5, 0, 5, 1, 3), (4097, 65, 0, 64, 0, 33), (100001, 65, 10, 64, 10, 40),
+                                          (33, 80, 0, 80, 0, 80), (2, 9, 2, 8, 3, 8), (5000, 150, 5, 140, 5, 100)])
+@pytest.mark.parametrize("trans", [False, True])
+def test_multinplace(gpu_ctx, n, m, l, k, s, e, trans):
+    G, O, rng = _mk(gpu_ctx, n, m, seed=2)
+    Q = np.asfortranarray(rng.standard_normal((m, m)))
+    G.set_active(l, k)
+    O.set_active_columns(l, k)
+    G.multinplace(Q, s, e, trans)
+    O.op_multinplace(Q, s, e, trans)
+    assert _close(G.to_numpy(), O.array, scale=10 * np.sqrt(k - l))
+    G.destroy()
+
+
+def test_scale_norm_copy(gpu_ctx):
+    n, m = 30001, 9
+    G, O, rng = _mk(gpu_ctx, n, m, seed=3)
+    G.set_active(2, 7)
+    O.set_active_columns(2, 7)
+    for nt in (obv.NORM_1, obv.NORM_2, obv.NORM_FROBENIUS, obv.NORM_INFINITY):
+        assert abs(G.norm(-1, nt) - O.op_norm(-1, nt)) <= 1e-12 * O.op_norm(-1, nt)
+        assert abs(G.norm(4, nt) - O.op_norm(4, nt)) <= 1e-12 * O.op_norm(4, nt)
+    G.scale(3, -2.5)
+    O.op_scale(3, -2.5)
+    G.scale(-1, 0.5)
+    O.op_scale(-1, 0.5)
+    G.scale(8, 0.0)
+    O.op_scale(8, 0.0)
+    assert np.array_equal(G.to_numpy(), O.array)          # scaling is exact in fp64
+    G.copy_column(1, 6)
+    O.copy_column(1, 6)
+    assert np.array_equal(G.to_numpy(), O.array)
+    G.destroy()
+
+
+def test_golden_bv_test1(gpu_ctx):
+    """The reference's bv test1 (n=10, k=5, l=3) on the device: exact small-integer
+    results of BVMult, BVMultVec, BVDot, BVDotVec, BVMultInPlace+BVScale, norms."""
+    import json, os
+    from slepc_amd import ksgpu
+    g = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "bv_test1.json")))
+    n, k, l = 10, 5, 3
+    X = ksgpu.DeviceBV(gpu_ctx, n, k)
+    Y = ksgpu.DeviceBV(gpu_ctx, n, l)
+    Xh = np.zeros((n, k))
+    for j in range(k):
+        for i in range(4):
+            if i + j < n:
+                Xh[i + j, j] = 3 * i + j - 2
+    X.from_numpy(Xh)
+    Y.from_numpy(np.stack([np.full(n, (j + 1) / 4.0) for j in range(l)], axis=1))
+    Q = np.asfortranarray(np.array([[2.0 if i < j else -0.5 for j in range(l)] for i in range(k)]))
+    Y.mult(2.0, 1.0, X, Q)
+    assert np.array_equal(Y.to_numpy(), np.array(g["Y_after_mult"]).reshape(l, n).T)
+    z = np.array([2.0 * (-0.5) ** i for i in range(k)])
+    X.multvec(-1.0, 1.0, Y.column(0), z)
+    assert np.array_equal(Y.to_numpy(), np.array(g["Y_after_multvec"]).reshape(l, n).T)
+    M = np.zeros((l, k), order="F")
+    X.dot(Y, M)
+    assert np.array_equal(M, np.array(g["M"]))
+    assert np.array_equal(X.dotvec(Y.column(0)), np.array(g["z"]))
+    X.set_active(0, k)
+    X.multinplace(Q, 1, l)
+    X.scale(-1, 2.0)
+    assert np.array_equal(X.to_numpy(), np.array(g["X_after_multinplace"]).reshape(k, n).T)
+    assert "%g" % X.norm(0, obv.NORM_2) == g["norm_X0"]
+    assert "%g" % X.norm(-1, obv.NORM_FROBENIUS) == g["norm_fro"]
+    X.destroy()
+    Y.destroy()
+
+
+def test_bv_mult_dot_general(gpu_ctx):
+    from slepc_amd import ksgpu
+    n = 20011
+    rng = np.random.default_rng(5)
+    Xa, Ya = rng.standard_normal((n, 12)), rng.standard_normal((n, 7))
+    X, Y = ksgpu.DeviceBV(gpu_ctx, n, 12), ksgpu.DeviceBV(gpu_ctx, n, 7)
+    X.from_numpy(Xa)
+    Y.from_numpy(Ya)
+    OX, OY = obv.BV(n, 12), obv.BV(n, 7)
+    OX.array[:] = Xa
+    OY.array[:] = Ya
+    X.set_active(2, 11)
+    Y.set_active(1, 6)
+    OX.set_active_columns(2, 11)
+    OY.set_active_columns(1, 6)
+    Q = np.asfortranarray(rng.standard_normal((12, 7)))
+    Y.mult(0.5, -1.5, X, Q)
+    OY.op_mult(0.5, -1.5, OX, Q)
+    assert _close(Y.to_numpy(), OY.array, scale=50)
+    M = np.zeros((7, 12), order="F")
+    Mo = np.zeros((7, 12), order="F")
+    X.dot(Y, M)
+    OX.op_dot(OY, Mo)
+    assert _close(M, Mo, scale=n)
+    X.destroy()
+    Y.destroy()

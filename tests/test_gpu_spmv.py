@@ -1,0 +1,106 @@
+"""Parity of the HIP CSR SpMV (through the C ABI) against the CPU oracle.
+
+Index handling must be exact: on matrices whose rows all take the
+one-lane-per-row path the result must be bit-identical to a sequential CSR
+loop; grouped and long-row paths sum in a different order and are held to
+1e-13 relative to sum |a_ij x_j|.
+"""
+import numpy as np
+import pytest
+
+from oracle import matgen as og
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(ctx, rp, ci, va, x):
+    from slepc_amd import ksgpu
+    n = len(rp) - 1
+    A = ksgpu.DeviceCSR(ctx, rp, ci, va)
+    xd, yd = ctx.vec_alloc(n), ctx.vec_alloc(n)
+    ctx.upload(xd, x)
+    ctx.upload(yd, np.full(n, np.nan))
+    A.mult(xd, yd)
+    y = ctx.download(yd, n)
+    info = A.info()
+    ctx.vec_free(xd)
+    ctx.vec_free(yd)
+    A.destroy()
+    return y, info
+
+
+@pytest.mark.parametrize("gen", ["lap1d", "lap2d", "lap3d", "markov"])
+def test_stencils_bit_exact(gpu_ctx, gen):
+    from slepc_amd import matgen as mg
+    rp, ci, va = {"lap1d": lambda: mg.laplacian1d(100003), "lap2d": lambda: mg.laplacian2d(301, 217),
+                  "lap3d": lambda: mg.laplacian3d(41, 37, 29), "markov": lambda: mg.markov(300)}[gen]()
+    n = len(rp) - 1
+    x = np.random.default_rng(0).standard_normal(n)
+    y, info = _run(gpu_ctx, rp, ci, va, x)
+    yo = og.csr_matvec_fast(rp, ci, va, x, np.zeros(n))
+    assert info["long_rows"] == 0
+    if info["group_tiles"] == 0:
+        assert np.array_equal(y, yo)
+    else:   # only the last, short tile may be grouped
+        assert info["group_tiles"] <= 1
+        assert np.abs(y - yo).max() <= 1e-13 * np.abs(yo).max()
+
+
+def test_golden_bv_test7(gpu_ctx):
+    """Reference bv test7: 1-D Laplacian times staircase vectors = e_0 + e_j - e_{j+1};
+    the printed error is exactly 0."""
+    from slepc_amd import ksgpu, matgen as mg
+    import json, os
+    g = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "bv_misc.json")))
+    n, k = 10, 5
+    rp, ci, va = mg.laplacian1d(n)
+    A = ksgpu.DeviceCSR(gpu_ctx, rp, ci, va)
+    V, W = ksgpu.DeviceBV(gpu_ctx, n, k), ksgpu.DeviceBV(gpu_ctx, n, k)
+    Vh = np.zeros((n, k))
+    for j in range(k):
+        Vh[:j + 1, j] = 1.0
+    V.from_numpy(Vh)
+    V.matmult(A, W)
+    Wh = W.to_numpy()
+    for j in range(k):
+        e = np.zeros(n)
+        e[0] += 1.0
+        e[j] += 1.0
+        e[j + 1] -= 1.0
+        assert "%g" % np.linalg.norm(Wh[:, j] - e) == g["test7_errors"][0].rstrip(".")
+    for o in (A, V, W):
+        o.destroy()
+
+
+def test_irregular_rows(gpu_ctx):
+    """R-MAT graph Laplacian: grouped tiles and long rows."""
+    from slepc_amd import matgen as mg
+    rp, ci, va = mg.rmat_laplacian(15)
+    n = len(rp) - 1
+    assert np.diff(rp).max() > 2048
+    x = np.random.default_rng(1).standard_normal(n)
+    y, info = _run(gpu_ctx, rp, ci, va, x)
+    assert info["long_rows"] > 0 and info["group_tiles"] > 0
+    yo = og.csr_matvec_fast(rp, ci, va, x, np.zeros(n))
+    absA = np.abs(va)
+    bound = og.csr_matvec_fast(rp, ci, absA, np.abs(x), np.zeros(n))
+    assert np.all(np.abs(y - yo) <= 1e-13 * np.maximum(bound, 1.0))
+    # integer data: exact whatever the summation order
+    xi = np.arange(n, dtype=np.float64) % 7 - 3
+    y, _ = _run(gpu_ctx, rp, ci, va, xi)
+    assert np.array_equal(y, og.csr_matvec_fast(rp, ci, va, xi, np.zeros(n)))
+
+
+def test_edge_cases(gpu_ctx):
+    from slepc_amd import ksgpu
+    # empty rows, a single dense row, a 1x1 matrix
+    rp = np.array([0, 0, 3, 3, 4], dtype=np.int64)
+    ci = np.array([0, 1, 3, 2], dtype=np.int32)
+    va = np.array([1.0, 2.0, 3.0, -1.0])
+    x = np.array([1.0, 10.0, 100.0, 1000.0])
+    y, _ = _run(gpu_ctx, rp, ci, va, x)
+    assert np.array_equal(y, [0.0, 3021.0, 0.0, -100.0])
+    y, _ = _run(gpu_ctx, np.array([0, 1], dtype=np.int64), np.array([0], dtype=np.int32), np.array([2.5]), np.array([4.0]))
+    assert np.array_equal(y, [10.0])
+    with pytest.raises(ksgpu.KsgError):
+        ksgpu.DeviceCSR(gpu_ctx, np.array([0, 1], dtype=np.int64), np.array([5], dtype=np.int32), np.array([1.0]))
