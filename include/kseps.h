@@ -1,0 +1,302 @@
+/*
+ * kseps.h -- C ABI of libkseps, the host side of the Krylov-Schur hot path.
+ *
+ * A small, PETSc-free mirror of the interfaces the reference (SLEPc 3.7.3-dev)
+ * exposes on this path: the EPS solver object with its Krylov-Schur drivers,
+ * the BV class with its type registry and op table, the DS projected problems
+ * (HEP compact, NHEP), and the handful of Vec/Mat entry points the solver
+ * calls.  Names, argument meaning and error behaviour follow the reference;
+ * every function returns a PetscErrorCode (0 = success) and the message of the
+ * last error is available from KSGetLastError().  The compute back end is
+ * libksgpu (include/ksgpu.h); there is no CPU implementation of the vector
+ * kernels in this library.  Paths in comments are relative to the reference
+ * root.
+ */
+#ifndef KSEPS_H
+#define KSEPS_H
+
+#include <stdint.h>
+
+#include "ksgpu.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef int PetscErrorCode;
+typedef int PetscInt;
+typedef int64_t PetscInt64;
+typedef double PetscScalar;
+typedef double PetscReal;
+typedef int PetscBool;
+#define PETSC_TRUE 1
+#define PETSC_FALSE 0
+
+/* error codes (values of PETSc's petscerror.h) */
+#define PETSC_ERR_MEM            55
+#define PETSC_ERR_SUP            56
+#define PETSC_ERR_ORDER          58
+#define PETSC_ERR_ARG_SIZ        60
+#define PETSC_ERR_ARG_WRONG      62
+#define PETSC_ERR_ARG_OUTOFRANGE 63
+#define PETSC_ERR_ARG_INCOMP     75
+#define PETSC_ERR_ARG_NULL       85
+#define PETSC_ERR_ARG_WRONGSTATE 73
+#define PETSC_ERR_LIB            76
+#define PETSC_ERR_PLIB           77
+#define PETSC_ERR_USER           83
+
+const char *KSGetLastError(void);
+
+typedef enum { NORM_1 = 0, NORM_2 = 1, NORM_FROBENIUS = 2, NORM_INFINITY = 3 } NormType;
+
+typedef struct _p_Vec *Vec;
+typedef struct _p_Mat *Mat;
+typedef struct _p_BV *BV;
+typedef struct _p_DS *DS;
+typedef struct _p_EPS *EPS;
+
+/* ------------------------------------------------------------------ Vec */
+/* Op table of a vector type: the PETSc Vec operations the hot-path host code
+ * invokes on BV column views (VecCopy bvbasic.c:1645, VecAXPY epssolve.c:531,
+ * VecNorm epssolve.c:533, VecDot bvglobal.c:477, VecScale/VecSet
+ * epsdefault.c:374,398).  `array` is an address in the memory of the back end
+ * (device memory for the "hip" type); the host code never dereferences it. */
+struct _VecOps {
+  PetscErrorCode (*alloc)(Vec v);                       /* allocate v->array for v->n entries */
+  PetscErrorCode (*free)(Vec v);
+  PetscErrorCode (*copy)(Vec x, Vec y);
+  PetscErrorCode (*set)(Vec x, PetscScalar a);
+  PetscErrorCode (*scale)(Vec x, PetscScalar a);
+  PetscErrorCode (*axpy)(Vec y, PetscScalar a, Vec x);
+  PetscErrorCode (*dot)(Vec x, Vec y, PetscScalar *r);  /* collective */
+  PetscErrorCode (*norm2)(Vec x, PetscReal *r);         /* collective */
+  PetscErrorCode (*fillhash)(Vec x, uint64_t seed);     /* x[i] = f(seed, row0+i) */
+  PetscErrorCode (*tohost)(Vec x, PetscScalar *host);   /* copy the local entries out */
+  PetscErrorCode (*fromhost)(Vec x, const PetscScalar *host);
+};
+struct _p_Vec {
+  const struct _VecOps *ops;
+  PetscInt64 n, N, row0;
+  PetscScalar *array;       /* current storage */
+  PetscScalar *own;         /* storage owned by the vector (NULL for pure views) */
+  PetscInt64 state;         /* bumped on every modification */
+  void *ctx;                /* back-end context (ksg_ctx for "hip") */
+};
+PetscErrorCode VecCreateHIP(ksg_ctx ctx, PetscInt64 n, PetscInt64 N, PetscInt64 row0, Vec *v);
+PetscErrorCode VecCreateWithOps(const struct _VecOps *ops, void *ctx, PetscInt64 n, PetscInt64 N,
+                                PetscInt64 row0, PetscBool allocate, Vec *v);
+PetscErrorCode VecDuplicate(Vec v, Vec *w);
+PetscErrorCode VecDestroy(Vec *v);
+PetscErrorCode VecPlaceArray(Vec v, PetscScalar *array);   /* svec.c:322 */
+PetscErrorCode VecResetArray(Vec v);                       /* svec.c:334 */
+PetscErrorCode VecCopy(Vec x, Vec y);
+PetscErrorCode VecSet(Vec x, PetscScalar a);
+PetscErrorCode VecScale(Vec x, PetscScalar a);
+PetscErrorCode VecAXPY(Vec y, PetscScalar a, Vec x);
+PetscErrorCode VecDot(Vec x, Vec y, PetscScalar *r);
+PetscErrorCode VecNorm(Vec x, NormType type, PetscReal *r);
+PetscErrorCode VecGetSize(Vec x, PetscInt64 *N);
+PetscErrorCode VecGetLocalSize(Vec x, PetscInt64 *n);
+PetscErrorCode VecGetValuesHost(Vec x, PetscScalar *host);         /* stands in for VecGetArray */
+PetscErrorCode VecSetValuesHost(Vec x, const PetscScalar *host);
+PetscErrorCode VecFillHash(Vec x, uint64_t seed);
+
+/* ------------------------------------------------------------------ Mat */
+/* The solver needs MatMult (shift.c:38, epssolve.c:527), MatCreateVecs
+ * (stfunc.c:546) and the sizes (epssetup.c:135-136). */
+struct _MatOps {
+  PetscErrorCode (*mult)(Mat A, Vec x, Vec y);
+  PetscErrorCode (*createvecs)(Mat A, Vec *right, Vec *left);
+  PetscErrorCode (*destroy)(Mat A);
+};
+struct _p_Mat {
+  struct _MatOps ops;
+  PetscInt64 n, N, row0;
+  void *data;               /* ksg_mat for "aijhip", user context for shells */
+  void *ctx;
+};
+/* GPU AIJ operator: the rows [row0,row0+n) in CSR with global column indices
+ * (the role of MatCreateAIJ + MatSetValues + MatAssembly with -mat_type set to
+ * the device type, ex2.c:50-66). */
+PetscErrorCode MatCreateAIJHIP(ksg_ctx ctx, PetscInt64 n, PetscInt64 N, PetscInt64 row0,
+                               const int64_t *rowptr, const int32_t *colidx, const double *val, Mat *A);
+/* User operator (MatCreateShell + MatShellSetOperation(MATOP_MULT), tests/test8.c:57-61).
+ * createvecs may be NULL when template vectors are supplied by another route. */
+PetscErrorCode MatCreateShell(void *ctx, PetscInt64 n, PetscInt64 N, PetscInt64 row0, void *user,
+                              PetscErrorCode (*mult)(Mat, Vec, Vec),
+                              PetscErrorCode (*createvecs)(Mat, Vec *, Vec *), Mat *A);
+PetscErrorCode MatShellGetContext(Mat A, void **user);
+PetscErrorCode MatMult(Mat A, Vec x, Vec y);
+PetscErrorCode MatCreateVecs(Mat A, Vec *right, Vec *left);
+PetscErrorCode MatGetSize(Mat A, PetscInt64 *M, PetscInt64 *N);
+PetscErrorCode MatGetLocalSize(Mat A, PetscInt64 *m, PetscInt64 *n);
+PetscErrorCode MatDestroy(Mat *A);
+
+/* ------------------------------------------------------------------ BV */
+typedef enum { BV_ORTHOG_CGS = 0, BV_ORTHOG_MGS = 1 } BVOrthogType;
+typedef enum { BV_ORTHOG_REFINE_IFNEEDED = 0, BV_ORTHOG_REFINE_NEVER = 1, BV_ORTHOG_REFINE_ALWAYS = 2 } BVOrthogRefineType;
+
+/* Op table of a BV type: struct _BVOps of include/slepc/private/bvimpl.h:35-64.
+ * Q matrices are host column-major arrays with leading dimension ldq. */
+struct _BVOps {
+  PetscErrorCode (*mult)(BV Y, PetscScalar alpha, PetscScalar beta, BV X, const PetscScalar *Q, PetscInt ldq);
+  PetscErrorCode (*multvec)(BV X, PetscScalar alpha, PetscScalar beta, Vec y, PetscScalar *q);
+  PetscErrorCode (*multinplace)(BV V, const PetscScalar *Q, PetscInt ldq, PetscInt s, PetscInt e);
+  PetscErrorCode (*multinplacetrans)(BV V, const PetscScalar *Q, PetscInt ldq, PetscInt s, PetscInt e);
+  PetscErrorCode (*dot)(BV X, BV Y, PetscScalar *M, PetscInt ldm);
+  PetscErrorCode (*dotvec)(BV X, Vec y, PetscScalar *q);
+  PetscErrorCode (*dotvec_local)(BV X, Vec y, PetscScalar *q);
+  PetscErrorCode (*scale)(BV bv, PetscInt j, PetscScalar alpha);
+  PetscErrorCode (*norm)(BV bv, PetscInt j, NormType type, PetscReal *val);
+  PetscErrorCode (*norm_local)(BV bv, PetscInt j, NormType type, PetscReal *val);
+  PetscErrorCode (*matmult)(BV V, Mat A, BV W);
+  PetscErrorCode (*copy)(BV V, BV W);
+  PetscErrorCode (*resize)(BV bv, PetscInt m, PetscBool copy);
+  PetscErrorCode (*getcolumn)(BV bv, PetscInt j, Vec *v);
+  PetscErrorCode (*restorecolumn)(BV bv, PetscInt j, Vec *v);
+  PetscErrorCode (*destroy)(BV bv);
+};
+
+/* struct _p_BV of bvimpl.h:66-105 (the fields this path uses). */
+struct _p_BV {
+  struct _BVOps ops;
+  char type_name[32];
+  Vec t;                        /* template vector */
+  PetscInt64 n, N;              /* local / global rows */
+  PetscInt m, l, k, nc;         /* columns, active range, constraints */
+  BVOrthogType orthog_type;
+  BVOrthogRefineType orthog_ref;
+  PetscReal orthog_eta;
+  PetscScalar *buffer;          /* host, (nc+m)*m, column 0 = scratch, column j = h_j (bvbasic.c:791-827) */
+  PetscScalar *h, *c;           /* host coefficient arrays for BVOrthogonalizeVec */
+  Vec cv[2];                    /* column views */
+  PetscInt ci[2];               /* column index of each outstanding view, or -nc-1 */
+  PetscInt64 st[2];             /* state of the view when it was handed out */
+  PetscInt64 state;
+  uint64_t rand_seed;
+  void *data;                   /* type-specific (ksg_bv for "hip") */
+  void *ctx;
+};
+
+PetscErrorCode BVCreate(void *ctx, BV *bv);
+/* Registers a BV type: BVRegister(name, constructor), include/slepcbv.h:196,
+ * bvfunc.c:677-684.  The constructor runs when type and sizes are both known
+ * (bvbasic.c:64-70,193-197); on entry bv->t, n, N, m, k are set. */
+PetscErrorCode BVRegister(const char *name, PetscErrorCode (*create)(BV));
+PetscErrorCode BVSetType(BV bv, const char *type);
+PetscErrorCode BVSetSizesFromVec(BV bv, Vec t, PetscInt m);
+PetscErrorCode BVGetSizes(BV bv, PetscInt64 *n, PetscInt64 *N, PetscInt *m);
+PetscErrorCode BVResize(BV bv, PetscInt m, PetscBool copy);
+PetscErrorCode BVSetActiveColumns(BV bv, PetscInt l, PetscInt k);
+PetscErrorCode BVGetActiveColumns(BV bv, PetscInt *l, PetscInt *k);
+PetscErrorCode BVSetOrthogonalization(BV bv, BVOrthogType type, BVOrthogRefineType refine, PetscReal eta);
+PetscErrorCode BVGetColumn(BV bv, PetscInt j, Vec *v);
+PetscErrorCode BVRestoreColumn(BV bv, PetscInt j, Vec *v);
+PetscErrorCode BVGetBuffer(BV bv, PetscScalar **buffer, PetscInt *ld);     /* BVGetBufferVec */
+PetscErrorCode BVInsertVec(BV bv, PetscInt j, Vec w);
+PetscErrorCode BVInsertVecs(BV bv, PetscInt s, PetscInt *m, Vec *W, PetscBool orth);
+PetscErrorCode BVSetRandomColumn(BV bv, PetscInt j);
+PetscErrorCode BVCopy(BV V, BV W);
+PetscErrorCode BVCopyVec(BV V, PetscInt j, Vec w);
+PetscErrorCode BVCopyColumn(BV V, PetscInt j, PetscInt i);
+PetscErrorCode BVMult(BV Y, PetscScalar alpha, PetscScalar beta, BV X, const PetscScalar *Q, PetscInt ldq);
+PetscErrorCode BVMultVec(BV X, PetscScalar alpha, PetscScalar beta, Vec y, PetscScalar *q);
+PetscErrorCode BVMultColumn(BV X, PetscScalar alpha, PetscScalar beta, PetscInt j, PetscScalar *q);
+PetscErrorCode BVMultInPlace(BV V, const PetscScalar *Q, PetscInt ldq, PetscInt s, PetscInt e);
+PetscErrorCode BVMultInPlaceTranspose(BV V, const PetscScalar *Q, PetscInt ldq, PetscInt s, PetscInt e);
+PetscErrorCode BVDot(BV X, BV Y, PetscScalar *M, PetscInt ldm);
+PetscErrorCode BVDotVec(BV X, Vec y, PetscScalar *q);
+PetscErrorCode BVDotColumn(BV X, PetscInt j, PetscScalar *q);
+PetscErrorCode BVScale(BV bv, PetscScalar alpha);
+PetscErrorCode BVScaleColumn(BV bv, PetscInt j, PetscScalar alpha);
+PetscErrorCode BVNorm(BV bv, NormType type, PetscReal *val);
+PetscErrorCode BVNormColumn(BV bv, PetscInt j, NormType type, PetscReal *val);
+PetscErrorCode BVNormVec(BV bv, Vec v, NormType type, PetscReal *val);
+PetscErrorCode BVMatMult(BV V, Mat A, BV W);
+PetscErrorCode BVOrthogonalizeVec(BV bv, Vec v, PetscScalar *H, PetscReal *norm, PetscBool *lindep);
+PetscErrorCode BVOrthogonalizeColumn(BV bv, PetscInt j, PetscScalar *H, PetscReal *norm, PetscBool *lindep);
+PetscErrorCode BVOrthonormalizeColumn(BV bv, PetscInt j, PetscBool replace, PetscReal *norm, PetscBool *lindep);
+PetscErrorCode BVDestroy(BV *bv);
+/* Constructor of the device type, registered as "hip" (the role BVCreate_Svec plays
+ * for "svec", svec.c:417-520). */
+PetscErrorCode BVCreate_HIP(BV bv);
+
+/* ------------------------------------------------------------------ DS */
+typedef enum { DS_STATE_RAW = 0, DS_STATE_INTERMEDIATE, DS_STATE_CONDENSED, DS_STATE_TRUNCATED } DSStateType;
+typedef enum { DS_MAT_A = 0, DS_MAT_Q, DS_MAT_X, DS_MAT_T, DS_NUM_MAT } DSMatType;
+typedef PetscErrorCode (*SlepcCompareFn)(PetscScalar ar, PetscScalar ai, PetscScalar br, PetscScalar bi, PetscInt *res, void *ctx);
+
+PetscErrorCode DSCreate(DS *ds);
+PetscErrorCode DSSetType(DS ds, const char *type);          /* "hep" or "nhep" */
+PetscErrorCode DSSetCompact(DS ds, PetscBool comp);
+PetscErrorCode DSSetExtraRow(DS ds, PetscBool ext);
+PetscErrorCode DSAllocate(DS ds, PetscInt ld);
+PetscErrorCode DSSetSlepcSC(DS ds, SlepcCompareFn cmp, void *ctx);
+PetscErrorCode DSSetDimensions(DS ds, PetscInt n, PetscInt m, PetscInt l, PetscInt k);
+PetscErrorCode DSGetDimensions(DS ds, PetscInt *n, PetscInt *m, PetscInt *l, PetscInt *k, PetscInt *t);
+PetscErrorCode DSGetLeadingDimension(DS ds, PetscInt *ld);
+PetscErrorCode DSSetState(DS ds, DSStateType state);
+PetscErrorCode DSGetState(DS ds, DSStateType *state);
+PetscErrorCode DSGetArray(DS ds, DSMatType m, PetscScalar **a);
+PetscErrorCode DSGetArrayReal(DS ds, DSMatType m, PetscReal **a);
+PetscErrorCode DSSolve(DS ds, PetscScalar *eigr, PetscScalar *eigi);
+PetscErrorCode DSSort(DS ds, PetscScalar *eigr, PetscScalar *eigi, PetscScalar *rr, PetscScalar *ri, PetscInt *k);
+PetscErrorCode DSUpdateExtraRow(DS ds);
+PetscErrorCode DSVectors(DS ds, DSMatType mat, PetscInt *j, PetscReal *rnorm);
+PetscErrorCode DSTruncate(DS ds, PetscInt n);
+/* DSGetMat (dsops.c:280-315): copies the rows x cols leading part into `out`
+ * (column-major, leading dimension *rows). */
+PetscErrorCode DSGetMat(DS ds, DSMatType m, PetscScalar *out, PetscInt *rows, PetscInt *cols);
+PetscErrorCode DSDestroy(DS *ds);
+
+PetscErrorCode SlepcCompareLargestMagnitude(PetscScalar, PetscScalar, PetscScalar, PetscScalar, PetscInt *, void *);
+PetscErrorCode SlepcCompareSmallestMagnitude(PetscScalar, PetscScalar, PetscScalar, PetscScalar, PetscInt *, void *);
+PetscErrorCode SlepcCompareLargestReal(PetscScalar, PetscScalar, PetscScalar, PetscScalar, PetscInt *, void *);
+PetscErrorCode SlepcCompareSmallestReal(PetscScalar, PetscScalar, PetscScalar, PetscScalar, PetscInt *, void *);
+PetscErrorCode SlepcCompareLargestImaginary(PetscScalar, PetscScalar, PetscScalar, PetscScalar, PetscInt *, void *);
+PetscErrorCode SlepcCompareSmallestImaginary(PetscScalar, PetscScalar, PetscScalar, PetscScalar, PetscInt *, void *);
+PetscErrorCode SlepcSortEigenvalues(SlepcCompareFn cmp, void *ctx, PetscInt n, PetscScalar *eigr, PetscScalar *eigi, PetscInt *perm);
+
+/* ------------------------------------------------------------------ EPS */
+typedef enum { EPS_HEP = 1, EPS_NHEP = 3 } EPSProblemType;
+typedef enum { EPS_LARGEST_MAGNITUDE = 1, EPS_SMALLEST_MAGNITUDE, EPS_LARGEST_REAL, EPS_SMALLEST_REAL,
+               EPS_LARGEST_IMAGINARY, EPS_SMALLEST_IMAGINARY } EPSWhich;
+typedef enum { EPS_ERROR_ABSOLUTE = 0, EPS_ERROR_RELATIVE = 1 } EPSErrorType;
+typedef enum { EPS_CONVERGED_TOL = 1, EPS_CONVERGED_USER = 2, EPS_DIVERGED_ITS = -1, EPS_DIVERGED_BREAKDOWN = -2,
+               EPS_DIVERGED_SYMMETRY_LOST = -3, EPS_CONVERGED_ITERATING = 0 } EPSConvergedReason;
+typedef PetscErrorCode (*EPSMonitorFn)(EPS eps, PetscInt its, PetscInt nconv, PetscScalar *eigr, PetscScalar *eigi,
+                                       PetscReal *errest, PetscInt nest, void *ctx);
+
+PetscErrorCode EPSCreate(void *ctx, EPS *eps);                                   /* epsbasic.c:60-80 */
+PetscErrorCode EPSSetOperators(EPS eps, Mat A, Mat B);                           /* B must be NULL */
+PetscErrorCode EPSSetProblemType(EPS eps, EPSProblemType type);                  /* epsopts.c:946-989 */
+PetscErrorCode EPSSetDimensions(EPS eps, PetscInt nev, PetscInt ncv, PetscInt mpd);
+PetscErrorCode EPSSetTolerances(EPS eps, PetscReal tol, PetscInt maxits);
+PetscErrorCode EPSSetWhichEigenpairs(EPS eps, EPSWhich which);
+PetscErrorCode EPSSetInitialSpace(EPS eps, PetscInt n, Vec *is);                 /* epssetup.c:449-460 */
+PetscErrorCode EPSKrylovSchurSetRestart(EPS eps, PetscReal keep);                /* krylovschur.c:290 */
+PetscErrorCode EPSKrylovSchurSetLocking(EPS eps, PetscBool lock);
+PetscErrorCode EPSMonitorSet(EPS eps, EPSMonitorFn monitor, void *ctx);
+PetscErrorCode EPSGetBV(EPS eps, BV *bv);
+PetscErrorCode EPSGetDS(EPS eps, DS *ds);
+PetscErrorCode EPSSetUp(EPS eps);                                                /* epssetup.c:100-288 */
+PetscErrorCode EPSSolve(EPS eps);                                                /* epssolve.c:63-146 */
+PetscErrorCode EPSGetIterationNumber(EPS eps, PetscInt *its);
+PetscErrorCode EPSGetConverged(EPS eps, PetscInt *nconv);
+PetscErrorCode EPSGetConvergedReason(EPS eps, EPSConvergedReason *reason);
+PetscErrorCode EPSGetDimensions(EPS eps, PetscInt *nev, PetscInt *ncv, PetscInt *mpd);
+PetscErrorCode EPSGetTolerances(EPS eps, PetscReal *tol, PetscInt *maxits);
+PetscErrorCode EPSGetEigenvalue(EPS eps, PetscInt i, PetscScalar *eigr, PetscScalar *eigi);
+PetscErrorCode EPSGetEigenvector(EPS eps, PetscInt i, Vec Vr, Vec Vi);
+PetscErrorCode EPSGetEigenpair(EPS eps, PetscInt i, PetscScalar *eigr, PetscScalar *eigi, Vec Vr, Vec Vi);
+PetscErrorCode EPSGetErrorEstimate(EPS eps, PetscInt i, PetscReal *errest);
+PetscErrorCode EPSComputeError(EPS eps, PetscInt i, EPSErrorType type, PetscReal *error);
+/* number of Gram-Schmidt passes and operator applications so far (for the byte model) */
+PetscErrorCode EPSGetCounters(EPS eps, PetscInt64 *matvecs, PetscInt64 *gs_passes);
+PetscErrorCode EPSDestroy(EPS *eps);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,675 @@
+/* BV interface layer: creation / registry / active columns / column views
+ * (src/sys/classes/bv/interface/bvbasic.c, bvfunc.c, bvregis.c), the dispatch
+ * wrappers (bvops.c, bvglobal.c) and Gram-Schmidt (bvorthog.c).  The numerical
+ * work is done by the op table of the BV type; this file only holds the host
+ * control flow, which is the same for every type. */
+#include <stdio.h>
+
+#include "ksimpl.h"
+
+PetscInt64 ks_gs_passes = 0;
+
+/* ---- registry (bvfunc.c:677-684, bvregis.c:45-48) ------------------------------- */
+#define KS_MAX_BV_TYPES 16
+static struct { char name[32]; PetscErrorCode (*create)(BV); } bv_types[KS_MAX_BV_TYPES];
+static int bv_ntypes = 0;
+static int bv_registered_builtin = 0;
+
+static void BVRegisterAll(void) {
+  if (bv_registered_builtin) return;
+  bv_registered_builtin = 1;
+  BVRegister("hip", BVCreate_HIP);
+}
+
+PetscErrorCode BVRegister(const char *name, PetscErrorCode (*create)(BV)) {
+  BVRegisterAll();
+  if (!name || !create) SETERRQ(PETSC_ERR_ARG_NULL, "Null argument");
+  for (int i = 0; i < bv_ntypes; i++)
+    if (!strcmp(bv_types[i].name, name)) { bv_types[i].create = create; return 0; }
+  if (bv_ntypes == KS_MAX_BV_TYPES) SETERRQ(PETSC_ERR_MEM, "Too many BV types");
+  snprintf(bv_types[bv_ntypes].name, sizeof(bv_types[0].name), "%s", name);
+  bv_types[bv_ntypes++].create = create;
+  return 0;
+}
+
+/* ---- creation, sizes (bvbasic.c:45-72,171-199; bvfunc.c:160-200) ------------------- */
+PetscErrorCode BVCreate(void *ctx, BV *bv) {
+  BVRegisterAll();
+  if (!bv) SETERRQ(PETSC_ERR_ARG_NULL, "Null argument");
+  BV b = (BV)calloc(1, sizeof(*b));
+  if (!b) SETERRQ(PETSC_ERR_MEM, "Out of memory");
+  b->ctx = ctx;
+  b->n = -1; b->N = -1;
+  b->orthog_type = BV_ORTHOG_CGS;               /* bvfunc.c:184-187 */
+  b->orthog_ref = BV_ORTHOG_REFINE_IFNEEDED;
+  b->orthog_eta = 0.7071;
+  b->ci[0] = b->ci[1] = -1;
+  b->rand_seed = 0x12345678;                    /* bvbasic.c:884 */
+  *bv = b;
+  return 0;
+}
+
+static PetscErrorCode BVSetUpStorage(BV bv) {
+  PetscErrorCode ierr;
+  PetscErrorCode (*r)(BV) = NULL;
+  for (int i = 0; i < bv_ntypes; i++) if (!strcmp(bv_types[i].name, bv->type_name)) r = bv_types[i].create;
+  if (!r) SETERRQ(PETSC_ERR_ARG_WRONG, "Unable to find requested BV type %s", bv->type_name);
+  bv->ci[0] = bv->ci[1] = -bv->nc - 1;
+  ierr = (*r)(bv);CHKERRQ(ierr);
+  return 0;
+}
+
+PetscErrorCode BVSetType(BV bv, const char *type) {
+  PetscErrorCode ierr;
+  if (!bv || !type) SETERRQ(PETSC_ERR_ARG_NULL, "Null argument");
+  if (!strcmp(bv->type_name, type)) return 0;
+  int found = 0;
+  for (int i = 0; i < bv_ntypes; i++) if (!strcmp(bv_types[i].name, type)) found = 1;
+  if (!found) SETERRQ(PETSC_ERR_ARG_WRONG, "Unable to find requested BV type %s", type);
+  if (bv->data) SETERRQ(PETSC_ERR_ORDER, "Cannot change the type of a BV that already has storage");
+  snprintf(bv->type_name, sizeof(bv->type_name), "%s", type);
+  if (bv->n >= 0) { ierr = BVSetUpStorage(bv);CHKERRQ(ierr); }   /* sizes known: create now, else deferred */
+  return 0;
+}
+
+PetscErrorCode BVSetSizesFromVec(BV bv, Vec t, PetscInt m) {
+  PetscErrorCode ierr;
+  if (!bv || !t) SETERRQ(PETSC_ERR_ARG_NULL, "Null argument");
+  if (m <= 0) SETERRQ(PETSC_ERR_ARG_OUTOFRANGE, "Number of columns %d must be positive", m);
+  if (bv->t) SETERRQ(PETSC_ERR_ARG_WRONGSTATE, "Template vector was already set by a previous call to BVSetSizes/FromVec");
+  bv->n = t->n; bv->N = t->N;
+  bv->m = m; bv->k = m; bv->l = 0; bv->nc = 0;
+  ierr = VecCreateWithOps(t->ops, t->ctx, t->n, t->N, t->row0, PETSC_FALSE, &bv->t);CHKERRQ(ierr);
+  if (bv->type_name[0]) { ierr = BVSetUpStorage(bv);CHKERRQ(ierr); }
+  return 0;
+}
+
+#define BVCheckSizes(bv) do { if (!(bv)) SETERRQ(PETSC_ERR_ARG_NULL, "Null BV"); \
+  if (!(bv)->data) SETERRQ(PETSC_ERR_ARG_WRONGSTATE, "BV sizes and type have not been defined: call BVSetSizes() and BVSetType()"); } while (0)
+
+PetscErrorCode BVGetSizes(BV bv, PetscInt64 *n, PetscInt64 *N, PetscInt *m) {
+  if (!bv) SETERRQ(PETSC_ERR_ARG_NULL, "Null BV");
+  if (n) *n = bv->n;
+  if (N) *N = bv->N;
+  if (m) *m = bv->m;
+  return 0;
+}
+
+PetscErrorCode BVResize(BV bv, PetscInt m, PetscBool copy) {
+  PetscErrorCode ierr;
+  BVCheckSizes(bv);
+  if (m <= 0) SETERRQ(PETSC_ERR_ARG_OUTOFRANGE, "Number of columns %d must be positive", m);
+  if (bv->nc) SETERRQ(PETSC_ERR_ARG_WRONGSTATE, "Cannot resize a BV with constraints");
+  if (bv->m == m) return 0;
+  ierr = bv->ops.resize(bv, m, copy);CHKERRQ(ierr);
+  free(bv->buffer); bv->buffer = NULL;
+  free(bv->h); bv->h = NULL;
+  free(bv->c); bv->c = NULL;
+  bv->m = m;
+  bv->k = PetscMin(bv->k, m);
+  bv->l = PetscMin(bv->l, m);
+  return 0;
+}
+
+PetscErrorCode BVSetActiveColumns(BV bv, PetscInt l, PetscInt k) {
+  BVCheckSizes(bv);
+  if (k < 0 || k > bv->m) SETERRQ(PETSC_ERR_ARG_OUTOFRANGE, "Illegal value of k (%d). Must be between 0 and m (%d)", k, bv->m);
+  if (l < 0 || l > k) SETERRQ(PETSC_ERR_ARG_OUTOFRANGE, "Illegal value of l (%d). Must be between 0 and k (%d)", l, k);
+  bv->l = l; bv->k = k;
+  return 0;
+}
+PetscErrorCode BVGetActiveColumns(BV bv, PetscInt *l, PetscInt *k) {
+  if (!bv) SETERRQ(PETSC_ERR_ARG_NULL, "Null BV");
+  if (l) *l = bv->l;
+  if (k) *k = bv->k;
+  return 0;
+}
+
+PetscErrorCode BVSetOrthogonalization(BV bv, BVOrthogType type, BVOrthogRefineType refine, PetscReal eta) {
+  if (!bv) SETERRQ(PETSC_ERR_ARG_NULL, "Null BV");
+  if (type != BV_ORTHOG_CGS && type != BV_ORTHOG_MGS) SETERRQ(PETSC_ERR_ARG_WRONG, "Unknown orthogonalization type");
+  if (refine < BV_ORTHOG_REFINE_IFNEEDED || refine > BV_ORTHOG_REFINE_ALWAYS) SETERRQ(PETSC_ERR_ARG_WRONG, "Unknown refinement type");
+  bv->orthog_type = type; bv->orthog_ref = refine;
+  if (eta == 0.0) bv->orthog_eta = 0.7071;       /* PETSC_DEFAULT */
+  else {
+    if (eta <= 0.0 || eta > 1.0) SETERRQ(PETSC_ERR_ARG_OUTOFRANGE, "Invalid eta value");
+    bv->orthog_eta = eta;
+  }
+  return 0;
+}
+
+/* ---- column views (bvbasic.c:1152-1224) ----------------------------------------------- */
+PetscErrorCode BVGetColumn(BV bv, PetscInt j, Vec *v) {
+  PetscErrorCode ierr;
+  BVCheckSizes(bv);
+  if (j < 0 && -j > bv->nc) SETERRQ(PETSC_ERR_ARG_OUTOFRANGE, "You requested constraint %d but only %d are available", -j, bv->nc);
+  if (j >= bv->m) SETERRQ(PETSC_ERR_ARG_OUTOFRANGE, "You requested column %d but only %d are available", j, bv->m);
+  if (j == bv->ci[0] || j == bv->ci[1]) SETERRQ(PETSC_ERR_SUP, "Column %d already fetched in a previous call to BVGetColumn", j);
+  const int l = (bv->ci[0] == -bv->nc - 1) ? 0 : (bv->ci[1] == -bv->nc - 1) ? 1 : -1;    /* BVAvailableVec */
+  if (l == -1) SETERRQ(PETSC_ERR_SUP, "Too many requested columns; you must call BVRestoreColumn for one of the previously fetched columns");
+  ierr = bv->ops.getcolumn(bv, j, v);CHKERRQ(ierr);
+  bv->ci[l] = j;
+  bv->st[l] = bv->cv[l]->state;
+  *v = bv->cv[l];
+  return 0;
+}
+
+PetscErrorCode BVRestoreColumn(BV bv, PetscInt j, Vec *v) {
+  PetscErrorCode ierr;
+  BVCheckSizes(bv);
+  if (!v || !*v) SETERRQ(PETSC_ERR_ARG_NULL, "Null vector");
+  if (j != bv->ci[0] && j != bv->ci[1]) SETERRQ(PETSC_ERR_ARG_WRONG, "Column %d has not been fetched with a call to BVGetColumn", j);
+  const int l = (j == bv->ci[0]) ? 0 : 1;
+  if (*v != bv->cv[l]) SETERRQ(PETSC_ERR_ARG_WRONG, "Argument 3 is not the same Vec that was obtained with BVGetColumn");
+  if (bv->cv[l]->state != bv->st[l]) bv->state++;           /* the view was modified */
+  if (bv->ops.restorecolumn) { ierr = bv->ops.restorecolumn(bv, j, v);CHKERRQ(ierr); }
+  bv->ci[l] = -bv->nc - 1;
+  *v = NULL;
+  return 0;
+}
+
+/* bvbasic.c:791-827: host array of (nc+m)*m coefficients, leading dimension nc+m */
+PetscErrorCode BVGetBuffer(BV bv, PetscScalar **buffer, PetscInt *ld) {
+  BVCheckSizes(bv);
+  if (!bv->buffer) {
+    bv->buffer = (PetscScalar *)calloc((size_t)(bv->nc + bv->m) * bv->m, sizeof(PetscScalar));
+    if (!bv->buffer) SETERRQ(PETSC_ERR_MEM, "Out of memory");
+  }
+  if (buffer) *buffer = bv->buffer;
+  if (ld) *ld = bv->nc + bv->m;
+  return 0;
+}
+
+/* ---- data movement (bvfunc.c:280-377, bvbasic.c:1540-1650, bvops.c:462-479) -------------- */
+PetscErrorCode BVInsertVec(BV bv, PetscInt j, Vec w) {
+  PetscErrorCode ierr;
+  Vec v;
+  BVCheckSizes(bv);
+  if (!w) SETERRQ(PETSC_ERR_ARG_NULL, "Null vector");
+  if (w->N != bv->N || w->n != bv->n) SETERRQ(PETSC_ERR_ARG_INCOMP, "Vec sizes (global %lld, local %lld) do not match BV sizes (global %lld, local %lld)", (long long)w->N, (long long)w->n, (long long)bv->N, (long long)bv->n);
+  if (j < 0 || j >= bv->m) SETERRQ(PETSC_ERR_ARG_OUTOFRANGE, "Argument j has wrong value %d, should be between 0 and %d", j, bv->m - 1);
+  ierr = BVGetColumn(bv, j, &v);CHKERRQ(ierr);
+  ierr = VecCopy(w, v);CHKERRQ(ierr);
+  ierr = BVRestoreColumn(bv, j, &v);CHKERRQ(ierr);
+  bv->state++;
+  return 0;
+}
+
+PetscErrorCode BVInsertVecs(BV V, PetscInt s, PetscInt *m, Vec *W, PetscBool orth) {
+  PetscErrorCode ierr;
+  PetscInt i, ndep;
+  PetscBool lindep;
+  PetscReal norm;
+  Vec v;
+  BVCheckSizes(V);
+  if (!m) SETERRQ(PETSC_ERR_ARG_NULL, "Null argument");
+  if (!*m) return 0;
+  if (*m < 0) SETERRQ(PETSC_ERR_ARG_OUTOFRANGE, "Number of vectors (given %d) cannot be negative", *m);
+  if (!W || !*W) SETERRQ(PETSC_ERR_ARG_NULL, "Null argument");
+  if ((*W)->N != V->N || (*W)->n != V->n) SETERRQ(PETSC_ERR_ARG_INCOMP, "Vec sizes do not match BV sizes");
+  if (s < 0 || s >= V->m) SETERRQ(PETSC_ERR_ARG_OUTOFRANGE, "Argument s has wrong value %d, should be between 0 and %d", s, V->m - 1);
+  if (s + (*m) > V->m) SETERRQ(PETSC_ERR_ARG_OUTOFRANGE, "Too many vectors provided, there is only room for %d", V->m);
+  ndep = 0;
+  for (i = 0; i < *m; i++) {
+    ierr = BVGetColumn(V, s + i - ndep, &v);CHKERRQ(ierr);
+    ierr = VecCopy(W[i], v);CHKERRQ(ierr);
+    ierr = BVRestoreColumn(V, s + i - ndep, &v);CHKERRQ(ierr);
+    if (orth) {
+      ierr = BVOrthogonalizeColumn(V, s + i - ndep, NULL, &norm, &lindep);CHKERRQ(ierr);
+      if (norm == 0.0 || lindep) ndep++;
+      else { ierr = BVScaleColumn(V, s + i - ndep, 1.0 / norm);CHKERRQ(ierr); }
+    }
+  }
+  *m -= ndep;
+  V->state++;
+  return 0;
+}
+
+/* The reference fills the column from a PetscRandom (bvops.c:390-412); here the
+ * values are a counter-based hash of (seed, global row), reproducible for any
+ * row partition, like its -bv_reproducible_random mode. */
+PetscErrorCode BVSetRandomColumn(BV bv, PetscInt j) {
+  PetscErrorCode ierr;
+  Vec v;
+  BVCheckSizes(bv);
+  if (j < 0 || j >= bv->m) SETERRQ(PETSC_ERR_ARG_OUTOFRANGE, "Argument j has wrong value %d, the number of columns is %d", j, bv->m);
+  ierr = BVGetColumn(bv, j, &v);CHKERRQ(ierr);
+  ierr = VecFillHash(v, bv->rand_seed);CHKERRQ(ierr);
+  bv->rand_seed = bv->rand_seed * 6364136223846793005ULL + 1442695040888963407ULL;
+  ierr = BVRestoreColumn(bv, j, &v);CHKERRQ(ierr);
+  bv->state++;
+  return 0;
+}
+
+PetscErrorCode BVCopy(BV V, BV W) {
+  PetscErrorCode ierr;
+  BVCheckSizes(V); BVCheckSizes(W);
+  if (V->n != W->n) SETERRQ(PETSC_ERR_ARG_INCOMP, "Mismatching local dimension V %lld, W %lld", (long long)V->n, (long long)W->n);
+  if (V->k - V->l > W->m - W->l) SETERRQ(PETSC_ERR_ARG_SIZ, "W has %d non-leading columns, not enough to store %d columns", W->m - W->l, V->k - V->l);
+  if (!V->n) return 0;
+  W->k = W->l + V->k - V->l;
+  ierr = V->ops.copy(V, W);CHKERRQ(ierr);
+  W->state++;
+  return 0;
+}
+
+PetscErrorCode BVCopyVec(BV V, PetscInt j, Vec w) {
+  PetscErrorCode ierr;
+  Vec z;
+  BVCheckSizes(V);
+  if (!w) SETERRQ(PETSC_ERR_ARG_NULL, "Null vector");
+  if (w->n != V->n) SETERRQ(PETSC_ERR_ARG_INCOMP, "Mismatching local dimension V %lld, w %lld", (long long)V->n, (long long)w->n);
+  ierr = BVGetColumn(V, j, &z);CHKERRQ(ierr);
+  ierr = VecCopy(z, w);CHKERRQ(ierr);
+  ierr = BVRestoreColumn(V, j, &z);CHKERRQ(ierr);
+  return 0;
+}
+
+PetscErrorCode BVCopyColumn(BV V, PetscInt j, PetscInt i) {
+  PetscErrorCode ierr;
+  Vec z, w;
+  BVCheckSizes(V);
+  if (j == i) return 0;
+  ierr = BVGetColumn(V, j, &z);CHKERRQ(ierr);
+  ierr = BVGetColumn(V, i, &w);CHKERRQ(ierr);
+  ierr = VecCopy(z, w);CHKERRQ(ierr);
+  ierr = BVRestoreColumn(V, j, &z);CHKERRQ(ierr);
+  ierr = BVRestoreColumn(V, i, &w);CHKERRQ(ierr);
+  return 0;
+}
+
+/* ---- products (bvops.c:60-313) ------------------------------------------------------------- */
+PetscErrorCode BVMult(BV Y, PetscScalar alpha, PetscScalar beta, BV X, const PetscScalar *Q, PetscInt ldq) {
+  PetscErrorCode ierr;
+  BVCheckSizes(Y); BVCheckSizes(X);
+  if (X == Y) SETERRQ(PETSC_ERR_ARG_WRONG, "X and Y arguments must be different");
+  if (Q) {
+    if (ldq < X->k) SETERRQ(PETSC_ERR_ARG_SIZ, "Mat argument has %d rows, should have at least %d", ldq, X->k);
+  } else if (X->k - X->l != Y->k - Y->l) SETERRQ(PETSC_ERR_ARG_SIZ, "Y has %d active columns, should match %d active columns in X", Y->k - Y->l, X->k - X->l);
+  if (X->n != Y->n) SETERRQ(PETSC_ERR_ARG_INCOMP, "Mismatching local dimension X %lld, Y %lld", (long long)X->n, (long long)Y->n);
+  if (!X->n) return 0;
+  ierr = Y->ops.mult(Y, alpha, beta, X, Q, ldq);CHKERRQ(ierr);
+  Y->state++;
+  return 0;
+}
+
+PetscErrorCode BVMultVec(BV X, PetscScalar alpha, PetscScalar beta, Vec y, PetscScalar *q) {
+  PetscErrorCode ierr;
+  BVCheckSizes(X);
+  if (!y) SETERRQ(PETSC_ERR_ARG_NULL, "Null vector");
+  if (X->n != y->n) SETERRQ(PETSC_ERR_ARG_INCOMP, "Mismatching local dimension X %lld, y %lld", (long long)X->n, (long long)y->n);
+  if (!X->n) return 0;
+  if (!q) { ierr = BVGetBuffer(X, &q, NULL);CHKERRQ(ierr); }
+  ierr = X->ops.multvec(X, alpha, beta, y, q);CHKERRQ(ierr);
+  y->state++;
+  return 0;
+}
+
+PetscErrorCode BVMultColumn(BV X, PetscScalar alpha, PetscScalar beta, PetscInt j, PetscScalar *q) {
+  PetscErrorCode ierr;
+  PetscInt ksave;
+  Vec y;
+  BVCheckSizes(X);
+  if (j < 0) SETERRQ(PETSC_ERR_ARG_OUTOFRANGE, "Index j must be non-negative");
+  if (j >= X->m) SETERRQ(PETSC_ERR_ARG_OUTOFRANGE, "Index j=%d but BV only has %d columns", j, X->m);
+  ksave = X->k;
+  X->k = j;
+  if (!q) { ierr = BVGetBuffer(X, &q, NULL);CHKERRQ(ierr); }
+  ierr = BVGetColumn(X, j, &y);CHKERRQ(ierr);
+  ierr = X->ops.multvec(X, alpha, beta, y, q);
+  if (!ierr) y->state++;
+  X->k = ksave;
+  CHKERRQ(ierr);
+  ierr = BVRestoreColumn(X, j, &y);CHKERRQ(ierr);
+  return 0;
+}
+
+static PetscErrorCode BVMultInPlace_Check(BV V, const PetscScalar *Q, PetscInt ldq, PetscInt s, PetscInt e, PetscBool trans) {
+  if (!Q) SETERRQ(PETSC_ERR_ARG_NULL, "Null matrix");
+  if (s < V->l || s > V->m) SETERRQ(PETSC_ERR_ARG_OUTOFRANGE, "Argument s has wrong value %d, should be between %d and %d", s, V->l, V->m);
+  if (e < V->l || e > V->m) SETERRQ(PETSC_ERR_ARG_OUTOFRANGE, "Argument e has wrong value %d, should be between %d and %d", e, V->l, V->m);
+  if (!trans && ldq < V->k) SETERRQ(PETSC_ERR_ARG_SIZ, "Mat argument has %d rows, should have at least %d", ldq, V->k);
+  if (trans && e > ldq) SETERRQ(PETSC_ERR_ARG_SIZ, "Mat argument only has %d rows, the requested value of e is larger: %d", ldq, e);
+  return 0;
+}
+
+PetscErrorCode BVMultInPlace(BV V, const PetscScalar *Q, PetscInt ldq, PetscInt s, PetscInt e) {
+  PetscErrorCode ierr;
+  BVCheckSizes(V);
+  ierr = BVMultInPlace_Check(V, Q, ldq, s, e, PETSC_FALSE);CHKERRQ(ierr);
+  if (s >= e || !V->n) return 0;
+  ierr = V->ops.multinplace(V, Q, ldq, s, e);CHKERRQ(ierr);
+  V->state++;
+  return 0;
+}
+
+PetscErrorCode BVMultInPlaceTranspose(BV V, const PetscScalar *Q, PetscInt ldq, PetscInt s, PetscInt e) {
+  PetscErrorCode ierr;
+  BVCheckSizes(V);
+  ierr = BVMultInPlace_Check(V, Q, ldq, s, e, PETSC_TRUE);CHKERRQ(ierr);
+  if (s >= e || !V->n) return 0;
+  ierr = V->ops.multinplacetrans(V, Q, ldq, s, e);CHKERRQ(ierr);
+  V->state++;
+  return 0;
+}
+
+/* ---- reductions (bvglobal.c:92-188,324-349,520-545,704-730) ------------------------------------ */
+PetscErrorCode BVDot(BV X, BV Y, PetscScalar *M, PetscInt ldm) {
+  PetscErrorCode ierr;
+  BVCheckSizes(X); BVCheckSizes(Y);
+  if (!M) SETERRQ(PETSC_ERR_ARG_NULL, "Null matrix");
+  if (ldm < Y->k) SETERRQ(PETSC_ERR_ARG_SIZ, "Mat argument has %d rows, should have at least %d", ldm, Y->k);
+  if (X->n != Y->n) SETERRQ(PETSC_ERR_ARG_INCOMP, "Mismatching local dimension X %lld, Y %lld", (long long)X->n, (long long)Y->n);
+  ierr = X->ops.dot(X, Y, M, ldm);CHKERRQ(ierr);
+  return 0;
+}
+
+PetscErrorCode BVDotVec(BV X, Vec y, PetscScalar *q) {
+  PetscErrorCode ierr;
+  BVCheckSizes(X);
+  if (!y) SETERRQ(PETSC_ERR_ARG_NULL, "Null vector");
+  if (X->n != y->n) SETERRQ(PETSC_ERR_ARG_INCOMP, "Mismatching local dimension X %lld, y %lld", (long long)X->n, (long long)y->n);
+  if (!q) { ierr = BVGetBuffer(X, &q, NULL);CHKERRQ(ierr); }
+  ierr = X->ops.dotvec(X, y, q);CHKERRQ(ierr);
+  return 0;
+}
+
+PetscErrorCode BVDotColumn(BV X, PetscInt j, PetscScalar *q) {
+  PetscErrorCode ierr;
+  PetscInt ksave;
+  Vec y;
+  BVCheckSizes(X);
+  if (j < 0) SETERRQ(PETSC_ERR_ARG_OUTOFRANGE, "Index j must be non-negative");
+  if (j >= X->m) SETERRQ(PETSC_ERR_ARG_OUTOFRANGE, "Index j=%d but BV only has %d columns", j, X->m);
+  ksave = X->k;
+  X->k = j;
+  if (!q) { ierr = BVGetBuffer(X, &q, NULL);CHKERRQ(ierr); }
+  ierr = BVGetColumn(X, j, &y);CHKERRQ(ierr);
+  ierr = X->ops.dotvec(X, y, q);
+  X->k = ksave;
+  CHKERRQ(ierr);
+  ierr = BVRestoreColumn(X, j, &y);CHKERRQ(ierr);
+  return 0;
+}
+
+/* bvorthog.c:176-192: as BVDotColumn but including column j itself */
+static PetscErrorCode BVDotColumnInc(BV X, PetscInt j, PetscScalar *q) {
+  PetscErrorCode ierr;
+  PetscInt ksave;
+  Vec y;
+  ksave = X->k;
+  X->k = j + 1;
+  ierr = BVGetColumn(X, j, &y);CHKERRQ(ierr);
+  ierr = X->ops.dotvec(X, y, q);
+  X->k = ksave;
+  CHKERRQ(ierr);
+  ierr = BVRestoreColumn(X, j, &y);CHKERRQ(ierr);
+  return 0;
+}
+
+PetscErrorCode BVScale(BV bv, PetscScalar alpha) {
+  PetscErrorCode ierr;
+  BVCheckSizes(bv);
+  if (!bv->n || (bv->l == bv->k && !bv->nc) || alpha == 1.0) return 0;
+  ierr = bv->ops.scale(bv, -1, alpha);CHKERRQ(ierr);
+  bv->state++;
+  return 0;
+}
+
+PetscErrorCode BVScaleColumn(BV bv, PetscInt j, PetscScalar alpha) {
+  PetscErrorCode ierr;
+  BVCheckSizes(bv);
+  if (j < 0 || j >= bv->m) SETERRQ(PETSC_ERR_ARG_OUTOFRANGE, "Argument j has wrong value %d, the number of columns is %d", j, bv->m);
+  if (!bv->n || alpha == 1.0) return 0;
+  ierr = bv->ops.scale(bv, j, alpha);CHKERRQ(ierr);
+  bv->state++;
+  return 0;
+}
+
+PetscErrorCode BVNorm(BV bv, NormType type, PetscReal *val) {
+  PetscErrorCode ierr;
+  BVCheckSizes(bv);
+  if (!val) SETERRQ(PETSC_ERR_ARG_NULL, "Null argument");
+  if (type == NORM_2) SETERRQ(PETSC_ERR_SUP, "Requested norm not available");
+  ierr = bv->ops.norm(bv, -1, type, val);CHKERRQ(ierr);
+  return 0;
+}
+
+PetscErrorCode BVNormColumn(BV bv, PetscInt j, NormType type, PetscReal *val) {
+  PetscErrorCode ierr;
+  BVCheckSizes(bv);
+  if (!val) SETERRQ(PETSC_ERR_ARG_NULL, "Null argument");
+  if (j < 0 || j >= bv->m) SETERRQ(PETSC_ERR_ARG_OUTOFRANGE, "Argument j has wrong value %d, the number of columns is %d", j, bv->m);
+  ierr = bv->ops.norm(bv, j, type, val);CHKERRQ(ierr);
+  return 0;
+}
+
+PetscErrorCode BVNormVec(BV bv, Vec v, NormType type, PetscReal *val) {
+  PetscErrorCode ierr;
+  BVCheckSizes(bv);
+  if (!v || !val) SETERRQ(PETSC_ERR_ARG_NULL, "Null argument");
+  if (bv->n != v->n) SETERRQ(PETSC_ERR_ARG_INCOMP, "Mismatching local dimension bv %lld, v %lld", (long long)bv->n, (long long)v->n);
+  ierr = VecNorm(v, type, val);CHKERRQ(ierr);
+  return 0;
+}
+
+PetscErrorCode BVMatMult(BV V, Mat A, BV W) {
+  PetscErrorCode ierr;
+  BVCheckSizes(V); BVCheckSizes(W);
+  if (!A) SETERRQ(PETSC_ERR_ARG_NULL, "Null matrix");
+  if (V->n != A->n) SETERRQ(PETSC_ERR_ARG_INCOMP, "Mat argument has %lld columns, cannot multiply a BV with %lld rows", (long long)A->n, (long long)V->n);
+  if (W->n != A->n) SETERRQ(PETSC_ERR_ARG_INCOMP, "Mat argument has %lld rows, cannot store the result in a BV with %lld rows", (long long)A->n, (long long)W->n);
+  if (V->k - V->l > W->m - W->l) SETERRQ(PETSC_ERR_ARG_SIZ, "W has %d non-leading columns, not enough to store %d columns", W->m - W->l, V->k - V->l);
+  W->k = W->l + V->k - V->l;
+  ierr = V->ops.matmult(V, A, W);CHKERRQ(ierr);
+  W->state++;
+  return 0;
+}
+
+/* ---- Gram-Schmidt (bvorthog.c) ----------------------------------------------------------------- */
+/* coefficient arrays: h == NULL means "column j of the buffer", c == NULL means
+ * "column 0 of the buffer" (bvorthog.c:30-156) */
+static PetscScalar *HH(BV bv, PetscInt j, PetscScalar *h) { return h ? h : bv->buffer + (size_t)j * (bv->nc + bv->m); }
+static PetscScalar *CC(BV bv, PetscScalar *c) { return c ? c : bv->buffer; }
+
+static PetscErrorCode BV_SafeSqrt(PetscScalar alpha, PetscReal *res) {     /* bvimpl.h:113-134, definite case */
+  if (alpha < 0.0) SETERRQ(1, "The inner product is not well defined: indefinite matrix");
+  *res = sqrt(alpha);
+  return 0;
+}
+
+static PetscErrorCode BV_NormVecOrColumn(BV bv, PetscInt j, Vec v, PetscReal *nrm) {
+  PetscErrorCode ierr;
+  if (v) { ierr = BVNormVec(bv, v, NORM_2, nrm);CHKERRQ(ierr); }
+  else { ierr = BVNormColumn(bv, j, NORM_2, nrm);CHKERRQ(ierr); }
+  return 0;
+}
+
+/* bvorthog.c:197-227 */
+static PetscErrorCode BVOrthogonalizeMGS1(BV bv, PetscInt j, Vec v, PetscScalar *h, PetscScalar *c, PetscReal *onrm, PetscReal *nrm) {
+  PetscErrorCode ierr;
+  PetscInt i;
+  PetscScalar dot, *cc = CC(bv, c), *hh = HH(bv, j, h);
+  Vec vi, w = v;
+  if (!v) { ierr = BVGetColumn(bv, j, &w);CHKERRQ(ierr); }
+  if (onrm) { ierr = BVNormVec(bv, w, NORM_2, onrm);CHKERRQ(ierr); }
+  for (i = -bv->nc; i < j; i++) {
+    ierr = BVGetColumn(bv, i, &vi);CHKERRQ(ierr);
+    ierr = VecDot(w, vi, &dot);CHKERRQ(ierr);
+    cc[bv->nc + i] = dot;
+    ierr = VecAXPY(w, -dot, vi);CHKERRQ(ierr);
+    ierr = BVRestoreColumn(bv, i, &vi);CHKERRQ(ierr);
+  }
+  if (nrm) { ierr = BVNormVec(bv, w, NORM_2, nrm);CHKERRQ(ierr); }
+  if (!v) { ierr = BVRestoreColumn(bv, j, &w);CHKERRQ(ierr); }
+  for (i = 0; i < bv->nc + j; i++) hh[i] += cc[i];
+  ks_gs_passes++;
+  return 0;
+}
+
+/* bvorthog.c:233-277: |v'| (estimated), |v| and one step of CGS with one global reduction */
+static PetscErrorCode BVOrthogonalizeCGS1(BV bv, PetscInt j, Vec v, PetscScalar *h, PetscScalar *c, PetscReal *onorm, PetscReal *norm) {
+  PetscErrorCode ierr;
+  PetscReal sum, beta = 0.0;
+  PetscScalar *cc = CC(bv, c), *hh = HH(bv, j, h);
+  PetscInt i;
+  bv->k = j;
+  if (onorm || norm) {
+    if (!v) {
+      ierr = BVDotColumnInc(bv, j, c ? c : bv->buffer);CHKERRQ(ierr);
+      ierr = BV_SafeSqrt(cc[bv->nc + j], &beta);CHKERRQ(ierr);
+    } else {
+      ierr = BVDotVec(bv, v, cc);CHKERRQ(ierr);
+      ierr = BVNormVec(bv, v, NORM_2, &beta);CHKERRQ(ierr);
+    }
+  } else {
+    if (!v) { ierr = BVDotColumn(bv, j, cc);CHKERRQ(ierr); }
+    else { ierr = BVDotVec(bv, v, cc);CHKERRQ(ierr); }
+  }
+  /* q = v - V h */
+  if (!v) { ierr = BVMultColumn(bv, -1.0, 1.0, j, cc);CHKERRQ(ierr); }
+  else { ierr = BVMultVec(bv, -1.0, 1.0, v, cc);CHKERRQ(ierr); }
+  if (onorm) *onorm = beta;
+  if (norm) {
+    sum = 0.0;
+    for (i = 0; i < bv->nc + j; i++) sum += cc[i] * cc[i];      /* BV_SquareSum */
+    *norm = beta * beta - sum;
+    if (*norm <= 0.0) { ierr = BV_NormVecOrColumn(bv, j, v, norm);CHKERRQ(ierr); }
+    else *norm = sqrt(*norm);
+  }
+  for (i = 0; i < bv->nc + j; i++) hh[i] += cc[i];               /* BV_AddCoefficients */
+  ks_gs_passes++;
+  return 0;
+}
+
+/* bvorthog.c:290-361 */
+static PetscErrorCode BVOrthogonalizeGS(BV bv, PetscInt j, Vec v, PetscReal *norm, PetscBool *lindep) {
+  PetscErrorCode ierr;
+  PetscScalar *h, *c, *hh;
+  PetscReal onrm = 0.0, nrm = 0.0;
+  PetscInt k, l, i;
+  const PetscBool mgs = (bv->orthog_type == BV_ORTHOG_MGS);
+  const PetscBool dolindep = lindep ? PETSC_TRUE : PETSC_FALSE;
+  if (v) { k = bv->k; h = bv->h; c = bv->c; }
+  else { k = j; h = NULL; c = NULL; }
+#define GS1(on, nr) (mgs ? BVOrthogonalizeMGS1(bv, k, v, h, c, on, nr) : BVOrthogonalizeCGS1(bv, k, v, h, c, on, nr))
+  hh = HH(bv, k, h);
+  for (i = 0; i < bv->nc + k; i++) hh[i] = 0.0;                   /* BV_CleanCoefficients */
+  switch (bv->orthog_ref) {
+    case BV_ORTHOG_REFINE_IFNEEDED:
+      ierr = GS1(&onrm, &nrm);CHKERRQ(ierr);
+      l = 1;
+      while (l < 3 && nrm && nrm < bv->orthog_eta * onrm) {
+        l++;
+        if (mgs) onrm = nrm;
+        ierr = GS1(mgs ? NULL : &onrm, &nrm);CHKERRQ(ierr);
+      }
+      if (dolindep) *lindep = !(nrm && nrm >= bv->orthog_eta * onrm);
+      break;
+    case BV_ORTHOG_REFINE_NEVER:
+      ierr = GS1(NULL, NULL);CHKERRQ(ierr);
+      if (norm || dolindep) { ierr = BV_NormVecOrColumn(bv, k, v, &nrm);CHKERRQ(ierr); }
+      if (dolindep) *lindep = !nrm;
+      break;
+    case BV_ORTHOG_REFINE_ALWAYS:
+      ierr = GS1(NULL, NULL);CHKERRQ(ierr);
+      ierr = GS1(dolindep ? &onrm : NULL, (norm || dolindep) ? &nrm : NULL);CHKERRQ(ierr);
+      if (dolindep) *lindep = !(nrm && nrm >= bv->orthog_eta * onrm);
+      break;
+  }
+#undef GS1
+  if (norm) {
+    *norm = nrm;
+    if (!v) hh[bv->nc + k] = (dolindep && *lindep) ? 0.0 : nrm;    /* store the norm next to the coefficients */
+  }
+  return 0;
+}
+
+static PetscErrorCode BV_AllocateCoeffs(BV bv) {
+  if (!bv->h) {
+    bv->h = (PetscScalar *)calloc((size_t)2 * (bv->nc + bv->m), sizeof(PetscScalar));
+    if (!bv->h) SETERRQ(PETSC_ERR_MEM, "Out of memory");
+    bv->c = bv->h + bv->nc + bv->m;
+  }
+  return 0;
+}
+
+/* bvorthog.c:391-418 */
+PetscErrorCode BVOrthogonalizeVec(BV bv, Vec v, PetscScalar *H, PetscReal *norm, PetscBool *lindep) {
+  PetscErrorCode ierr;
+  PetscInt i, ksave, lsave;
+  BVCheckSizes(bv);
+  if (!v) SETERRQ(PETSC_ERR_ARG_NULL, "Null vector");
+  ksave = bv->k; lsave = bv->l;
+  bv->l = -bv->nc;
+  ierr = BV_AllocateCoeffs(bv);CHKERRQ(ierr);
+  ierr = BVGetBuffer(bv, NULL, NULL);CHKERRQ(ierr);
+  ierr = BVOrthogonalizeGS(bv, 0, v, norm, lindep);
+  bv->k = ksave; bv->l = lsave;
+  CHKERRQ(ierr);
+  if (H) for (i = bv->l; i < bv->k; i++) H[i - bv->l] = bv->h[bv->nc + i];     /* BV_StoreCoefficients */
+  return 0;
+}
+
+/* bvorthog.c:460-485 */
+PetscErrorCode BVOrthogonalizeColumn(BV bv, PetscInt j, PetscScalar *H, PetscReal *norm, PetscBool *lindep) {
+  PetscErrorCode ierr;
+  PetscInt i, ksave, lsave;
+  BVCheckSizes(bv);
+  if (j < 0) SETERRQ(PETSC_ERR_ARG_OUTOFRANGE, "Index j must be non-negative");
+  if (j >= bv->m) SETERRQ(PETSC_ERR_ARG_OUTOFRANGE, "Index j=%d but BV only has %d columns", j, bv->m);
+  ksave = bv->k; lsave = bv->l;
+  bv->l = -bv->nc;
+  ierr = BVGetBuffer(bv, NULL, NULL);CHKERRQ(ierr);
+  ierr = BVOrthogonalizeGS(bv, j, NULL, norm, lindep);
+  bv->k = ksave; bv->l = lsave;
+  CHKERRQ(ierr);
+  if (H) { PetscScalar *hh = HH(bv, j, NULL); for (i = bv->l; i < j; i++) H[i - bv->l] = hh[bv->nc + i]; }
+  bv->state++;
+  return 0;
+}
+
+/* bvorthog.c:523-572 */
+PetscErrorCode BVOrthonormalizeColumn(BV bv, PetscInt j, PetscBool replace, PetscReal *norm, PetscBool *lindep) {
+  PetscErrorCode ierr;
+  PetscReal nrm;
+  PetscInt ksave, lsave;
+  PetscBool lndep;
+  BVCheckSizes(bv);
+  if (j < 0) SETERRQ(PETSC_ERR_ARG_OUTOFRANGE, "Index j must be non-negative");
+  if (j >= bv->m) SETERRQ(PETSC_ERR_ARG_OUTOFRANGE, "Index j=%d but BV only has %d columns", j, bv->m);
+  ksave = bv->k; lsave = bv->l;
+  bv->l = -bv->nc;
+  ierr = BVGetBuffer(bv, NULL, NULL);CHKERRQ(ierr);
+  ierr = BVOrthogonalizeGS(bv, j, NULL, &nrm, &lndep);
+  if (!ierr && replace && (nrm == 0.0 || lndep)) {
+    ierr = BVSetRandomColumn(bv, j);
+    if (!ierr) ierr = BVOrthogonalizeGS(bv, j, NULL, &nrm, &lndep);
+    if (!ierr && (nrm == 0.0 || lndep)) {
+      ierr = BVSetRandomColumn(bv, j);
+      if (!ierr) ierr = BVOrthogonalizeGS(bv, j, NULL, &nrm, &lndep);
+    }
+  }
+  bv->k = ksave; bv->l = lsave;
+  CHKERRQ(ierr);
+  if (nrm != 1.0 && nrm != 0.0 && bv->n) { ierr = bv->ops.scale(bv, j, 1.0 / nrm);CHKERRQ(ierr); }
+  if (norm) *norm = nrm;
+  if (lindep) *lindep = lndep;
+  bv->state++;
+  return 0;
+}
+
+PetscErrorCode BVDestroy(BV *bv) {
+  PetscErrorCode ierr;
+  if (!bv || !*bv) return 0;
+  BV b = *bv;
+  if (b->data && b->ops.destroy) { ierr = b->ops.destroy(b);CHKERRQ(ierr); }
+  ierr = VecDestroy(&b->t);CHKERRQ(ierr);
+  ierr = VecDestroy(&b->cv[0]);CHKERRQ(ierr);
+  ierr = VecDestroy(&b->cv[1]);CHKERRQ(ierr);
+  free(b->buffer);
+  free(b->h);
+  free(b);
+  *bv = NULL;
+  return 0;
+}

@@ -1,0 +1,15 @@
+/* LAPACK-free dense kernels for the projected problem (see dense.c). */
+#ifndef KS_DENSE_H
+#define KS_DENSE_H
+
+void ksd_lartg(double f, double g, double *c, double *s, double *r);
+void ksd_rot(int n, double *x, double *y, double c, double s);
+int ksd_steqr(int n, double *d, double *e, double *Z, int ldz, int nrows);
+int ksd_gehrd_orghr(int n, int ilo, double *A, int lda, double *Q, int ldq);
+void ksd_lanv2(double *a, double *b, double *c, double *d, double *rt1r, double *rt1i,
+               double *rt2r, double *rt2i, double *cs, double *sn);
+int ksd_hseqr(int n, int ilo, double *T, int ldt, double *wr, double *wi, double *Z, int ldz);
+int ksd_trexc(int n, double *T, int ldt, double *Q, int ldq, int nq, int ifst, int ilst);
+int ksd_trevc_right(int n, const double *T, int ldt, int k, double *xr, double *xi);
+
+#endif

@@ -1,0 +1,613 @@
+/* EPS: the eigensolver object and its Krylov-Schur drivers -- host control flow
+ * only; every vector operation goes through the BV/Vec/Mat op tables and so runs
+ * on the device.  Follows src/eps/interface/{epsbasic,epsopts,epssetup,epssolve,
+ * epsdefault}.c, src/eps/impls/krylov/epskrylov.c and
+ * src/eps/impls/krylov/krylovschur/{krylovschur,ks-symm}.c of the reference. */
+#include "ksimpl.h"
+
+#define EPSCheckSolved(eps) do { if ((eps)->state < 2) SETERRQ(PETSC_ERR_ARG_WRONGSTATE, "Must call EPSSolve() first: Parameter #1"); } while (0)
+
+/* ---- creation and options (epsbasic.c:60-80, epsopts.c) ----------------------------------- */
+PetscErrorCode EPSCreate(void *ctx, EPS *outeps) {
+  PetscErrorCode ierr;
+  if (!outeps) SETERRQ(PETSC_ERR_ARG_NULL, "Null argument");
+  EPS eps = (EPS)calloc(1, sizeof(*eps));
+  if (!eps) SETERRQ(PETSC_ERR_MEM, "Out of memory");
+  eps->ctx = ctx;
+  eps->nev = 1;
+  eps->tol = 0.0;                 /* PETSC_DEFAULT -> 1e-8 at setup (epssetup.c:184) */
+  eps->lock = PETSC_TRUE;
+  eps->problem_type = (EPSProblemType)0;
+  ierr = BVCreate(ctx, &eps->V);CHKERRQ(ierr);
+  ierr = DSCreate(&eps->ds);CHKERRQ(ierr);
+  *outeps = eps;
+  return 0;
+}
+
+PetscErrorCode EPSSetOperators(EPS eps, Mat A, Mat B) {
+  if (!eps || !A) SETERRQ(PETSC_ERR_ARG_NULL, "Null argument");
+  if (B) SETERRQ(PETSC_ERR_SUP, "Generalized problems are not available");
+  eps->A = A;
+  eps->state = 0;
+  return 0;
+}
+
+PetscErrorCode EPSSetProblemType(EPS eps, EPSProblemType type) {
+  if (!eps) SETERRQ(PETSC_ERR_ARG_NULL, "Null EPS");
+  switch (type) {
+    case EPS_HEP: eps->ishermitian = PETSC_TRUE; break;
+    case EPS_NHEP: eps->ishermitian = PETSC_FALSE; break;
+    default: SETERRQ(PETSC_ERR_ARG_WRONG, "Unknown eigenvalue problem type");
+  }
+  eps->problem_type = type;
+  eps->state = 0;
+  return 0;
+}
+
+PetscErrorCode EPSSetDimensions(EPS eps, PetscInt nev, PetscInt ncv, PetscInt mpd) {
+  if (!eps) SETERRQ(PETSC_ERR_ARG_NULL, "Null EPS");
+  if (nev < 1) SETERRQ(PETSC_ERR_ARG_OUTOFRANGE, "Illegal value of nev. Must be > 0");
+  eps->nev = nev;
+  if (ncv < 0) SETERRQ(PETSC_ERR_ARG_OUTOFRANGE, "Illegal value of ncv. Must be > 0");
+  eps->ncv = ncv;      /* 0 = PETSC_DEFAULT */
+  if (mpd < 0) SETERRQ(PETSC_ERR_ARG_OUTOFRANGE, "Illegal value of mpd. Must be > 0");
+  eps->mpd = mpd;
+  eps->state = 0;
+  return 0;
+}
+
+PetscErrorCode EPSSetTolerances(EPS eps, PetscReal tol, PetscInt maxits) {
+  if (!eps) SETERRQ(PETSC_ERR_ARG_NULL, "Null EPS");
+  if (tol < 0.0) SETERRQ(PETSC_ERR_ARG_OUTOFRANGE, "Illegal value of tol. Must be > 0");
+  if (maxits < 0) SETERRQ(PETSC_ERR_ARG_OUTOFRANGE, "Illegal value of maxits. Must be > 0");
+  eps->tol = tol;            /* 0 = PETSC_DEFAULT */
+  eps->max_it = maxits;      /* 0 = PETSC_DEFAULT */
+  return 0;
+}
+
+PetscErrorCode EPSSetWhichEigenpairs(EPS eps, EPSWhich which) {
+  if (!eps) SETERRQ(PETSC_ERR_ARG_NULL, "Null EPS");
+  if (which < EPS_LARGEST_MAGNITUDE || which > EPS_SMALLEST_IMAGINARY) SETERRQ(PETSC_ERR_ARG_OUTOFRANGE, "Invalid 'which' value");
+  eps->which = which;
+  eps->state = 0;
+  return 0;
+}
+
+PetscErrorCode EPSSetInitialSpace(EPS eps, PetscInt n, Vec *is) {
+  PetscErrorCode ierr;
+  PetscInt i;
+  if (!eps) SETERRQ(PETSC_ERR_ARG_NULL, "Null EPS");
+  if (n < 0) SETERRQ(PETSC_ERR_ARG_OUTOFRANGE, "Argument n cannot be negative");
+  if (eps->IS) for (i = 0; i < eps->nini; i++) { ierr = VecDestroy(&eps->IS[i]);CHKERRQ(ierr); }
+  free(eps->IS); eps->IS = NULL; eps->nini = 0;
+  if (n > 0) {
+    eps->IS = (Vec *)calloc((size_t)n, sizeof(Vec));
+    if (!eps->IS) SETERRQ(PETSC_ERR_MEM, "Out of memory");
+    for (i = 0; i < n; i++) {       /* SlepcBasisReference_Private keeps references; we keep copies */
+      ierr = VecDuplicate(is[i], &eps->IS[i]);CHKERRQ(ierr);
+      ierr = VecCopy(is[i], eps->IS[i]);CHKERRQ(ierr);
+    }
+    eps->nini = n;
+    eps->state = 0;
+  }
+  return 0;
+}
+
+PetscErrorCode EPSKrylovSchurSetRestart(EPS eps, PetscReal keep) {
+  if (!eps) SETERRQ(PETSC_ERR_ARG_NULL, "Null EPS");
+  if (keep == 0.0) eps->keep = 0.5;
+  else {
+    if (keep < 0.1 || keep > 0.9) SETERRQ(PETSC_ERR_ARG_OUTOFRANGE, "The keep argument must be in the range [0.1,0.9]");
+    eps->keep = keep;
+  }
+  return 0;
+}
+PetscErrorCode EPSKrylovSchurSetLocking(EPS eps, PetscBool lock) { if (!eps) SETERRQ(PETSC_ERR_ARG_NULL, "Null EPS"); eps->lock = lock; return 0; }
+PetscErrorCode EPSMonitorSet(EPS eps, EPSMonitorFn monitor, void *ctx) { if (!eps) SETERRQ(PETSC_ERR_ARG_NULL, "Null EPS"); eps->monitor = monitor; eps->monitorctx = ctx; return 0; }
+PetscErrorCode EPSGetBV(EPS eps, BV *bv) { if (!eps || !bv) SETERRQ(PETSC_ERR_ARG_NULL, "Null argument"); *bv = eps->V; return 0; }
+PetscErrorCode EPSGetDS(EPS eps, DS *ds) { if (!eps || !ds) SETERRQ(PETSC_ERR_ARG_NULL, "Null argument"); *ds = eps->ds; return 0; }
+
+/* ---- setup (epssetup.c:100-288,466-555; krylovschur.c:73-167) ----------------------------------- */
+static PetscErrorCode EPSSetDimensions_Default(EPS eps, PetscInt nev, PetscInt *ncv, PetscInt *mpd) {
+  const PetscInt n = (PetscInt)PetscMin(eps->n, (PetscInt64)2147483647);
+  if (*ncv) {
+    if (*ncv < nev + 1 && !(*ncv == nev && *ncv == n)) SETERRQ(1, "The value of ncv must be at least nev+1");
+  } else if (*mpd) *ncv = PetscMin(n, nev + (*mpd));
+  else {
+    if (nev < 500) *ncv = PetscMin(n, PetscMax(2 * nev, nev + 15));
+    else { *mpd = 500; *ncv = PetscMin(n, nev + (*mpd)); }
+  }
+  if (!*mpd) *mpd = *ncv;
+  return 0;
+}
+
+PetscErrorCode EPSSetUp(EPS eps) {
+  PetscErrorCode ierr;
+  PetscInt oldm = 0, k;
+  Vec t;
+  static const SlepcCompareFn cmps[] = { NULL, SlepcCompareLargestMagnitude, SlepcCompareSmallestMagnitude, SlepcCompareLargestReal,
+                                         SlepcCompareSmallestReal, SlepcCompareLargestImaginary, SlepcCompareSmallestImaginary };
+  if (!eps) SETERRQ(PETSC_ERR_ARG_NULL, "Null EPS");
+  if (eps->state) return 0;
+  if (!eps->A) SETERRQ(PETSC_ERR_ARG_WRONGSTATE, "EPSSetOperators must be called first");
+  if (!eps->problem_type) { ierr = EPSSetProblemType(eps, EPS_NHEP);CHKERRQ(ierr); }     /* epssetup.c:138-141 */
+  ierr = MatGetSize(eps->A, &eps->n, NULL);CHKERRQ(ierr);
+  ierr = MatGetLocalSize(eps->A, &eps->nloc, NULL);CHKERRQ(ierr);
+  if (eps->nev > eps->n) eps->nev = (PetscInt)eps->n;
+  if (eps->ncv > eps->n) eps->ncv = (PetscInt)eps->n;
+
+  /* EPSSetUp_KrylovSchur */
+  ierr = EPSSetDimensions_Default(eps, eps->nev, &eps->ncv, &eps->mpd);CHKERRQ(ierr);
+  if (eps->ncv > eps->nev + eps->mpd) SETERRQ(1, "The value of ncv must not be larger than nev+mpd");
+  if (!eps->max_it) eps->max_it = (PetscInt)PetscMax((PetscInt64)100, 2 * eps->n / eps->ncv);
+  if (!eps->which) eps->which = EPS_LARGEST_MAGNITUDE;                                    /* epsdefault.c:243-253 */
+  if (!eps->lock && eps->mpd < eps->ncv) SETERRQ(PETSC_ERR_SUP, "Should not use mpd parameter in non-locking variant");
+  if (eps->ishermitian && (eps->which == EPS_LARGEST_IMAGINARY || eps->which == EPS_SMALLEST_IMAGINARY)) SETERRQ(1, "Wrong value of eps->which");
+  if (!eps->keep) eps->keep = 0.5;
+  if (eps->tol == 0.0) eps->tol = 1e-8;                                                   /* SLEPC_DEFAULT_TOL */
+  eps->cmp = cmps[eps->which];
+
+  /* EPSAllocateSolution(eps,1) */
+  ierr = BVGetSizes(eps->V, NULL, NULL, &oldm);CHKERRQ(ierr);
+  const PetscInt requested = eps->ncv + 1;
+  if (requested != oldm || !eps->eigr) {
+    free(eps->eigr); free(eps->eigi); free(eps->errest); free(eps->perm);
+    eps->eigr = (PetscScalar *)calloc((size_t)requested, sizeof(PetscScalar));
+    eps->eigi = (PetscScalar *)calloc((size_t)requested, sizeof(PetscScalar));
+    eps->errest = (PetscReal *)calloc((size_t)requested, sizeof(PetscReal));
+    eps->perm = (PetscInt *)calloc((size_t)requested, sizeof(PetscInt));
+    if (!eps->eigr || !eps->eigi || !eps->errest || !eps->perm) SETERRQ(PETSC_ERR_MEM, "Out of memory");
+  }
+  if (!eps->V->t) {
+    if (!eps->V->type_name[0]) { ierr = BVSetType(eps->V, "hip");CHKERRQ(ierr); }        /* default type (BVSVEC there) */
+    ierr = MatCreateVecs(eps->A, &t, NULL);CHKERRQ(ierr);
+    ierr = BVSetSizesFromVec(eps->V, t, requested);CHKERRQ(ierr);
+    ierr = VecDestroy(&t);CHKERRQ(ierr);
+  } else { ierr = BVResize(eps->V, requested, PETSC_FALSE);CHKERRQ(ierr); }
+
+  /* dispatch solve method: DS type */
+  if (eps->ishermitian) {
+    ierr = DSSetType(eps->ds, "hep");CHKERRQ(ierr);
+    ierr = DSSetCompact(eps->ds, PETSC_TRUE);CHKERRQ(ierr);
+    ierr = DSSetExtraRow(eps->ds, PETSC_TRUE);CHKERRQ(ierr);
+  } else { ierr = DSSetType(eps->ds, "nhep");CHKERRQ(ierr); }
+  ierr = DSAllocate(eps->ds, eps->ncv + 1);CHKERRQ(ierr);
+  ierr = DSSetSlepcSC(eps->ds, eps->cmp, NULL);CHKERRQ(ierr);
+
+  /* process initial vectors (epssetup.c:277-283) */
+  if (eps->nini > 0) {
+    k = eps->nini;
+    ierr = BVInsertVecs(eps->V, 0, &k, eps->IS, PETSC_TRUE);CHKERRQ(ierr);
+    for (PetscInt i = 0; i < eps->nini; i++) { ierr = VecDestroy(&eps->IS[i]);CHKERRQ(ierr); }
+    free(eps->IS); eps->IS = NULL;
+    eps->nini = k;      /* number of usable initial vectors now stored in V */
+  }
+  eps->state = 1;
+  return 0;
+}
+
+/* ---- building blocks ------------------------------------------------------------------------------ */
+/* stsolve.c:44-72 + shift.c:27-41 with sigma = 0: y = A x */
+static PetscErrorCode STApply(EPS eps, Vec x, Vec y) {
+  PetscErrorCode ierr;
+  if (x == y) SETERRQ(PETSC_ERR_ARG_WRONG, "x and y must be different vectors");
+  ierr = MatMult(eps->A, x, y);CHKERRQ(ierr);
+  eps->matvecs++;
+  return 0;
+}
+
+/* epssolve.c:675-710 */
+static PetscErrorCode EPSGetStartVector(EPS eps, PetscInt i, PetscBool *breakdown) {
+  PetscErrorCode ierr;
+  PetscReal norm;
+  PetscBool lindep;
+  if (i > 0 || eps->nini == 0) { ierr = BVSetRandomColumn(eps->V, i);CHKERRQ(ierr); }
+  ierr = BVOrthogonalizeColumn(eps->V, i, NULL, &norm, &lindep);CHKERRQ(ierr);
+  if (breakdown) *breakdown = lindep;
+  else if (lindep || norm == 0.0) {
+    if (i == 0) SETERRQ(1, "Initial vector is zero or belongs to the deflation space");
+    else SETERRQ(1, "Unable to generate more start vectors");
+  }
+  ierr = BVScaleColumn(eps->V, i, 1.0 / norm);CHKERRQ(ierr);
+  return 0;
+}
+
+/* epskrylov.c:347-376 */
+static PetscErrorCode EPSFullLanczos(EPS eps, PetscReal *alpha, PetscReal *beta, PetscInt k, PetscInt *M, PetscBool *breakdown) {
+  PetscErrorCode ierr;
+  PetscScalar *a;
+  PetscInt j, nc = eps->V->nc, ld, m = *M;
+  Vec vj, vj1;
+  ierr = BVSetActiveColumns(eps->V, 0, m);CHKERRQ(ierr);
+  for (j = k; j < m; j++) {
+    ierr = BVGetColumn(eps->V, j, &vj);CHKERRQ(ierr);
+    ierr = BVGetColumn(eps->V, j + 1, &vj1);CHKERRQ(ierr);
+    ierr = STApply(eps, vj, vj1);CHKERRQ(ierr);
+    ierr = BVRestoreColumn(eps->V, j, &vj);CHKERRQ(ierr);
+    ierr = BVRestoreColumn(eps->V, j + 1, &vj1);CHKERRQ(ierr);
+    ierr = BVOrthonormalizeColumn(eps->V, j + 1, PETSC_FALSE, beta + j, breakdown);CHKERRQ(ierr);
+    if (*breakdown) { *M = j + 1; break; }
+  }
+  /* the diagonal of T sits in the BV buffer (beta is already in its place) */
+  ierr = BVGetBuffer(eps->V, &a, &ld);CHKERRQ(ierr);
+  for (j = k; j < *M; j++) alpha[j] = a[nc + j + (size_t)(j + 1) * ld];
+  return 0;
+}
+
+/* epskrylov.c:39-74 */
+static PetscErrorCode EPSBasicArnoldi(EPS eps, PetscScalar *H, PetscInt ldh, PetscInt k, PetscInt *M, PetscReal *beta, PetscBool *breakdown) {
+  PetscErrorCode ierr;
+  PetscScalar *a;
+  PetscInt j, nc = eps->V->nc, ld, m = *M;
+  Vec vj, vj1;
+  ierr = BVSetActiveColumns(eps->V, 0, m);CHKERRQ(ierr);
+  for (j = k; j < m; j++) {
+    ierr = BVGetColumn(eps->V, j, &vj);CHKERRQ(ierr);
+    ierr = BVGetColumn(eps->V, j + 1, &vj1);CHKERRQ(ierr);
+    ierr = STApply(eps, vj, vj1);CHKERRQ(ierr);
+    ierr = BVRestoreColumn(eps->V, j, &vj);CHKERRQ(ierr);
+    ierr = BVRestoreColumn(eps->V, j + 1, &vj1);CHKERRQ(ierr);
+    ierr = BVOrthonormalizeColumn(eps->V, j + 1, PETSC_FALSE, beta, breakdown);CHKERRQ(ierr);
+    if (*breakdown) { *M = j + 1; break; }
+  }
+  /* extract the Hessenberg matrix from the BV buffer */
+  ierr = BVGetBuffer(eps->V, &a, &ld);CHKERRQ(ierr);
+  for (j = k; j < *M; j++) memcpy(H + (size_t)j * ldh, a + nc + (size_t)(j + 1) * ld, (size_t)(j + 2) * sizeof(PetscScalar));
+  return 0;
+}
+
+/* epskrylov.c:252-327 (trivial region, estimated residuals) with the relative
+ * convergence test EPSConvergedRelative (epsdefault.c:258-266) */
+static PetscErrorCode EPSKrylovConvergence(EPS eps, PetscInt kini, PetscInt nits, PetscReal beta, PetscReal corrf, PetscInt *kout) {
+  PetscErrorCode ierr;
+  PetscInt k, newk, marker = -1;
+  PetscReal resnorm;
+  for (k = kini; k < kini + nits; k++) {
+    const PetscScalar re = eps->eigr[k], im = eps->eigi[k];
+    newk = k;
+    ierr = DSVectors(eps->ds, DS_MAT_X, &newk, &resnorm);CHKERRQ(ierr);
+    resnorm *= beta * corrf;
+    eps->errest[k] = resnorm / SlepcAbsEigenvalue(re, im);
+    if (marker == -1 && eps->errest[k] >= eps->tol) marker = k;
+    if (newk == k + 1) { eps->errest[k + 1] = eps->errest[k]; k++; }
+    if (marker != -1) break;
+  }
+  if (marker != -1) k = marker;
+  *kout = k;
+  return 0;
+}
+
+/* epsdefault.c:324-338 */
+static void EPSStoppingBasic(EPS eps, PetscInt its, PetscInt max_it, PetscInt nconv, PetscInt nev, EPSConvergedReason *reason) {
+  *reason = EPS_CONVERGED_ITERATING;
+  if (nconv >= nev) *reason = EPS_CONVERGED_TOL;
+  else if (its >= max_it) *reason = EPS_DIVERGED_ITS;
+}
+
+/* V(:,s:e) = V * Q(:,s:e) with Q taken from the DS (DSGetMat + BVMultInPlace + MatDestroy) */
+static PetscErrorCode UpdateBasis(EPS eps, DSMatType m, PetscInt s, PetscInt e) {
+  PetscErrorCode ierr;
+  PetscInt rows, cols;
+  ierr = DSGetMat(eps->ds, m, NULL, &rows, &cols);CHKERRQ(ierr);
+  PetscScalar *U = (PetscScalar *)malloc((size_t)PetscMax(rows * cols, 1) * sizeof(PetscScalar));
+  if (!U) SETERRQ(PETSC_ERR_MEM, "Out of memory");
+  ierr = DSGetMat(eps->ds, m, U, &rows, &cols);
+  if (!ierr) ierr = BVMultInPlace(eps->V, U, rows, s, e);
+  free(U);
+  CHKERRQ(ierr);
+  return 0;
+}
+
+/* ---- ks-symm.c:30-111 ----------------------------------------------------------------------------- */
+static PetscErrorCode EPSSolve_KrylovSchur_Symm(EPS eps) {
+  PetscErrorCode ierr;
+  PetscInt k, l, ld, nv, nconv;
+  PetscReal *a, *b, beta;
+  PetscBool breakdown;
+  ierr = DSGetLeadingDimension(eps->ds, &ld);CHKERRQ(ierr);
+  /* get the starting Lanczos vector */
+  ierr = EPSGetStartVector(eps, 0, NULL);CHKERRQ(ierr);
+  l = 0;
+  /* restart loop */
+  while (eps->reason == EPS_CONVERGED_ITERATING) {
+    eps->its++;
+    /* compute an nv-step Lanczos factorization */
+    nv = PetscMin(eps->nconv + eps->mpd, eps->ncv);
+    ierr = DSGetArrayReal(eps->ds, DS_MAT_T, &a);CHKERRQ(ierr);
+    b = a + ld;
+    ierr = EPSFullLanczos(eps, a, b, eps->nconv + l, &nv, &breakdown);CHKERRQ(ierr);
+    beta = b[nv - 1];
+    ierr = DSSetDimensions(eps->ds, nv, 0, eps->nconv, eps->nconv + l);CHKERRQ(ierr);
+    ierr = DSSetState(eps->ds, l == 0 ? DS_STATE_INTERMEDIATE : DS_STATE_RAW);CHKERRQ(ierr);
+    ierr = BVSetActiveColumns(eps->V, eps->nconv, nv);CHKERRQ(ierr);
+    /* solve projected problem */
+    ierr = DSSolve(eps->ds, eps->eigr, NULL);CHKERRQ(ierr);
+    ierr = DSSort(eps->ds, eps->eigr, NULL, NULL, NULL, NULL);CHKERRQ(ierr);
+    ierr = DSUpdateExtraRow(eps->ds);CHKERRQ(ierr);
+    /* check convergence */
+    ierr = EPSKrylovConvergence(eps, eps->nconv, nv - eps->nconv, beta, 1.0, &k);CHKERRQ(ierr);
+    EPSStoppingBasic(eps, eps->its, eps->max_it, k, eps->nev, &eps->reason);
+    nconv = k;
+    /* update l */
+    if (eps->reason != EPS_CONVERGED_ITERATING || breakdown) l = 0;
+    else l = PetscMax(1, (PetscInt)((nv - k) * eps->keep));
+    if (!eps->lock && l > 0) { l += k; k = 0; }     /* non-locking variant: reset no. of converged pairs */
+    if (eps->reason == EPS_CONVERGED_ITERATING) {
+      if (breakdown) {
+        /* start a new Lanczos factorization */
+        if (k < eps->nev) {
+          ierr = EPSGetStartVector(eps, k, &breakdown);CHKERRQ(ierr);
+          if (breakdown) eps->reason = EPS_DIVERGED_BREAKDOWN;
+        }
+      } else {
+        /* prepare the Rayleigh quotient for restart */
+        ierr = DSTruncate(eps->ds, k + l);CHKERRQ(ierr);
+      }
+    }
+    /* update the corresponding vectors V(:,idx) = V*Q(:,idx) */
+    ierr = UpdateBasis(eps, DS_MAT_Q, eps->nconv, k + l);CHKERRQ(ierr);
+    /* normalize u and append it to V */
+    if (eps->reason == EPS_CONVERGED_ITERATING && !breakdown) { ierr = BVCopyColumn(eps->V, nv, k + l);CHKERRQ(ierr); }
+    eps->nconv = k;
+    if (eps->monitor) { ierr = eps->monitor(eps, eps->its, nconv, eps->eigr, eps->eigi, eps->errest, nv, eps->monitorctx);CHKERRQ(ierr); }
+  }
+  return 0;
+}
+
+/* ---- krylovschur.c:169-288 (Ritz extraction) ---------------------------------------------------------- */
+static PetscErrorCode EPSSolve_KrylovSchur_Default(EPS eps) {
+  PetscErrorCode ierr;
+  PetscInt i, k, l, nv, ld, nconv;
+  PetscScalar *S, *Q;
+  PetscReal beta;
+  PetscBool breakdown;
+  ierr = DSGetLeadingDimension(eps->ds, &ld);CHKERRQ(ierr);
+  /* get the starting Arnoldi vector */
+  ierr = EPSGetStartVector(eps, 0, NULL);CHKERRQ(ierr);
+  l = 0;
+  while (eps->reason == EPS_CONVERGED_ITERATING) {
+    eps->its++;
+    /* compute an nv-step Arnoldi factorization */
+    nv = PetscMin(eps->nconv + eps->mpd, eps->ncv);
+    ierr = DSGetArray(eps->ds, DS_MAT_A, &S);CHKERRQ(ierr);
+    ierr = EPSBasicArnoldi(eps, S, ld, eps->nconv + l, &nv, &beta, &breakdown);CHKERRQ(ierr);
+    ierr = DSSetDimensions(eps->ds, nv, 0, eps->nconv, eps->nconv + l);CHKERRQ(ierr);
+    ierr = DSSetState(eps->ds, l == 0 ? DS_STATE_INTERMEDIATE : DS_STATE_RAW);CHKERRQ(ierr);
+    ierr = BVSetActiveColumns(eps->V, eps->nconv, nv);CHKERRQ(ierr);
+    /* solve projected problem */
+    ierr = DSSolve(eps->ds, eps->eigr, eps->eigi);CHKERRQ(ierr);
+    ierr = DSSort(eps->ds, eps->eigr, eps->eigi, NULL, NULL, NULL);CHKERRQ(ierr);
+    /* check convergence */
+    ierr = EPSKrylovConvergence(eps, eps->nconv, nv - eps->nconv, beta, 1.0, &k);CHKERRQ(ierr);
+    EPSStoppingBasic(eps, eps->its, eps->max_it, k, eps->nev, &eps->reason);
+    nconv = k;
+    /* update l */
+    if (eps->reason != EPS_CONVERGED_ITERATING || breakdown) l = 0;
+    else {
+      l = PetscMax(1, (PetscInt)((nv - k) * eps->keep));
+      if (S[k + l + (size_t)(k + l - 1) * ld] != 0.0) {      /* do not split a 2x2 block */
+        if (k + l < nv - 1) l = l + 1;
+        else l = l - 1;
+      }
+    }
+    if (!eps->lock && l > 0) { l += k; k = 0; }
+    if (eps->reason == EPS_CONVERGED_ITERATING) {
+      if (breakdown) {
+        if (k < eps->nev) {
+          ierr = EPSGetStartVector(eps, k, &breakdown);CHKERRQ(ierr);
+          if (breakdown) eps->reason = EPS_DIVERGED_BREAKDOWN;
+        }
+      } else {
+        /* prepare the Rayleigh quotient for restart */
+        ierr = DSGetArray(eps->ds, DS_MAT_Q, &Q);CHKERRQ(ierr);
+        for (i = k; i < k + l; i++) S[k + l + (size_t)i * ld] = Q[nv - 1 + (size_t)i * ld] * beta;
+      }
+    }
+    /* update the corresponding vectors V(:,idx) = V*Q(:,idx) */
+    ierr = UpdateBasis(eps, DS_MAT_Q, eps->nconv, k + l);CHKERRQ(ierr);
+    if (eps->reason == EPS_CONVERGED_ITERATING && !breakdown) { ierr = BVCopyColumn(eps->V, nv, k + l);CHKERRQ(ierr); }
+    eps->nconv = k;
+    if (eps->monitor) { ierr = eps->monitor(eps, eps->its, nconv, eps->eigr, eps->eigi, eps->errest, nv, eps->monitorctx);CHKERRQ(ierr); }
+  }
+  /* truncate the Schur decomposition and change the state to raw so that
+     DSVectors() computes eigenvectors from scratch */
+  ierr = DSSetDimensions(eps->ds, eps->nconv, 0, 0, 0);CHKERRQ(ierr);
+  ierr = DSSetState(eps->ds, DS_STATE_RAW);CHKERRQ(ierr);
+  return 0;
+}
+
+/* ---- epsdefault.c:40-74,136-205 -------------------------------------------------------------------------- */
+static PetscErrorCode EPSComputeVectors(EPS eps) {
+  PetscErrorCode ierr;
+  PetscInt n;
+  EPSCheckSolved(eps);
+  if (eps->state == 3) return 0;
+  eps->state = 3;
+  if (eps->ishermitian) return 0;              /* Lanczos vectors are the eigenvectors of a standard HEP */
+  ierr = DSGetDimensions(eps->ds, &n, NULL, NULL, NULL, NULL);CHKERRQ(ierr);
+  if (!n) return 0;
+  ierr = DSVectors(eps->ds, DS_MAT_X, NULL, NULL);CHKERRQ(ierr);        /* right eigenvectors of T */
+  ierr = BVSetActiveColumns(eps->V, 0, n);CHKERRQ(ierr);
+  ierr = UpdateBasis(eps, DS_MAT_X, 0, n);CHKERRQ(ierr);                /* V = V * Z */
+  return 0;
+}
+
+/* ---- epssolve.c:63-146 ---------------------------------------------------------------------------------------- */
+PetscErrorCode EPSSolve(EPS eps) {
+  PetscErrorCode ierr;
+  PetscInt i;
+  if (!eps) SETERRQ(PETSC_ERR_ARG_NULL, "Null EPS");
+  if (eps->state >= 2) return 0;
+  ierr = EPSSetUp(eps);CHKERRQ(ierr);
+  eps->nconv = 0;
+  eps->its = 0;
+  eps->reason = EPS_CONVERGED_ITERATING;
+  for (i = 0; i < eps->ncv; i++) { eps->eigr[i] = 0.0; eps->eigi[i] = 0.0; eps->errest[i] = 0.0; eps->perm[i] = i; }
+  if (eps->ishermitian) { ierr = EPSSolve_KrylovSchur_Symm(eps);CHKERRQ(ierr); }
+  else { ierr = EPSSolve_KrylovSchur_Default(eps);CHKERRQ(ierr); }
+  eps->state = 2;
+  if (!eps->reason) SETERRQ(PETSC_ERR_PLIB, "Internal error, solver returned without setting converged reason");
+  /* reorder conjugate eigenvalues (positive imaginary first) */
+  for (i = 0; i < eps->nconv - 1; i++) {
+    if (eps->eigi[i] != 0) {
+      if (eps->eigi[i] < 0) {
+        eps->eigi[i] = -eps->eigi[i];
+        eps->eigi[i + 1] = -eps->eigi[i + 1];
+        /* the next correction only works with eigenvectors */
+        ierr = EPSComputeVectors(eps);CHKERRQ(ierr);
+        ierr = BVScaleColumn(eps->V, i + 1, -1.0);CHKERRQ(ierr);
+      }
+      i++;
+    }
+  }
+  /* sort eigenvalues according to eps->which */
+  for (i = 0; i < eps->ncv; i++) eps->perm[i] = i;
+  ierr = SlepcSortEigenvalues(eps->cmp, NULL, eps->nconv, eps->eigr, eps->eigi, eps->perm);CHKERRQ(ierr);
+  eps->nini = 0;
+  return 0;
+}
+
+/* ---- results (epssolve.c:148-462,580-649) ------------------------------------------------------------------------- */
+PetscErrorCode EPSGetIterationNumber(EPS eps, PetscInt *its) { if (!eps || !its) SETERRQ(PETSC_ERR_ARG_NULL, "Null argument"); *its = eps->its; return 0; }
+PetscErrorCode EPSGetConverged(EPS eps, PetscInt *nconv) { if (!eps || !nconv) SETERRQ(PETSC_ERR_ARG_NULL, "Null argument"); EPSCheckSolved(eps); *nconv = eps->nconv; return 0; }
+PetscErrorCode EPSGetConvergedReason(EPS eps, EPSConvergedReason *reason) { if (!eps || !reason) SETERRQ(PETSC_ERR_ARG_NULL, "Null argument"); EPSCheckSolved(eps); *reason = eps->reason; return 0; }
+PetscErrorCode EPSGetDimensions(EPS eps, PetscInt *nev, PetscInt *ncv, PetscInt *mpd) {
+  if (!eps) SETERRQ(PETSC_ERR_ARG_NULL, "Null EPS");
+  if (nev) *nev = eps->nev;
+  if (ncv) *ncv = eps->ncv;
+  if (mpd) *mpd = eps->mpd;
+  return 0;
+}
+PetscErrorCode EPSGetTolerances(EPS eps, PetscReal *tol, PetscInt *maxits) {
+  if (!eps) SETERRQ(PETSC_ERR_ARG_NULL, "Null EPS");
+  if (tol) *tol = eps->tol;
+  if (maxits) *maxits = eps->max_it;
+  return 0;
+}
+
+PetscErrorCode EPSGetEigenvalue(EPS eps, PetscInt i, PetscScalar *eigr, PetscScalar *eigi) {
+  if (!eps) SETERRQ(PETSC_ERR_ARG_NULL, "Null EPS");
+  EPSCheckSolved(eps);
+  if (i < 0 || i >= eps->nconv) SETERRQ(PETSC_ERR_ARG_OUTOFRANGE, "Argument 2 out of range");
+  const PetscInt k = eps->perm[i];
+  if (eigr) *eigr = eps->eigr[k];
+  if (eigi) *eigi = eps->eigi[k];
+  return 0;
+}
+
+PetscErrorCode EPSGetEigenvector(EPS eps, PetscInt i, Vec Vr, Vec Vi) {
+  PetscErrorCode ierr;
+  if (!eps || !Vr) SETERRQ(PETSC_ERR_ARG_NULL, "Null argument");
+  EPSCheckSolved(eps);
+  if (i < 0 || i >= eps->nconv) SETERRQ(PETSC_ERR_ARG_OUTOFRANGE, "Argument 2 out of range");
+  ierr = EPSComputeVectors(eps);CHKERRQ(ierr);
+  const PetscInt k = eps->perm[i];
+  if (eps->eigi[k] > 0) {            /* first value of conjugate pair */
+    ierr = BVCopyVec(eps->V, k, Vr);CHKERRQ(ierr);
+    if (Vi) { ierr = BVCopyVec(eps->V, k + 1, Vi);CHKERRQ(ierr); }
+  } else if (eps->eigi[k] < 0) {     /* second value of conjugate pair */
+    ierr = BVCopyVec(eps->V, k - 1, Vr);CHKERRQ(ierr);
+    if (Vi) { ierr = BVCopyVec(eps->V, k, Vi);CHKERRQ(ierr); ierr = VecScale(Vi, -1.0);CHKERRQ(ierr); }
+  } else {                           /* real eigenvalue */
+    ierr = BVCopyVec(eps->V, k, Vr);CHKERRQ(ierr);
+    if (Vi) { ierr = VecSet(Vi, 0.0);CHKERRQ(ierr); }
+  }
+  return 0;
+}
+
+PetscErrorCode EPSGetEigenpair(EPS eps, PetscInt i, PetscScalar *eigr, PetscScalar *eigi, Vec Vr, Vec Vi) {
+  PetscErrorCode ierr;
+  if (!eps) SETERRQ(PETSC_ERR_ARG_NULL, "Null EPS");
+  EPSCheckSolved(eps);
+  if (i < 0 || i >= eps->nconv) SETERRQ(PETSC_ERR_ARG_OUTOFRANGE, "Argument 2 out of range");
+  ierr = EPSGetEigenvalue(eps, i, eigr, eigi);CHKERRQ(ierr);
+  if (Vr) { ierr = EPSGetEigenvector(eps, i, Vr, Vi);CHKERRQ(ierr); }
+  return 0;
+}
+
+PetscErrorCode EPSGetErrorEstimate(EPS eps, PetscInt i, PetscReal *errest) {
+  if (!eps || !errest) SETERRQ(PETSC_ERR_ARG_NULL, "Null argument");
+  EPSCheckSolved(eps);
+  if (i < 0 || i >= eps->nconv) SETERRQ(PETSC_ERR_ARG_OUTOFRANGE, "Argument 2 out of range");
+  *errest = eps->errest[eps->perm[i]];
+  return 0;
+}
+
+/* epssolve.c:506-556 */
+static PetscErrorCode EPSComputeResidualNorm_Private(EPS eps, PetscScalar kr, PetscScalar ki, Vec xr, Vec xi, Vec *z, PetscReal *norm) {
+  PetscErrorCode ierr;
+  Vec u = z[0], v = z[1], w = z[2];
+  PetscReal ni, nr;
+  if (ki == 0 || fabs(ki) < fabs(kr * PETSC_MACHINE_EPSILON)) {
+    ierr = MatMult(eps->A, xr, u);CHKERRQ(ierr);                       /* u=A*x */
+    if (fabs(kr) > PETSC_MACHINE_EPSILON) {
+      ierr = VecCopy(xr, w);CHKERRQ(ierr);                             /* w=B*x */
+      ierr = VecAXPY(u, -kr, w);CHKERRQ(ierr);                         /* u=A*x-k*B*x */
+    }
+    ierr = VecNorm(u, NORM_2, norm);CHKERRQ(ierr);
+  } else {
+    ierr = MatMult(eps->A, xr, u);CHKERRQ(ierr);                       /* u=A*xr */
+    if (SlepcAbsEigenvalue(kr, ki) > PETSC_MACHINE_EPSILON) {
+      ierr = VecCopy(xr, v);CHKERRQ(ierr);                             /* v=B*xr */
+      ierr = VecAXPY(u, -kr, v);CHKERRQ(ierr);                         /* u=A*xr-kr*B*xr */
+      ierr = VecCopy(xi, w);CHKERRQ(ierr);                             /* w=B*xi */
+      ierr = VecAXPY(u, ki, w);CHKERRQ(ierr);                          /* u=A*xr-kr*B*xr+ki*B*xi */
+    }
+    ierr = VecNorm(u, NORM_2, &nr);CHKERRQ(ierr);
+    ierr = MatMult(eps->A, xi, u);CHKERRQ(ierr);                       /* u=A*xi */
+    if (SlepcAbsEigenvalue(kr, ki) > PETSC_MACHINE_EPSILON) {
+      ierr = VecAXPY(u, -kr, w);CHKERRQ(ierr);                         /* u=A*xi-kr*B*xi */
+      ierr = VecAXPY(u, -ki, v);CHKERRQ(ierr);                         /* u=A*xi-kr*B*xi-ki*B*xr */
+    }
+    ierr = VecNorm(u, NORM_2, &ni);CHKERRQ(ierr);
+    *norm = SlepcAbsEigenvalue(nr, ni);
+  }
+  return 0;
+}
+
+/* epssolve.c:580-649 */
+PetscErrorCode EPSComputeError(EPS eps, PetscInt i, EPSErrorType type, PetscReal *error) {
+  PetscErrorCode ierr;
+  PetscScalar kr, ki;
+  Vec t, w[3];
+  if (!eps || !error) SETERRQ(PETSC_ERR_ARG_NULL, "Null argument");
+  EPSCheckSolved(eps);
+  if (eps->nwork < 5) {          /* EPSSetWorkVecs(eps,5) */
+    ierr = BVGetColumn(eps->V, 0, &t);CHKERRQ(ierr);
+    for (PetscInt j = eps->nwork; j < 5; j++) { ierr = VecDuplicate(t, &eps->work[j]);CHKERRQ(ierr); }
+    ierr = BVRestoreColumn(eps->V, 0, &t);CHKERRQ(ierr);
+    eps->nwork = 5;
+  }
+  Vec xr = eps->work[0], xi = eps->work[3];
+  w[0] = eps->work[1]; w[1] = eps->work[4]; w[2] = eps->work[2];
+  ierr = EPSGetEigenpair(eps, i, &kr, &ki, xr, xi);CHKERRQ(ierr);
+  ierr = EPSComputeResidualNorm_Private(eps, kr, ki, xr, xi, w, error);CHKERRQ(ierr);
+  switch (type) {
+    case EPS_ERROR_ABSOLUTE: break;
+    case EPS_ERROR_RELATIVE: *error /= SlepcAbsEigenvalue(kr, ki); break;
+    default: SETERRQ(PETSC_ERR_ARG_OUTOFRANGE, "Invalid error type");
+  }
+  return 0;
+}
+
+PetscErrorCode EPSGetCounters(EPS eps, PetscInt64 *matvecs, PetscInt64 *gs_passes) {
+  if (!eps) SETERRQ(PETSC_ERR_ARG_NULL, "Null EPS");
+  if (matvecs) *matvecs = eps->matvecs;
+  if (gs_passes) *gs_passes = ks_gs_passes;
+  return 0;
+}
+
+PetscErrorCode EPSDestroy(EPS *peps) {
+  PetscErrorCode ierr;
+  if (!peps || !*peps) return 0;
+  EPS eps = *peps;
+  for (PetscInt j = 0; j < eps->nwork; j++) { ierr = VecDestroy(&eps->work[j]);CHKERRQ(ierr); }
+  for (PetscInt j = 0; j < eps->nini && eps->IS; j++) { ierr = VecDestroy(&eps->IS[j]);CHKERRQ(ierr); }
+  free(eps->IS);
+  ierr = BVDestroy(&eps->V);CHKERRQ(ierr);
+  ierr = DSDestroy(&eps->ds);CHKERRQ(ierr);
+  free(eps->eigr); free(eps->eigi); free(eps->errest); free(eps->perm);
+  free(eps);
+  *peps = NULL;
+  return 0;
+}

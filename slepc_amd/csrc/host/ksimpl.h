@@ -1,0 +1,67 @@
+/* Private helpers of libkseps: error propagation in the style of PETSc's
+ * SETERRQ/CHKERRQ, allocation, and access to the DS / EPS structures. */
+#ifndef KSIMPL_H
+#define KSIMPL_H
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "kseps.h"
+
+PetscErrorCode KSError(const char *func, int line, PetscErrorCode code, const char *fmt, ...);
+void KSErrorTrace(const char *func, int line);
+
+#define SETERRQ(code, ...) return KSError(__func__, __LINE__, (code), __VA_ARGS__)
+#define CHKERRQ(ierr) do { if (ierr) { KSErrorTrace(__func__, __LINE__); return (ierr); } } while (0)
+/* a libksgpu call: its message becomes ours */
+#define CHKKSG(call) do { int rc_ = (call); if (rc_) return KSError(__func__, __LINE__, PETSC_ERR_LIB, "libksgpu: %s", ksg_last_error()); } while (0)
+
+#define PETSC_MACHINE_EPSILON 2.2204460492503131e-16
+#define PetscMax(a, b) ((a) < (b) ? (b) : (a))
+#define PetscMin(a, b) ((a) < (b) ? (a) : (b))
+
+static inline PetscReal SlepcAbsEigenvalue(PetscScalar re, PetscScalar im) { return hypot(re, im); }
+
+struct _p_DS {
+  int type;                 /* 0 hep, 1 nhep */
+  PetscBool compact, extrarow;
+  PetscInt ld, n, l, k, t;
+  DSStateType state;
+  PetscScalar *mat[DS_NUM_MAT];
+  PetscReal *rmat;          /* DS_MAT_T: 3*ld reals */
+  PetscInt *perm;
+  SlepcCompareFn cmp;
+  void *cmpctx;
+};
+
+struct _p_EPS {
+  void *ctx;
+  Mat A;
+  BV V;
+  DS ds;
+  EPSProblemType problem_type;
+  PetscBool ishermitian;
+  PetscInt nev, ncv, mpd, max_it;
+  PetscInt64 n, nloc;
+  PetscReal tol;
+  EPSWhich which;
+  SlepcCompareFn cmp;
+  PetscReal keep;
+  PetscBool lock, keep_set;
+  Vec *IS; PetscInt nini;
+  PetscScalar *eigr, *eigi;
+  PetscReal *errest;
+  PetscInt *perm;
+  PetscInt nconv, its;
+  EPSConvergedReason reason;
+  int state;                /* 0 initial, 1 setup, 2 solved, 3 eigenvectors */
+  EPSMonitorFn monitor; void *monitorctx;
+  Vec work[5]; PetscInt nwork;
+  PetscInt64 matvecs, gs_passes;
+};
+
+/* counters shared between bv.c and eps.c */
+extern PetscInt64 ks_gs_passes;
+
+#endif

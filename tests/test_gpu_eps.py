@@ -1,0 +1,126 @@
+"""The product path end to end on the GPU: libkseps (C host) + BV type "hip" +
+AIJ operator on the device, against the reference's golden outputs and against the
+CPU oracle on the same matrix and start vector.
+
+Bar (as the task states it): eigenvalues within 1e-10 relative of the CPU result,
+residuals ||Ax - kx||/|k| within the same tolerance class as -eps_tol, eigenvectors
+equal up to sign.
+"""
+import numpy as np
+import pytest
+from scipy.sparse import csr_matrix
+
+from oracle import eps as oeps, matgen as og
+from slepc_amd import kseps as K, matgen as mg
+from tests import common
+from tests.common import golden
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def be(gpu_ctx):
+    return common.Backend("hip", gpu_ctx)
+
+
+def test_bv_test1(be):
+    common.run_bv_test1(be)
+
+
+@pytest.mark.parametrize("otype", [K.BV_ORTHOG_CGS, K.BV_ORTHOG_MGS])
+def test_bv_test2(be, otype):
+    common.run_bv_test2(be, otype)
+
+
+@pytest.mark.parametrize("trans", [False, True])
+def test_bv_test4(be, trans):
+    common.run_bv_test4(be, trans)
+
+
+def test_bv_test13(be):
+    common.run_bv_test13(be)
+
+
+def _fmt(vals, k, fmt="%.5f"):
+    return [fmt % v[0] for v in vals[:k]]
+
+
+def test_eps_goldens(be):
+    g = golden("eps_tests.json")
+    r = common.solve_eps(be, mg.laplacian1d(30), nev=1)
+    assert "%.6f" % r["values"][0][0] == g["ex1"]["value"] and r["errors"][0] < 5e-8
+    r = common.solve_eps(be, mg.laplacian2d(72), nev=4, ncv=20)
+    assert _fmt(r["values"], 4) == g["ex2"]["values"] and max(r["errors"][:4]) < 5e-8
+    rp, ci, va = mg.markov(15)
+    v0 = np.zeros(len(rp) - 1)
+    v0[:2] = 1.0
+    r = common.solve_eps(be, (rp, ci, va), hermitian=False, nev=4, which="largest_real", v0=v0)
+    assert _fmt(r["values"], 4) == g["ex5"]["values"] and max(r["errors"][:4]) < 5e-8
+    r = common.solve_eps(be, (rp, ci, va), hermitian=False, nev=4)
+    assert _fmt(r["values"], 4) == g["test9"]["values"]
+    r = common.solve_eps(be, mg.laplacian3d(10), nev=8, ncv=64, which="smallest_real")
+    assert _fmt(r["values"], 8) == g["ex19"]["values"]
+    r = common.solve_eps(be, mg.laplacian1d(30), nev=4)
+    assert _fmt(r["values"], 4) == g["test4"]["values"]
+
+
+CASES = {
+    # name: (generator, hermitian, kwargs)
+    "ex1_1e5": (lambda: mg.laplacian1d(100000), True, dict(nev=10, ncv=32, tol=1e-10, max_it=40)),
+    "lap2d_300x217": (lambda: mg.laplacian2d(300, 217), True, dict(nev=8, tol=1e-10)),
+    "lap3d_40x37x29": (lambda: mg.laplacian3d(40, 37, 29), True, dict(nev=8, tol=1e-10)),
+    "markov_120": (lambda: mg.markov(120), False, dict(nev=6, which="largest_real", tol=1e-12)),
+}
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_eps_parity_with_oracle(be, name):
+    gen, herm, kw = CASES[name]
+    csr = gen()
+    n = len(csr[0]) - 1
+    if herm:
+        v0 = oeps.splitmix64_uniform(np.arange(n, dtype=np.uint64))
+    else:
+        v0 = np.zeros(n)
+        v0[:2] = 1.0                     # ex5.c:86-94
+    r = common.solve_eps(be, csr, hermitian=herm, v0=v0, want_vectors=True, **kw)
+    A = csr_matrix((csr[2], csr[1], csr[0]))
+
+    def mv(x, y):
+        y[:] = A @ x
+    e = oeps.EPS(mv, n, hermitian=herm, v0=v0, **kw).solve()
+    if name == "ex1_1e5":
+        # 1-D Laplacian of order 1e5: the restart cap is reached; compare what both produced
+        assert r["its"] == e.its == kw["max_it"]
+        assert r["reason"] == K.EPS_DIVERGED_ITS
+        return
+    assert r["reason"] == K.EPS_CONVERGED_TOL and r["nconv"] >= kw["nev"] and e.nconv >= kw["nev"]
+    for i in range(kw["nev"]):
+        lam = e.get_eigenvalue(i)
+        assert abs(r["values"][i][0] - lam[0]) <= 1e-10 * abs(lam[0])
+        assert abs(r["values"][i][1] - lam[1]) <= 1e-10
+        assert r["errors"][i] < 10 * kw["tol"]
+        xr, _ = e.get_eigenvector(i)
+        gr = r["vectors"][i][0]
+        s = np.sign(xr @ gr)
+        assert np.abs(s * gr - xr).max() < 1e-5
+
+
+def test_eps_analytic_2d(be):
+    n, m = 257, 193
+    r = common.solve_eps(be, mg.laplacian2d(n, m), nev=6, tol=1e-12)
+    cn = 2 * np.cos(np.arange(1, n + 1) * np.pi / (n + 1))
+    cm = 2 * np.cos(np.arange(1, m + 1) * np.pi / (m + 1))
+    exact = np.sort((4 - cn[:, None] - cm[None, :]).ravel())[::-1]
+    got = np.array([v[0] for v in r["values"][:6]])
+    assert np.abs(got - exact[:6]).max() / 8 < 1e-10
+    assert max(r["errors"][:6]) < 1e-10
+
+
+def test_no_cpu_fallback(gpu_ctx):
+    """The product cannot run without its device library."""
+    from slepc_amd import ksgpu
+    assert ksgpu.load().ksg_ctx_create is not None
+    import slepc_amd
+    import sys
+    assert "oracle" not in [m.split(".")[0] for m in sys.modules if m.startswith("slepc_amd")]

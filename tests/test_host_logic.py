@@ -1,0 +1,368 @@
+"""The C host library (libkseps) on a machine without a GPU: dense kernels against
+LAPACK, DS against the reference's golden outputs, and the BV / EPS control flow
+driven through a BV type registered with BVRegister whose kernels are the numpy
+oracle (tests/oracle_plugin.py)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from oracle import eps as oeps, lapack, matgen as og
+from slepc_amd import kseps as K
+from tests import common
+from tests.common import golden, dp
+
+lib = K.load()
+
+
+@pytest.fixture(scope="module")
+def be():
+    return common.Backend("oracle")
+
+
+# ---- dense kernels ------------------------------------------------------------------
+def _dense():
+    d = C.CDLL(K.LIB_PATH)
+    return d
+
+
+def test_dense_steqr_vs_lapack():
+    d = _dense()
+    rng = np.random.default_rng(0)
+    for n in (1, 2, 7, 33, 65):
+        dd, ee = rng.standard_normal(n), rng.standard_normal(max(n - 1, 1))
+        T = np.diag(dd) + np.diag(ee[:n - 1], 1) + np.diag(ee[:n - 1], -1)
+        Z = np.asfortranarray(np.eye(n))
+        d1, e1 = dd.copy(), ee.copy()
+        assert d.ksd_steqr(n, dp(d1), dp(e1), dp(Z), n, n) == 0
+        d2, e2 = dd.copy(), ee.copy()
+        Z2 = np.asfortranarray(np.eye(n)).reshape(-1, order="F")
+        assert lapack.dsteqr("V", n, d2, e2, Z2, n) == 0
+        assert np.abs(np.sort(d1) - np.sort(d2)).max() <= 1e-13 * max(1.0, np.abs(d2).max())
+        assert np.abs(Z @ np.diag(d1) @ Z.T - T).max() < 1e-13 * max(1, n)
+        assert np.abs(Z.T @ Z - np.eye(n)).max() < 1e-13 * max(1, n)
+
+
+@pytest.mark.parametrize("n,ilo", [(10, 0), (33, 0), (65, 0), (20, 5), (64, 20)])
+def test_dense_schur_swap_vectors(n, ilo):
+    d = _dense()
+    rng = np.random.default_rng(n + ilo)
+    A = rng.standard_normal((n, n))
+    if ilo:
+        A[:, :ilo] = np.triu(A[:, :ilo])
+    A = np.asfortranarray(A)
+    A0 = A.copy(order="F")
+    Q = np.zeros((n, n), order="F")
+    assert d.ksd_gehrd_orghr(n, ilo, dp(A), n, dp(Q), n) == 0
+    assert np.abs(np.tril(A[ilo:, ilo:], -2)).max() == 0.0
+    wr, wi = np.zeros(n), np.zeros(n)
+    assert d.ksd_hseqr(n, ilo, dp(A), n, dp(wr), dp(wi), dp(Q), n) == 0
+    tol = 1e-13 * n
+    assert np.abs(Q @ A @ Q.T - A0).max() < tol and np.abs(Q.T @ Q - np.eye(n)).max() < tol
+    ev = np.sort_complex(np.linalg.eigvals(A0[ilo:, ilo:]))
+    assert np.abs(np.sort_complex(wr[ilo:] + 1j * wi[ilo:]) - ev).max() < 1e-11
+    for a, b in ((n - 1, ilo), (ilo, n - 2), ((n + ilo) // 2, ilo + 1), (ilo + 2, n - 3)):
+        assert d.ksd_trexc(n, dp(A), n, dp(Q), n, n, a, b) == 0
+        assert np.abs(Q @ A @ Q.T - A0).max() < 4 * tol
+        assert np.abs(np.tril(A, -2)).max() == 0.0
+    xr, xi = np.zeros(n), np.zeros(n)
+    j = 0
+    while j < n:
+        if d.ksd_trevc_right(n, dp(A), n, j, dp(xr), dp(xi)):
+            assert A[j, j] == A[j + 1, j + 1] and A[j + 1, j] * A[j, j + 1] < 0      # standard form
+            lam = A[j, j] + 1j * np.sqrt(abs(A[j + 1, j])) * np.sqrt(abs(A[j, j + 1]))
+            x = xr + 1j * xi
+            assert np.abs(A @ x - lam * x).max() < 1e-11
+            j += 2
+        else:
+            assert np.abs(A @ xr - A[j, j] * xr).max() < 1e-11
+            j += 1
+
+
+# ---- DS ---------------------------------------------------------------------------------
+def _ds(dtype, ld):
+    h = C.c_void_p()
+    K.check(lib.DSCreate(C.byref(h)))
+    K.check(lib.DSSetType(h, dtype))
+    K.check(lib.DSAllocate(h, ld))
+    cmp_ = K.COMPARE_FN(("SlepcCompareLargestMagnitude", lib)[1].SlepcCompareLargestMagnitude)
+    K.check(lib.DSSetSlepcSC(h, C.cast(lib.SlepcCompareLargestMagnitude, K.COMPARE_FN), None))
+    return h
+
+
+def test_ds_hep_compact_golden():
+    """ds/examples/tests/test3.c -n 9 (l=2, k=5) against output/test3_1.out."""
+    g = golden("ds_tests.json")
+    n, l, k, ld = 9, 2, 5, 11
+    h = _ds(b"hep", ld)
+    K.check(lib.DSSetDimensions(h, n, 0, l, k))
+    K.check(lib.DSSetCompact(h, 1))
+    T = K.c_dp()
+    K.check(lib.DSGetArrayReal(h, K.DS_MAT_T, C.byref(T)))
+    for i in range(n):
+        T[i] = i + 1.0
+    for i in range(l, n - 1):
+        T[i + ld] = 1.0
+    K.check(lib.DSSetState(h, K.DS_STATE_RAW))
+    eig = np.zeros(n)
+    K.check(lib.DSSolve(h, dp(eig), None))
+    K.check(lib.DSSort(h, dp(eig), None, None, None, None))
+    assert ["%.5f" % v for v in eig] == g["hep_compact_eigs"]
+    # Q holds eigenvectors of the arrow matrix
+    Q = K.c_dp()
+    K.check(lib.DSGetArray(h, K.DS_MAT_Q, C.byref(Q)))
+    Qm = np.ctypeslib.as_array(Q, (ld * ld,)).reshape((ld, ld), order="F")[:n, :n]
+    Am = np.diag(np.arange(1.0, n + 1))
+    for i in range(l, k):
+        Am[i, k] = Am[k, i] = 1.0
+    for i in range(k, n - 1):
+        Am[i, i + 1] = Am[i + 1, i] = 1.0
+    assert np.abs(Am @ Qm - Qm @ np.diag(eig)).max() < 1e-13
+    K.check(lib.DSDestroy(C.byref(h)))
+
+
+def test_ds_nhep_grcar_golden():
+    """ds/examples/tests/test1.c (Grcar matrix, n=10) against output/test1_1.out."""
+    g = golden("ds_tests.json")
+    n, ld = 10, 12
+    h = _ds(b"nhep", ld)
+    K.check(lib.DSSetDimensions(h, n, 0, 0, 0))
+    A = K.c_dp()
+    K.check(lib.DSGetArray(h, K.DS_MAT_A, C.byref(A)))
+    for i in range(1, n):
+        A[i + (i - 1) * ld] = -1.0
+    for j in range(4):
+        for i in range(n - j):
+            A[i + (i + j) * ld] = 1.0
+    K.check(lib.DSSetState(h, K.DS_STATE_INTERMEDIATE))
+    wr, wi = np.zeros(n), np.zeros(n)
+    K.check(lib.DSSolve(h, dp(wr), dp(wi)))
+    K.check(lib.DSSort(h, dp(wr), dp(wi), None, None, None))
+    st = C.c_int()
+    K.check(lib.DSGetState(h, C.byref(st)))
+    assert st.value == K.DS_STATE_CONDENSED
+    assert ["%.5f%+.5fi" % (a, b) for a, b in zip(wr, wi)] == g["nhep_grcar_eigs"]
+    j, rnorm = C.c_int(2), C.c_double()
+    K.check(lib.DSVectors(h, K.DS_MAT_X, C.byref(j), C.byref(rnorm)))
+    assert "%.3f" % rnorm.value == g["nhep_rnorm3"]
+    K.check(lib.DSVectors(h, K.DS_MAT_X, None, None))
+    X = K.c_dp()
+    K.check(lib.DSGetArray(h, K.DS_MAT_X, C.byref(X)))
+    Xm = np.ctypeslib.as_array(X, (ld * ld,)).reshape((ld, ld), order="F")
+    assert "%.3f" % np.hypot(np.linalg.norm(Xm[:n, 0]), np.linalg.norm(Xm[:n, 1])) == g["nhep_norm1"]
+    K.check(lib.DSDestroy(C.byref(h)))
+
+
+def test_ds_errors():
+    h = C.c_void_p()
+    K.check(lib.DSCreate(C.byref(h)))
+    with pytest.raises(K.KsError):
+        K.check(lib.DSSetType(h, b"ghiep"))
+    with pytest.raises(K.KsError):
+        K.check(lib.DSAllocate(h, 5))                 # type first
+    K.check(lib.DSSetType(h, b"hep"))
+    K.check(lib.DSAllocate(h, 5))
+    with pytest.raises(K.KsError):
+        K.check(lib.DSSetDimensions(h, 6, 0, 0, 0))   # n > ld
+    with pytest.raises(K.KsError):
+        K.check(lib.DSTruncate(h, 2))                 # not solved
+    K.check(lib.DSDestroy(C.byref(h)))
+
+
+# ---- BV interface over the oracle plug-in -------------------------------------------------
+def test_bv_test1(be):
+    common.run_bv_test1(be)
+
+
+@pytest.mark.parametrize("otype", [K.BV_ORTHOG_CGS, K.BV_ORTHOG_MGS])
+def test_bv_test2(be, otype):
+    common.run_bv_test2(be, otype)
+
+
+@pytest.mark.parametrize("trans", [False, True])
+def test_bv_test4(be, trans):
+    common.run_bv_test4(be, trans)
+
+
+def test_bv_test13(be):
+    common.run_bv_test13(be)
+
+
+def test_bv_column_view_rules(be):
+    """bvbasic.c:1152-1224: at most two outstanding columns, same Vec restored."""
+    bv = be.bv(12, 4)
+    v0, v1, v2 = K.VecP(), K.VecP(), K.VecP()
+    K.check(lib.BVGetColumn(bv, 0, C.byref(v0)))
+    with pytest.raises(K.KsError):
+        K.check(lib.BVGetColumn(bv, 0, C.byref(v1)))          # already fetched
+    K.check(lib.BVGetColumn(bv, 1, C.byref(v1)))
+    with pytest.raises(K.KsError):
+        K.check(lib.BVGetColumn(bv, 2, C.byref(v2)))          # too many
+    with pytest.raises(K.KsError):
+        K.check(lib.BVRestoreColumn(bv, 2, C.byref(v1)))      # never fetched
+    K.check(lib.BVRestoreColumn(bv, 0, C.byref(v0)))
+    K.check(lib.BVRestoreColumn(bv, 1, C.byref(v1)))
+    with pytest.raises(K.KsError):
+        K.check(lib.BVGetColumn(bv, 4, C.byref(v0)))          # out of range
+    with pytest.raises(K.KsError):
+        K.check(lib.BVSetActiveColumns(bv, 3, 2))
+    with pytest.raises(K.KsError):
+        K.check(lib.BVSetType(bv, b"nosuchtype"))
+    be.destroy_bv(bv)
+
+
+def test_refinement_and_lindep(be):
+    """bvorthog.c:322-333: a vector in the span is flagged linearly dependent;
+    BVOrthonormalizeColumn stores the norm next to the coefficients."""
+    n, m = 50, 4
+    bv = be.bv(n, m)
+    rng = np.random.default_rng(0)
+    V = np.linalg.qr(rng.standard_normal((n, 2)))[0]
+    be.set_col(bv, 0, V[:, 0])
+    be.set_col(bv, 1, V[:, 1])
+    be.set_col(bv, 2, V @ np.array([0.3, -2.0]))
+    nrm, lin = C.c_double(), C.c_int()
+    K.check(lib.BVOrthogonalizeColumn(bv, 2, None, C.byref(nrm), C.byref(lin)))
+    # the criterion is only "not satisfied in the last pass": rounding noise that is already
+    # orthogonal passes it, so only the norm tells (as in the reference)
+    assert nrm.value < 1e-14
+    be.set_col(bv, 2, np.zeros(n))
+    K.check(lib.BVOrthogonalizeColumn(bv, 2, None, C.byref(nrm), C.byref(lin)))
+    assert lin.value == 1 and nrm.value == 0.0
+    w = rng.standard_normal(n)
+    be.set_col(bv, 2, w)
+    H = np.zeros(3)
+    K.check(lib.BVOrthonormalizeColumn(bv, 2, 0, C.byref(nrm), C.byref(lin)))
+    assert lin.value == 0
+    buf, ld = K.c_dp(), C.c_int()
+    K.check(lib.BVGetBuffer(bv, C.byref(buf), C.byref(ld)))
+    h = np.array([buf[2 * ld.value + i] for i in range(3)])
+    assert np.allclose(h[:2], V.T @ w, atol=1e-13) and abs(h[2] - nrm.value) == 0.0
+    assert abs(np.linalg.norm(be.get_col(bv, 2)) - 1.0) < 1e-14
+    be.destroy_bv(bv)
+
+
+# ---- EPS over the oracle plug-in ---------------------------------------------------------------
+def _fmt(vals, k, fmt="%.5f"):
+    return [fmt % v[0] for v in vals[:k]]
+
+
+def test_eps_goldens(be):
+    g = golden("eps_tests.json")
+    r = common.solve_eps(be, og.laplacian1d(30), nev=1)
+    assert "%.6f" % r["values"][0][0] == g["ex1"]["value"] and r["errors"][0] < 5e-8
+    r = common.solve_eps(be, og.laplacian2d(72), nev=4, ncv=20)
+    assert _fmt(r["values"], 4) == g["ex2"]["values"] and max(r["errors"][:4]) < 5e-8
+    rp, ci, va = og.markov(15)
+    v0 = np.zeros(len(rp) - 1)
+    v0[:2] = 1.0
+    r = common.solve_eps(be, (rp, ci, va), hermitian=False, nev=4, which="largest_real", v0=v0)
+    assert _fmt(r["values"], 4) == g["ex5"]["values"] and max(r["errors"][:4]) < 5e-8
+    r = common.solve_eps(be, (rp, ci, va), hermitian=False, nev=4)
+    assert _fmt(r["values"], 4) == g["test9"]["values"]
+    r = common.solve_eps(be, og.laplacian3d(10), nev=8, ncv=64, which="smallest_real")
+    assert _fmt(r["values"], 8) == g["ex19"]["values"]
+    r = common.solve_eps(be, og.laplacian1d(30), nev=4)
+    assert _fmt(r["values"], 4) == g["test4"]["values"]
+    r = common.solve_eps(be, og.laplacian1d(30), nev=4, which="smallest_real")
+    assert _fmt(r["values"], 4) == g["test2"]["smallest"]
+
+
+@pytest.mark.parametrize("case", ["lap2d", "lap1d_locking_off", "markov", "markov_mag"])
+def test_eps_matches_oracle_driver(be, case):
+    """Same start vector, same kernels: the C driver and the oracle driver must take
+    the same decisions (restarts, converged count) and agree to rounding."""
+    from scipy.sparse import csr_matrix
+    kw = dict(nev=5, tol=1e-10)
+    herm = True
+    if case == "lap2d":
+        csr = og.laplacian2d(31, 23)
+    elif case == "lap1d_locking_off":
+        csr = og.laplacian1d(200)
+        kw.update(lock=False, ncv=24)
+    else:
+        csr = og.markov(18)
+        herm = False
+        kw.update(which="largest_real" if case == "markov" else "largest_magnitude", tol=1e-12)
+    n = len(csr[0]) - 1
+    v0 = oeps.splitmix64_uniform(np.arange(n, dtype=np.uint64))
+    r = common.solve_eps(be, csr, hermitian=herm, v0=v0, want_vectors=True, **kw)
+    A = csr_matrix((csr[2], csr[1], csr[0]))
+
+    def mv(x, y):
+        y[:] = A @ x
+    e = oeps.EPS(mv, n, hermitian=herm, v0=v0, **kw).solve()
+    assert r["its"] == e.its and r["nconv"] == e.nconv
+    if case == "markov_mag":
+        # +lambda and -lambda tie in magnitude; their relative order is decided by the last bit
+        key = lambda v: (-round(abs(v[0]), 9), -v[0])
+        got = sorted(r["values"][:4], key=key)
+        ref = sorted([e.get_eigenvalue(i) for i in range(4)], key=key)
+        for a, b in zip(got, ref):
+            assert abs(a[0] - b[0]) <= 1e-10 and abs(a[1] - b[1]) <= 1e-10
+        return
+    for i in range(kw["nev"]):
+        lam = e.get_eigenvalue(i)
+        assert abs(r["values"][i][0] - lam[0]) <= 1e-10 * abs(lam[0]) and abs(r["values"][i][1] - lam[1]) <= 1e-10
+        assert r["errors"][i] < 10 * kw["tol"]
+        xr, _ = e.get_eigenvector(i)
+        gr = r["vectors"][i][0]
+        s = np.sign(xr @ gr)
+        assert np.abs(s * gr - xr).max() < 1e-6
+
+
+def test_eps_errors_and_defaults(be):
+    A = be.mat_csr(*og.laplacian1d(50))
+    eps = K.EPS(None)
+    with pytest.raises(K.KsError):
+        eps.solve()                                   # no operators
+    eps.set_operators(A)
+    with pytest.raises(K.KsError):
+        eps.set_dimensions(0)
+    with pytest.raises(K.KsError):
+        eps.get_eigenvalue(0)                         # not solved
+    eps.set_problem_type(K.EPS_HEP)
+    eps.set_bv_type("oracle")
+    eps.set_dimensions(3)
+    eps.setup()
+    assert eps.dimensions() == (3, 18, 18)            # ncv = max(2 nev, nev+15), mpd = ncv
+    eps.solve()
+    assert eps.reason == K.EPS_CONVERGED_TOL and eps.nconv >= 3
+    with pytest.raises(K.KsError):
+        eps.get_eigenvalue(eps.nconv)
+    eps.destroy()
+    eps = K.EPS(None)
+    eps.set_operators(A)
+    eps.set_problem_type(K.EPS_HEP)
+    eps.set_bv_type("oracle")
+    eps.set_dimensions(4, 4)                          # ncv < nev+1
+    with pytest.raises(K.KsError):
+        eps.solve()
+    eps.destroy()
+    eps = K.EPS(None)
+    eps.set_operators(A)
+    eps.set_problem_type(K.EPS_HEP)
+    eps.set_bv_type("oracle")
+    eps.set_dimensions(8, 16)
+    eps.set_tolerances(1e-14, 2)                      # two restarts only
+    eps.solve()
+    assert eps.reason == K.EPS_DIVERGED_ITS and eps.its == 2
+    eps.destroy()
+    A.destroy()
+
+
+def test_libraries_export_declared_symbols():
+    """Every function declared in include/ksgpu.h and include/kseps.h is exported."""
+    import os
+    import re
+    from slepc_amd import ksgpu
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for header, libpath, table in (("ksgpu.h", ksgpu.LIB_PATH, ksgpu.SIGNATURES), ("kseps.h", K.LIB_PATH, K.SIGNATURES)):
+        text = open(os.path.join(root, "include", header)).read()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        names = set(re.findall(r"\b((?:ksg_|KS|Vec|Mat|BV|DS|EPS|Slepc)\w+)\s*\(", text))
+        names = {n for n in names if not n.endswith("Fn") and n not in ("EPSMonitorFn",)}
+        dll = C.CDLL(libpath)
+        missing = [n for n in sorted(names) if not hasattr(dll, n)]
+        assert not missing, missing
+        assert names <= set(table) | {"SlepcCompareFn"}, sorted(names - set(table))
