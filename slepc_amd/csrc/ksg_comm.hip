@@ -115,7 +115,7 @@ int ksg_comm_destroy(ksg_ctx c) {
  * return. */
 int ksg_comm_allreduce(ksg_ctx c, double *d_buf, double *h_out, int count, int op) {
   if (count > KSG_RED_MAX) KSG_FAIL(KSG_ERR_ARG, "reduction of %d values exceeds %d", count, KSG_RED_MAX);
-  if (c->comm_kind == KSG_COMM_RCCL && c->nranks > 1) {
+  if (c->comm_kind == KSG_COMM_RCCL) {
     KSG_NCCL(g_rccl.AllReduce(d_buf, d_buf, (size_t)count, k_ncclDouble,
                               op ? k_ncclMax : k_ncclSum, c->rccl_comm, c->stream));
   } else if (c->comm_kind == KSG_COMM_CALLBACKS && c->nranks > 1 && c->cb_on_device) {

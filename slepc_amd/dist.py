@@ -1,0 +1,80 @@
+"""One process per GPU: wiring of a libksgpu context to the other ranks.
+
+``torch.distributed`` is used only as the rendezvous / plumbing layer (it reads
+RANK, WORLD_SIZE, MASTER_ADDR, MASTER_PORT as set by ``torch.distributed.run``):
+
+* ``transport="rccl"``  -- rank 0 creates an RCCL unique id, the id is broadcast
+  over the (gloo) process group, and every rank joins the RCCL communicator
+  inside libksgpu; all data-path collectives (dot-product all-reduce, halo
+  exchange) then run natively on RCCL over xGMI.
+* ``transport="gloo"``  -- the collectives are served by callbacks into
+  ``torch.distributed`` on host buffers (used by the tests, where two ranks may
+  share one GPU, which RCCL does not allow).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+
+def env_rank():
+    return (int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")),
+            int(os.environ.get("WORLD_SIZE", "1")))
+
+
+def init_process_group():
+    import torch.distributed as dist
+    if not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29512")
+        dist.init_process_group(backend="gloo")
+    return dist
+
+
+def gloo_callbacks(dist):
+    """(allreduce, exchange) working on raw host addresses through gloo."""
+    import torch
+
+    def _tensor(addr, count):
+        buf = (C.c_double * count).from_address(addr)
+        return torch.from_numpy(np.ctypeslib.as_array(buf))
+
+    def allreduce(addr, count, op):
+        t = _tensor(addr, count)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX if op else dist.ReduceOp.SUM)
+
+    def exchange(saddr, soff, raddr, roff):
+        rank, size = dist.get_rank(), dist.get_world_size()
+        reqs = []
+        for p in range(size):
+            ns, nr = soff[p + 1] - soff[p], roff[p + 1] - roff[p]
+            if p == rank:
+                if ns:
+                    C.memmove(raddr + 8 * roff[p], saddr + 8 * soff[p], 8 * ns)
+                continue
+            if nr:
+                reqs.append(dist.irecv(_tensor(raddr + 8 * roff[p], nr), src=p))
+            if ns:
+                reqs.append(dist.isend(_tensor(saddr + 8 * soff[p], ns), dst=p))
+        for r in reqs:
+            r.wait()
+
+    return allreduce, exchange
+
+
+def init_comm(ctx, transport="rccl"):
+    """Joins `ctx` to the communicator of all ranks.  Returns (rank, nranks)."""
+    rank, _, size = env_rank()
+    if size == 1 and transport != "rccl-force":
+        return 0, 1
+    dist = init_process_group()
+    if transport.startswith("rccl"):
+        uid = [ctx.unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(uid, src=0)
+        ctx.comm_init_rccl(rank, size, uid[0])
+    elif transport == "gloo":
+        ar, ex = gloo_callbacks(dist)
+        ctx.comm_init_callbacks(rank, size, ar, ex, on_device=False)
+    else:
+        raise ValueError("unknown transport " + transport)
+    return rank, size

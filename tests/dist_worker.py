@@ -1,0 +1,142 @@
+"""One rank of a multi-process solve (launched by tests/test_dist*.py through
+``torch.distributed.run``-style environment variables).
+
+mode cpu: C host driver + test-only oracle plug-in, reductions over gloo.
+mode gpu: the product path; every rank opens device 0 and the collectives of
+          libksgpu are served by gloo callbacks on host buffers (RCCL refuses two
+          ranks on one device, and the test box has one GPU).
+"""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+
+def main():
+    mode, case, out = sys.argv[1], sys.argv[2], sys.argv[3]
+    from slepc_amd import dist as kdist, kseps as K, matgen as mg
+    rank, _, size = kdist.env_rank()
+    dist = kdist.init_process_group() if size > 1 else None
+
+    if case == "lap2d":
+        gx, gy = 61, 47
+        N = gx * gy
+        row0, row1 = mg.split_rows(N, size, rank)
+        csr = mg.laplacian2d(gx, gy, row0, row1)
+        herm, kw = True, dict(nev=6, tol=1e-10)
+    elif case == "lap3d":
+        g = (17, 13, 11)
+        N = g[0] * g[1] * g[2]
+        row0, row1 = mg.split_rows(N, size, rank)
+        csr = mg.laplacian3d(*g, row0=row0, row1=row1)
+        herm, kw = True, dict(nev=5, tol=1e-10)
+    elif case == "markov":
+        m = 40
+        N = m * (m + 1) // 2
+        row0, row1 = mg.split_rows(N, size, rank)
+        csr = mg.markov(m, row0, row1)
+        herm, kw = False, dict(nev=5, tol=1e-12, which="largest_real")
+    elif case == "rmat":
+        N = 1 << 11
+        row0, row1 = mg.split_rows(N, size, rank)
+        csr = mg.rmat_laplacian(11, row0=row0, row1=row1)
+        herm, kw = True, dict(nev=4, tol=1e-10)
+    else:
+        raise ValueError(case)
+    n = row1 - row0
+    rp, ci, va = csr
+
+    if mode == "cpu":
+        import torch
+        from scipy.sparse import csr_matrix
+        from tests import oracle_plugin as plug
+
+        class GlooComm:
+            def __init__(self):
+                self.rank, self.size = rank, size
+
+            def _red(self, a, op):
+                t = torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64).copy())
+                if size > 1:
+                    dist.all_reduce(t, op=op)
+                return t.numpy()
+
+            def allreduce_sum(self, a):
+                return self._red(a, dist.ReduceOp.SUM if dist else None)
+
+            def allreduce_max(self, a):
+                return self._red(a, dist.ReduceOp.MAX if dist else None)
+
+        plug.COMM[0] = GlooComm()
+        A = csr_matrix((va, ci, rp), shape=(n, N))
+        counts = [mg.split_rows(N, size, r)[1] - mg.split_rows(N, size, r)[0] for r in range(size)]
+
+        def mv(x, y):
+            if size > 1:
+                parts = [torch.zeros(c, dtype=torch.float64) for c in counts]
+                dist.all_gather(parts, torch.from_numpy(x.copy())) if len(set(counts)) == 1 else \
+                    [dist.broadcast(parts[r] if r != rank else parts[r].copy_(torch.from_numpy(x)), src=r) for r in range(size)]
+                xf = torch.cat(parts).numpy()
+            else:
+                xf = x
+            y[:] = A @ xf
+
+        Am = plug.shell_mat(mv, n, N, row0)
+        eps = K.EPS(None)
+        bvtype = "oracle"
+        ctx = None
+    else:
+        from slepc_amd import ksgpu
+        ctx = ksgpu.Context(0)
+        if size > 1:
+            kdist.init_comm(ctx, transport=os.environ.get("KS_TRANSPORT", "gloo"))
+        Am = K.Mat.create_aij_hip(ctx, rp, ci, va, N=N, row0=row0)
+        eps = K.EPS(ctx.h)
+        bvtype = "hip"
+
+    eps.set_operators(Am)
+    eps.set_problem_type(K.EPS_HEP if herm else K.EPS_NHEP)
+    eps.set_dimensions(kw["nev"])
+    eps.set_tolerances(kw["tol"])
+    if "which" in kw:
+        eps.set_which(kw["which"])
+    eps.set_bv_type(bvtype)
+    if not herm:
+        v0 = Am.create_vecs()
+        g = np.arange(row0, row1)
+        v0.set_values(((g == 0) | (g == 1)).astype(np.float64))
+        eps.set_initial_space([v0])
+    eps.solve()
+    res = {"its": eps.its, "nconv": eps.nconv, "reason": eps.reason,
+           "values": [eps.get_eigenvalue(i) for i in range(eps.nconv)],
+           "errors": [eps.compute_error(i) for i in range(min(eps.nconv, kw["nev"]))]}
+    xr = Am.create_vecs()
+    eps.get_eigenpair(0, xr)
+    local = xr.get_values()
+    if size > 1:
+        gathered = [None] * size
+        dist.all_gather_object(gathered, local)
+        res["x0"] = np.concatenate(gathered).tolist()
+    else:
+        res["x0"] = local.tolist()
+    if mode == "gpu":
+        from slepc_amd import ksgpu  # noqa: F811
+        res["mat_info"] = None
+    if rank == 0:
+        with open(out, "w") as f:
+            json.dump(res, f)
+    if dist:
+        dist.barrier()
+    eps.destroy()
+    xr.destroy()
+    Am.destroy()
+    if ctx:
+        ctx.close()
+
+
+if __name__ == "__main__":
+    main()

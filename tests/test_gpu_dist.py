@@ -1,0 +1,41 @@
+"""Row-partitioned runs of the product path.  The box has one GPU, so two or three
+ranks share device 0 and the collectives of libksgpu are served by gloo callbacks
+(host buffers); the partitioning, the diagonal/ghost split, the halo gather lists
+and the ghost-block kernel are the ones the RCCL transport uses.  RCCL itself is
+exercised on a single-rank communicator."""
+import numpy as np
+import pytest
+
+from tests.dist_util import run_ranks
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("case,nev,ranks", [("lap2d", 6, 2), ("markov", 5, 2), ("lap3d", 5, 3), ("rmat", 4, 2)])
+def test_ranks_match_single(case, nev, ranks):
+    one = run_ranks("gpu", case, 1)
+    many = run_ranks("gpu", case, ranks)
+    assert one["reason"] == many["reason"] == 1
+    for a, b in zip(one["values"][:nev], many["values"][:nev]):
+        assert abs(a[0] - b[0]) <= 1e-10 * max(abs(a[0]), 1e-300) and abs(a[1] - b[1]) <= 1e-10
+    assert max(many["errors"]) < 1e-8
+    x1, x2 = np.array(one["x0"]), np.array(many["x0"])
+    s = np.sign(x1 @ x2)
+    assert np.abs(s * x2 - x1).max() < 1e-6
+
+
+def test_rccl_single_rank_communicator():
+    """dlopen of RCCL, ncclCommInitRank and the all-reduce on the compute stream."""
+    from slepc_amd import ksgpu
+    ctx = ksgpu.Context(0)
+    ctx.comm_init_rccl(0, 1, ctx.unique_id())
+    n = 100003
+    V = ksgpu.DeviceBV(ctx, n, 3)
+    rng = np.random.default_rng(0)
+    A = rng.standard_normal((n, 3))
+    V.from_numpy(A)
+    q = V.dotvec(V.column(2))
+    assert np.allclose(q, A.T @ A[:, 2], rtol=1e-12, atol=1e-9)
+    assert abs(V.norm(1, 1) - np.linalg.norm(A[:, 1])) < 1e-10
+    V.destroy()
+    ctx.close()
