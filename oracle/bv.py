@@ -51,6 +51,7 @@ class BV:
         self.buffer = None
         # counters used by the byte/flop model of the benchmark
         self.npasses = 0
+        self.bytes = 0.0     # algorithmic bytes moved by the op table (same model as the device library)
 
     # ---- views -------------------------------------------------------
     def col(self, j):
@@ -75,6 +76,7 @@ class BV:
         """``BVDotVec_Svec`` (svec.c:122-143) -> ``BVDotVec_BLAS_Private``
         (bvblas.c:242-266): q = X(:,l:k)^T y, then SUM-allreduce."""
         kk = self.k - self.l
+        self.bytes += 8.0 * self.n * (kk + 1)
         X = self.array[:, self.nc + self.l:self.nc + self.k]
         loc = X.T @ y if self.n else np.zeros(kk)
         res = self.comm.allreduce_sum(np.asarray(loc, dtype=np.float64))
@@ -88,6 +90,7 @@ class BV:
         """``BVMultVec_Svec`` (svec.c:51-66) -> gemv 'N' (bvblas.c:65-76):
         y = beta*y + alpha*X(:,l:k) q."""
         kk = self.k - self.l
+        self.bytes += 8.0 * self.n * (kk + 2)
         qq = self.get_buffer()[:kk] if q is None else np.asarray(q)[:kk]
         X = self.array[:, self.nc + self.l:self.nc + self.k]
         if self.n:
@@ -103,6 +106,7 @@ class BV:
         ``BVMultInPlace_BLAS_Private`` (bvblas.c:83-119):
         V(:,s:e) = V(:,l:k) * Q(l:k, s:e)   (Q indexed absolutely)."""
         l, k = self.l, self.k
+        self.bytes += 8.0 * self.n * ((k - l) + (e - s))
         A = self.array[:, self.nc + l:self.nc + k]
         if trans:
             B = Q[s:e, l:k].T
@@ -115,6 +119,7 @@ class BV:
         """``BVScale_Svec`` (svec.c:165-180), ``BVScale_BLAS_Private``
         (bvblas.c:271-285)."""
         tgt = self.active() if j < 0 else self.array[:, self.nc + j:self.nc + j + 1]
+        self.bytes += 16.0 * tgt.size
         if alpha == 0.0:
             tgt[...] = 0.0
         elif alpha != 1.0:
@@ -124,6 +129,7 @@ class BV:
         """``BVNorm_Svec`` (svec.c:182-197), ``BVNorm_LAPACK_Private``
         (bvblas.c:290-340)."""
         A = self.active() if j < 0 else self.array[:, self.nc + j:self.nc + j + 1]
+        self.bytes += 8.0 * A.size
         if ntype in (NORM_2, NORM_FROBENIUS):
             loc = np.array([float(np.sum(A * A))])
             return float(np.sqrt(self.comm.allreduce_sum(loc)[0]))
@@ -223,6 +229,7 @@ class BV:
         """``BVCopyColumn`` (bvbasic.c:1628-1650)."""
         if j == i:
             return
+        self.bytes += 16.0 * self.n
         self.col(i)[:] = self.col(j)
 
     def insert_vec(self, j, w):
