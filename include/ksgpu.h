@@ -51,6 +51,15 @@ int ksg_ctx_destroy(ksg_ctx ctx);
 int ksg_ctx_sync(ksg_ctx ctx);
 /* The HIP stream (hipStream_t) all kernels are launched on. */
 void *ksg_ctx_stream(ksg_ctx ctx);
+/* Tuning switches.  KSG_OPT_FUSE_DOTS (default 1): ksg_bv_multvec on the column that
+ * follows the active ones also forms that column's products with the active columns
+ * and with itself, and the ksg_bv_dotvec that asks for them next costs no pass over
+ * the basis.  No counterpart in the reference (its two GEMVs are separate BLAS calls,
+ * bvblas.c:65-76,242-266); results are the same reductions in a different order.
+ * KSG_OPT_DOT_GRID / KSG_OPT_MV_GRID: upper bound on the workgroups along the rows of
+ * the reduction (default 256, one per CU) and update (default 1024) kernels. */
+enum { KSG_OPT_FUSE_DOTS = 1, KSG_OPT_DOT_GRID = 2, KSG_OPT_MV_GRID = 3 };
+int ksg_ctx_set_option(ksg_ctx ctx, int option, int value);
 const char *ksg_last_error(void);
 
 /* Communicator.  The reference reduces with MPI_Allreduce on PetscObjectComm(bv)
@@ -99,6 +108,10 @@ int ksg_bv_set_active(ksg_bv bv, int l, int k);
 int ksg_bv_sizes(ksg_bv bv, int64_t *n_local, int64_t *N, int *m, int64_t *ld);
 /* Device address of column j (BVGetColumn_Svec, svec.c:312-324: pv+(nc+j)*n). */
 double *ksg_bv_column(ksg_bv bv, int j);
+/* Must be called after column storage was written by anything other than this
+ * library (a kernel of the caller, hipMemcpy) through a pointer from ksg_bv_column:
+ * the counterpart of the state bump in BVRestoreColumn (bvbasic.c:1212-1215). */
+int ksg_bv_touch(ksg_bv bv);
 /* q[i] = sum_r X[r,l+i]*y[r], i<k-l, summed over ranks; q is a HOST array
  * (BVDotVec_Svec svec.c:122 -> BVDotVec_BLAS_Private bvblas.c:242). */
 int ksg_bv_dotvec(ksg_bv X, const double *y_dev, double *q_host);
@@ -155,7 +168,9 @@ int ksg_mat_info(ksg_mat A, int64_t info[4]);
  * stfunc.c:75-82). */
 enum {
   KSG_EV_DOTVEC = 0, KSG_EV_MULTVEC, KSG_EV_MULTINPLACE, KSG_EV_SCALE, KSG_EV_NORM,
-  KSG_EV_COPY, KSG_EV_MATMULT, KSG_EV_MULT, KSG_EV_DOT, KSG_EV_VECOPS, KSG_EV_COUNT
+  KSG_EV_COPY, KSG_EV_MATMULT, KSG_EV_MULT, KSG_EV_DOT, KSG_EV_VECOPS,
+  KSG_EV_DOTVEC_FUSED,            /* dotvec requests answered by the preceding fused multvec: no bytes, no time */
+  KSG_EV_COUNT
 };
 typedef struct {
   int64_t calls[KSG_EV_COUNT];

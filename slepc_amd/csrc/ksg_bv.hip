@@ -43,86 +43,123 @@ __global__ __launch_bounds__(KSG_BLOCK) void k_reduce_partials(const double *__r
 }
 
 /* ------------------------------------------------------------------------ */
+/* streaming loads                                                            */
+/* ------------------------------------------------------------------------ */
+/* Basis columns are read once per kernel and are far larger than the caches:
+ * loading them with the non-temporal hint keeps them from displacing the lines
+ * that are reused (y, partial sums) and measurably raises the sustained HBM
+ * read rate. */
+__device__ __forceinline__ double2 ld_stream(const double2 *p) {
+  double2 r;
+  r.x = __builtin_nontemporal_load(&p->x);
+  r.y = __builtin_nontemporal_load(&p->y);
+  return r;
+}
+__device__ __forceinline__ double ld_stream(const double *p) { return __builtin_nontemporal_load(p); }
+/* Scheduling fence for a batch of independent loads: placed on every loaded value
+ * after the batch, it keeps the compiler from interleaving each load with its use
+ * (which would leave one request in flight per lane instead of the whole batch). */
+__device__ __forceinline__ void ld_fence(double2 &v) { asm volatile("" : "+v"(v.x), "+v"(v.y)); }
+__device__ __forceinline__ void ld_fence(double &v) { asm volatile("" : "+v"(v)); }
+
+template <int VEC> struct ksg_pack;
+template <> struct ksg_pack<2> { typedef double2 type; };
+template <> struct ksg_pack<1> { typedef double type; };
+__device__ __forceinline__ double dot_acc(double2 x, double2 y, double a) { return fma(x.y, y.y, fma(x.x, y.x, a)); }
+__device__ __forceinline__ double dot_acc(double x, double y, double a) { return fma(x, y, a); }
+__device__ __forceinline__ void axpy_acc(double2 x, double q, double2 &a) { a.x = fma(x.x, q, a.x); a.y = fma(x.y, q, a.y); }
+__device__ __forceinline__ void axpy_acc(double x, double q, double &a) { a = fma(x, q, a); }
+
+/* ------------------------------------------------------------------------ */
 /* dotvec: q = X^T y  (tall-skinny GEMV^T)                                    */
 /* ------------------------------------------------------------------------ */
-/* grid.x = row blocks (grid-stride), grid.y = chunks of C columns.  Each thread
- * keeps C accumulators; y is read once per chunk, every column once.  The last
- * chunk may hold fewer than C columns: its spare slots re-read the chunk's last
- * column (cache hits) and are dropped at the end, which keeps the loop free of
- * per-load branches.  VEC = 2 reads row pairs as double2 (pointers 16-byte
- * aligned), VEC = 1 is the fallback for unaligned vectors. */
-template <int C, int VEC>
-__global__ __launch_bounds__(KSG_BLOCK) void k_dotvec(const double *__restrict__ X, int64_t ld, int k,
-                                                       const double *__restrict__ y, int64_t n,
-                                                       double *__restrict__ partial, int nb) {
-  const int c0 = blockIdx.y * C;
-  const int kc = min(C, k - c0);
-  const double *col[C];
+/* A workgroup is G x R waves: wave (g, r) owns the CW columns of column group g
+ * and the r-th of the R blocks of 64 row pairs the workgroup walks per step, so
+ * the G waves that share rows read y from HBM once (the others hit in cache) and
+ * every basis element is loaded exactly once, 16 B per lane, CW independent
+ * loads in flight per lane.  The grid is small on purpose (a few waves per SIMD,
+ * all resident at once): read streams this wide sustain more bandwidth with
+ * fewer, longer-lived waves.  partial[col * nb + row block] holds one value per
+ * wave; k_reduce_partials adds them in a fixed order.  VEC = 2 needs 16-byte
+ * aligned columns; VEC = 1 is the fallback for unaligned vectors. */
+template <int CW, int NC, int VEC>
+__device__ __forceinline__ void dotw_rows(const typename ksg_pack<VEC>::type *const (&col)[CW],
+                                          const typename ksg_pack<VEC>::type *__restrict__ y, int64_t p,
+                                          int64_t npack, int64_t stride, double (&acc)[CW]) {
+  typedef typename ksg_pack<VEC>::type T;
+  for (; p < npack; p += stride) {
+    const T yv = y[p];
+    T xv[NC > 0 ? NC : 1];
 #pragma unroll
-  for (int c = 0; c < C; c++) col[c] = X + (int64_t)(c0 + (c < kc ? c : kc - 1)) * ld;
-  double acc[C];
+    for (int c = 0; c < NC; c++) xv[c] = ld_stream(col[c] + p);
 #pragma unroll
-  for (int c = 0; c < C; c++) acc[c] = 0.0;
-
-  const int64_t stride = (int64_t)gridDim.x * KSG_BLOCK;
-  int64_t p = (int64_t)blockIdx.x * KSG_BLOCK + threadIdx.x;
-  if (VEC == 2) {
-    const int64_t npair = n >> 1;
-    const double2 *y2 = reinterpret_cast<const double2 *>(y);
-    for (; p < npair; p += stride) {
-      const double2 yv = y2[p];
-      double2 xv[C];
+    for (int c = 0; c < NC; c++) ld_fence(xv[c]);
 #pragma unroll
-      for (int c = 0; c < C; c++) xv[c] = reinterpret_cast<const double2 *>(col[c])[p];
-#pragma unroll
-      for (int c = 0; c < C; c++) {
-        acc[c] = fma(xv[c].x, yv.x, acc[c]);
-        acc[c] = fma(xv[c].y, yv.y, acc[c]);
-      }
-    }
-    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
-      const double yv = y[n - 1];
-#pragma unroll
-      for (int c = 0; c < C; c++) acc[c] = fma(col[c][n - 1], yv, acc[c]);
-    }
-  } else {
-    for (; p < n; p += stride) {
-      const double yv = y[p];
-      double xv[C];
-#pragma unroll
-      for (int c = 0; c < C; c++) xv[c] = col[c][p];
-#pragma unroll
-      for (int c = 0; c < C; c++) acc[c] = fma(xv[c], yv, acc[c]);
-    }
-  }
-
-  __shared__ double sm[KSG_BLOCK / 64][C];
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-#pragma unroll
-  for (int c = 0; c < C; c++) {
-    const double v = wave_sum(acc[c]);
-    if (lane == 0) sm[w][c] = v;
-  }
-  __syncthreads();
-  if ((int)threadIdx.x < kc) {
-    double s = sm[0][threadIdx.x];
-#pragma unroll
-    for (int ww = 1; ww < KSG_BLOCK / 64; ww++) s += sm[ww][threadIdx.x];
-    partial[(int64_t)(c0 + threadIdx.x) * nb + blockIdx.x] = s;
+    for (int c = 0; c < NC; c++) acc[c] = dot_acc(xv[c], yv, acc[c]);
   }
 }
 
-template <int C>
-static void launch_dotvec_c(ksg_ctx c, const double *X, int64_t ld, int k, const double *y, int64_t n,
-                            int nb, int nchunks, bool vec2) {
-  dim3 grid(nb, nchunks);
-  if (vec2)
-    hipLaunchKernelGGL((k_dotvec<C, 2>), grid, dim3(KSG_BLOCK), 0, c->stream, X, ld, k, y, n, c->d_partial, nb);
-  else
-    hipLaunchKernelGGL((k_dotvec<C, 1>), grid, dim3(KSG_BLOCK), 0, c->stream, X, ld, k, y, n, c->d_partial, nb);
+/* The k columns are dealt to NG column groups as evenly as possible: the first
+ * NG-d groups take CW columns, the last d take CW-1 (k = NG*CW - d, 0 <= d < NG), so
+ * a wave runs one of two fully unrolled loop bodies and never issues a load it
+ * does not need. */
+__device__ __forceinline__ void group_columns(int gi, int k, int CW, int NG, int &c0, int &kc) {
+  const int d = NG * CW - k;
+  const int nfull = NG - d;
+  c0 = gi * CW - max(0, gi - nfull);
+  kc = gi < nfull ? CW : CW - 1;
+  if (gi >= NG) kc = 0;
+}
+
+template <int CW, int VEC>
+__global__ void k_dotw(const double *__restrict__ X, int64_t ld, int k, const double *__restrict__ y, int64_t n,
+                       double *__restrict__ partial, int nb, int G, int NG) {
+  typedef typename ksg_pack<VEC>::type T;
+  const int lane = threadIdx.x & 63;
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int R = (blockDim.x >> 6) / G;
+  const int g = w % G, r = w / G;
+  int c0, kc;                                   /* wave-uniform */
+  group_columns(blockIdx.y * G + g, k, CW, NG, c0, kc);
+  if (kc <= 0) return;
+  const T *col[CW];
+#pragma unroll
+  for (int c = 0; c < CW; c++) col[c] = reinterpret_cast<const T *>(X + (int64_t)(c0 + (c < kc ? c : 0)) * ld);
+  double acc[CW];
+#pragma unroll
+  for (int c = 0; c < CW; c++) acc[c] = 0.0;
+  const int64_t rb = (int64_t)blockIdx.x * R + r;
+  const int64_t stride = (int64_t)gridDim.x * R * 64;
+  const int64_t npack = (VEC == 2) ? (n >> 1) : n;
+  if (kc == CW) dotw_rows<CW, CW, VEC>(col, reinterpret_cast<const T *>(y), rb * 64 + lane, npack, stride, acc);
+  else          dotw_rows<CW, CW - 1, VEC>(col, reinterpret_cast<const T *>(y), rb * 64 + lane, npack, stride, acc);
+  if (VEC == 2 && (n & 1) && rb == 0 && lane == 0) {
+    const double yv = y[n - 1];
+#pragma unroll
+    for (int c = 0; c < CW; c++)
+      if (c < kc) acc[c] = fma(X[(int64_t)(c0 + c) * ld + n - 1], yv, acc[c]);
+  }
+#pragma unroll
+  for (int c = 0; c < CW; c++) {
+    const double v = wave_sum(acc[c]);
+    if (lane == 0 && c < kc) partial[(int64_t)(c0 + c) * nb + rb] = v;
+  }
 }
 
 static inline bool aligned16(const void *p) { return (((uintptr_t)p) & 15) == 0; }
+
+template <int VEC>
+static void launch_dotw(int CW, dim3 grid, dim3 block, hipStream_t st, const double *X, int64_t ld, int k,
+                        const double *y, int64_t n, double *partial, int nb, int G, int NG) {
+#define KSG_DOTW_CASE(C) case C: hipLaunchKernelGGL((k_dotw<C, VEC>), grid, block, 0, st, X, ld, k, y, n, partial, nb, G, NG); break;
+  switch (CW) {
+    KSG_DOTW_CASE(1) KSG_DOTW_CASE(2) KSG_DOTW_CASE(3) KSG_DOTW_CASE(4) KSG_DOTW_CASE(5) KSG_DOTW_CASE(6)
+    KSG_DOTW_CASE(7) KSG_DOTW_CASE(8) KSG_DOTW_CASE(9) KSG_DOTW_CASE(10) KSG_DOTW_CASE(11) KSG_DOTW_CASE(12)
+    KSG_DOTW_CASE(13) KSG_DOTW_CASE(14) KSG_DOTW_CASE(15)
+    default: hipLaunchKernelGGL((k_dotw<16, VEC>), grid, block, 0, st, X, ld, k, y, n, partial, nb, G, NG); break;
+  }
+#undef KSG_DOTW_CASE
+}
 
 /* d_out[i] = sum_r X[r + i*ld] * y[r], i < k (local rows only). */
 int ksg_launch_dotvec(ksg_ctx c, const double *X, int64_t ld, int k, const double *y, int64_t n,
@@ -130,80 +167,170 @@ int ksg_launch_dotvec(ksg_ctx c, const double *X, int64_t ld, int k, const doubl
   if (k <= 0) return KSG_OK;
   if (n <= 0) { KSG_HIP(hipMemsetAsync(d_out, 0, (size_t)k * sizeof(double), c->stream)); return KSG_OK; }
   const bool vec2 = aligned16(X) && aligned16(y) && (ld % 2 == 0);
-  const int nb = ksg_grid_for(vec2 ? (n + 1) / 2 : n);
+  /* column groups of at most 16 columns, evenly filled; at most 16 groups per workgroup */
+  const int ngroups = (k + 15) / 16;
+  const int CW = (k + ngroups - 1) / ngroups;
+  const int G = ngroups < 16 ? ngroups : 16;
+  const int R = G == 1 ? 4 : (G == 2 ? 2 : 1);
+  const int ny = (ngroups + G - 1) / G;
+  const int64_t nwork = ((vec2 ? (n + 1) / 2 : n) + 63) / 64;          /* blocks of 64 lanes */
+  int64_t gx = (nwork + R - 1) / R;
+  if (gx > c->dot_grid) gx = c->dot_grid;
+  const int nb = (int)gx * R;
   KSG_CHK(ksg_ensure_partial(c, (size_t)k * nb));
-  const int nchunks16 = (k + 15) / 16;
-  const int per = (k + nchunks16 - 1) / nchunks16;      /* columns per chunk, <= 16 */
-  if (per <= 4)       launch_dotvec_c<4>(c, X, ld, k, y, n, nb, (k + 3) / 4, vec2);
-  else if (per <= 8)  launch_dotvec_c<8>(c, X, ld, k, y, n, nb, (k + 7) / 8, vec2);
-  else if (per <= 12) launch_dotvec_c<12>(c, X, ld, k, y, n, nb, (k + 11) / 12, vec2);
-  else                launch_dotvec_c<16>(c, X, ld, k, y, n, nb, (k + 15) / 16, vec2);
+  if (vec2) launch_dotw<2>(CW, dim3((unsigned)gx, ny), dim3(64 * G * R), c->stream, X, ld, k, y, n, c->d_partial, nb, G, ngroups);
+  else      launch_dotw<1>(CW, dim3((unsigned)gx, ny), dim3(64 * G * R), c->stream, X, ld, k, y, n, c->d_partial, nb, G, ngroups);
   hipLaunchKernelGGL((k_reduce_partials<0>), dim3(k), dim3(KSG_BLOCK), 0, c->stream, c->d_partial, nb, d_out);
   KSG_HIP(hipGetLastError());
   return KSG_OK;
 }
 
 /* ------------------------------------------------------------------------ */
-/* multvec: y = beta*y + X q  (tall-skinny GEMV), q pre-scaled by alpha        */
+/* multvec: y = beta*y + X q  (tall-skinny GEMV), q pre-scaled by alpha,       */
+/* optionally fused with the next Gram-Schmidt reduction                      */
 /* ------------------------------------------------------------------------ */
 struct ksg_qarg { double v[KSG_QMAX]; };
 
-template <int VEC>
-__global__ __launch_bounds__(KSG_BLOCK) void k_multvec(const double *__restrict__ X, int64_t ld, int k,
-                                                        ksg_qarg q, double beta, double *__restrict__ y,
-                                                        int64_t n) {
-  const int64_t stride = (int64_t)gridDim.x * KSG_BLOCK;
-  int64_t p = (int64_t)blockIdx.x * KSG_BLOCK + threadIdx.x;
-  if (VEC == 2) {
-    const int64_t npair = n >> 1;
-    double2 *y2 = reinterpret_cast<double2 *>(y);
-    for (; p < npair; p += stride) {
-      double2 a = make_double2(0.0, 0.0);
-      if (beta != 0.0) { const double2 yv = y2[p]; a.x = beta * yv.x; a.y = beta * yv.y; }
-      const double2 *xp = reinterpret_cast<const double2 *>(X) + p;
-      const int64_t ld2 = ld >> 1;
-      int j = 0;
-      for (; j + 8 <= k; j += 8) {
-        double2 xv[8];
+/* NW waves per workgroup; wave w owns columns [w*CW, w*CW+CW) of the k <= NW*CW
+ * active ones and all waves walk the same 64 row pairs per step.  Each wave forms
+ * its partial row sums from registers, the partials meet in LDS (double
+ * buffered: one barrier per step) and every wave rebuilds the updated row
+ * y' = beta*y + X q from them in the same fixed order; wave 0 stores it.  With
+ * `dots` set the wave then multiplies the columns it still holds in registers by
+ * y': when the kernel ends, partial[] holds the pieces of X^T y' (k values) and of
+ * y'^T y' (slot k) -- the coefficients the next classical Gram-Schmidt pass would
+ * otherwise re-read the whole basis for.  Requires 16-byte aligned columns. */
+template <int CW, int NC, int NW>
+__device__ __forceinline__ void mvd_rows(const double2 *const (&col)[CW], const double (&qc)[CW], double beta,
+                                         double2 *__restrict__ y2, int64_t npair, int w, int lane, int dots,
+                                         double2 (&sm)[2][NW][64], double (&acc)[CW], double &self) {
+  const int64_t step = (int64_t)gridDim.x * 64;
+  int buf = 0;
+  /* the trip count is the same for every thread of the workgroup: the barrier inside is safe */
+  for (int64_t p0 = (int64_t)blockIdx.x * 64; p0 < npair; p0 += step, buf ^= 1) {
+    const int64_t p = p0 + lane;
+    const bool live = p < npair;
+    const int64_t pc = live ? p : npair - 1;
+    double2 xv[NC > 0 ? NC : 1];
 #pragma unroll
-        for (int u = 0; u < 8; u++) xv[u] = xp[(int64_t)(j + u) * ld2];
+    for (int c = 0; c < NC; c++) xv[c] = ld_stream(col[c] + pc);
+    double2 yv = make_double2(0.0, 0.0);
+    if (beta != 0.0) yv = y2[pc];
 #pragma unroll
-        for (int u = 0; u < 8; u++) { a.x = fma(xv[u].x, q.v[j + u], a.x); a.y = fma(xv[u].y, q.v[j + u], a.y); }
-      }
-      for (; j < k; j++) {
-        const double2 xv = xp[(int64_t)j * ld2];
-        a.x = fma(xv.x, q.v[j], a.x); a.y = fma(xv.y, q.v[j], a.y);
-      }
-      y2[p] = a;
-    }
-    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
-      const int64_t r = n - 1;
-      double a = (beta != 0.0) ? beta * y[r] : 0.0;
-      for (int j = 0; j < k; j++) a = fma(X[(int64_t)j * ld + r], q.v[j], a);
-      y[r] = a;
-    }
-  } else {
-    for (; p < n; p += stride) {
-      double a = (beta != 0.0) ? beta * y[p] : 0.0;
-      int j = 0;
-      for (; j + 8 <= k; j += 8) {
-        double xv[8];
+    for (int c = 0; c < NC; c++) ld_fence(xv[c]);
+    double2 a = make_double2(0.0, 0.0);
 #pragma unroll
-        for (int u = 0; u < 8; u++) xv[u] = X[(int64_t)(j + u) * ld + p];
+    for (int c = 0; c < NC; c++) axpy_acc(xv[c], qc[c], a);
+    sm[buf][w][lane] = a;
+    __syncthreads();
+    double2 s = sm[buf][0][lane];
 #pragma unroll
-        for (int u = 0; u < 8; u++) a = fma(xv[u], q.v[j + u], a);
-      }
-      for (; j < k; j++) a = fma(X[(int64_t)j * ld + p], q.v[j], a);
-      y[p] = a;
+    for (int ww = 1; ww < NW; ww++) { const double2 t = sm[buf][ww][lane]; s.x += t.x; s.y += t.y; }
+    double2 r;
+    r.x = fma(beta, yv.x, s.x);
+    r.y = fma(beta, yv.y, s.y);
+    if (!live) r = make_double2(0.0, 0.0);
+    if (w == 0 && live) y2[p] = r;
+    if (dots) {
+      if (w == 0) self = dot_acc(r, r, self);
+#pragma unroll
+      for (int c = 0; c < NC; c++) acc[c] = dot_acc(xv[c], r, acc[c]);
     }
   }
 }
 
+template <int CW, int NW>
+__global__ __launch_bounds__(64 * NW) void k_multvec_dot(const double *__restrict__ X, int64_t ld, int k, ksg_qarg q,
+                                                          double beta, double *__restrict__ y, int64_t n,
+                                                          double *__restrict__ partial, int nb, int dots) {
+  __shared__ double2 sm[2][NW][64];
+  const int lane = threadIdx.x & 63;
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  int c0, kc;                                   /* wave-uniform; kc may be 0 */
+  group_columns(w, k, CW, NW, c0, kc);
+  const double2 *col[CW];
+  double qc[CW];
+#pragma unroll
+  for (int c = 0; c < CW; c++) {
+    col[c] = reinterpret_cast<const double2 *>(X + (int64_t)(c < kc ? c0 + c : 0) * ld);
+    qc[c] = c < kc ? q.v[c0 + c] : 0.0;
+  }
+  double acc[CW];
+#pragma unroll
+  for (int c = 0; c < CW; c++) acc[c] = 0.0;
+  double self = 0.0;
+  double2 *y2 = reinterpret_cast<double2 *>(y);
+  if (kc == CW) mvd_rows<CW, CW, NW>(col, qc, beta, y2, n >> 1, w, lane, dots, sm, acc, self);
+  else          mvd_rows<CW, CW - 1, NW>(col, qc, beta, y2, n >> 1, w, lane, dots, sm, acc, self);
+  if ((n & 1) && blockIdx.x == 0) {               /* last row of an odd-length vector */
+    const int64_t rl = n - 1;
+    double t = (beta != 0.0) ? beta * y[rl] : 0.0;
+    for (int j = 0; j < k; j++) t = fma(X[(int64_t)j * ld + rl], q.v[j], t);
+    __syncthreads();                              /* every thread has read y[rl] */
+    if (threadIdx.x == 0) { y[rl] = t; self = fma(t, t, self); }
+    if (lane == 0) {
+#pragma unroll
+      for (int c = 0; c < CW; c++)
+        if (c < kc) acc[c] = fma(X[(int64_t)(c0 + c) * ld + rl], t, acc[c]);
+    }
+  }
+  if (dots) {
+#pragma unroll
+    for (int c = 0; c < CW; c++) {
+      const double v = wave_sum(acc[c]);
+      if (lane == 0 && c < kc) partial[(int64_t)(c0 + c) * nb + blockIdx.x] = v;
+    }
+    if (w == 0) {
+      self = wave_sum(self);
+      if (lane == 0) partial[(int64_t)k * nb + blockIdx.x] = self;
+    }
+  }
+}
+
+/* fallback for vectors that are not 16-byte aligned */
+__global__ __launch_bounds__(KSG_BLOCK) void k_multvec_scalar(const double *__restrict__ X, int64_t ld, int k, ksg_qarg q,
+                                                               double beta, double *__restrict__ y, int64_t n) {
+  const int64_t stride = (int64_t)gridDim.x * KSG_BLOCK;
+  for (int64_t p = (int64_t)blockIdx.x * KSG_BLOCK + threadIdx.x; p < n; p += stride) {
+    double a = (beta != 0.0) ? beta * y[p] : 0.0;
+    int j = 0;
+    for (; j + 8 <= k; j += 8) {
+      double xv[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) xv[u] = ld_stream(X + (int64_t)(j + u) * ld + p);
+#pragma unroll
+      for (int u = 0; u < 8; u++) a = fma(xv[u], q.v[j + u], a);
+    }
+    for (; j < k; j++) a = fma(X[(int64_t)j * ld + p], q.v[j], a);
+    y[p] = a;
+  }
+}
+
+template <int NW>
+static void launch_mvd(int CW, int nb, hipStream_t st, const double *X, int64_t ld, int k, const ksg_qarg &q, double beta,
+                       double *y, int64_t n, double *partial, int dots) {
+#define KSG_MVD_CASE(C) case C: hipLaunchKernelGGL((k_multvec_dot<C, NW>), dim3(nb), dim3(64 * NW), 0, st, X, ld, k, q, beta, y, n, partial, nb, dots); break;
+  switch (CW) {
+    KSG_MVD_CASE(1) KSG_MVD_CASE(2) KSG_MVD_CASE(3) KSG_MVD_CASE(4) KSG_MVD_CASE(5) KSG_MVD_CASE(6)
+    KSG_MVD_CASE(7) KSG_MVD_CASE(8) KSG_MVD_CASE(9) KSG_MVD_CASE(10) KSG_MVD_CASE(11) KSG_MVD_CASE(12)
+    KSG_MVD_CASE(13) KSG_MVD_CASE(14) KSG_MVD_CASE(15)
+    default: hipLaunchKernelGGL((k_multvec_dot<16, NW>), dim3(nb), dim3(64 * NW), 0, st, X, ld, k, q, beta, y, n, partial, nb, dots); break;
+  }
+#undef KSG_MVD_CASE
+}
+
+/* y = beta*y + alpha * X(:,0:k) q.  With d_dots != NULL (and k <= KSG_QMAX, aligned
+ * vectors) the launch also leaves X^T y' and y'^T y' (k+1 values) in d_dots and
+ * *fused is set; otherwise *fused is cleared. */
 static int launch_multvec(ksg_ctx c, const double *X, int64_t ld, int k, const double *q_host,
-                          double alpha, double beta, double *y, int64_t n) {
+                          double alpha, double beta, double *y, int64_t n, double *d_dots, int *fused) {
+  if (fused) *fused = 0;
   if (n <= 0) return KSG_OK;
   const bool vec2 = aligned16(X) && aligned16(y) && (ld % 2 == 0);
-  const int nb = ksg_grid_for(vec2 ? (n + 1) / 2 : n);
+  const bool dots = d_dots && vec2 && k <= KSG_QMAX;
+  int nb = (int)((((vec2 ? (n + 1) / 2 : n)) + 63) / 64);
+  if (nb > c->mv_grid) nb = c->mv_grid;
+  if (dots) KSG_CHK(ksg_ensure_partial(c, (size_t)(k + 1) * nb));
   int done = 0;
   do {   /* at most KSG_QMAX coefficients travel with one launch */
     const int kk = (k - done < KSG_QMAX) ? k - done : KSG_QMAX;
@@ -211,10 +338,18 @@ static int launch_multvec(ksg_ctx c, const double *X, int64_t ld, int k, const d
     for (int j = 0; j < kk; j++) q.v[j] = alpha * q_host[done + j];
     const double b = done ? 1.0 : beta;
     const double *Xc = X + (int64_t)done * ld;
-    if (vec2) hipLaunchKernelGGL((k_multvec<2>), dim3(nb), dim3(KSG_BLOCK), 0, c->stream, Xc, ld, kk, q, b, y, n);
-    else      hipLaunchKernelGGL((k_multvec<1>), dim3(nb), dim3(KSG_BLOCK), 0, c->stream, Xc, ld, kk, q, b, y, n);
+    if (vec2) {
+      if (kk <= 64) launch_mvd<4>((kk + 3) / 4, nb, c->stream, Xc, ld, kk, q, b, y, n, c->d_partial, dots ? 1 : 0);
+      else          launch_mvd<8>((kk + 7) / 8, nb, c->stream, Xc, ld, kk, q, b, y, n, c->d_partial, dots ? 1 : 0);
+    } else {
+      hipLaunchKernelGGL(k_multvec_scalar, dim3(ksg_grid_for(n)), dim3(KSG_BLOCK), 0, c->stream, Xc, ld, kk, q, b, y, n);
+    }
     done += kk;
   } while (done < k);
+  if (dots) {
+    hipLaunchKernelGGL((k_reduce_partials<0>), dim3(k + 1), dim3(KSG_BLOCK), 0, c->stream, c->d_partial, nb, d_dots);
+    if (fused) *fused = 1;
+  }
   KSG_HIP(hipGetLastError());
   return KSG_OK;
 }
@@ -453,6 +588,7 @@ extern "C" int ksg_bv_destroy(ksg_bv bv) {
   hipSetDevice(bv->ctx->device);
   hipStreamSynchronize(bv->ctx->stream);
   hipFree(bv->d);
+  bv->ctx->gen++;
   delete bv;
   return KSG_OK;
 }
@@ -474,6 +610,7 @@ extern "C" int ksg_bv_resize(ksg_bv bv, int m, int copy) {
   }
   KSG_HIP(hipStreamSynchronize(c->stream));
   KSG_HIP(hipFree(bv->d));
+  c->gen++;
   bv->d = nd;
   bv->m = m;
   if (bv->k > m) bv->k = m;
@@ -502,6 +639,15 @@ extern "C" double *ksg_bv_column(ksg_bv bv, int j) {
   return bv_col(bv, j);
 }
 
+/* The reduction a fused multvec left behind is reused when nothing has been written
+ * through the library since and the request is exactly the one it anticipated: the
+ * same active columns followed by the updated column itself. */
+static bool spec_matches(ksg_ctx c, ksg_bv X, const double *y, int k) {
+  const ksg_spec &sp = c->spec;
+  return sp.valid && sp.gen == c->gen && sp.X == bv_col(X, X->l) && sp.ld == X->ld && sp.n == X->n &&
+         sp.k + 1 == k && sp.y == y && y == sp.X + (int64_t)sp.k * sp.ld;
+}
+
 static int dotvec_impl(ksg_bv X, const double *y, double *q_host, int global) {
   BV_CHECK(X, "ksg_bv_dotvec");
   if (!y || !q_host) KSG_FAIL(KSG_ERR_ARG, "ksg_bv_dotvec: NULL vector");
@@ -510,11 +656,19 @@ static int dotvec_impl(ksg_bv X, const double *y, double *q_host, int global) {
   const int k = X->k - X->l;
   if (k == 0) return KSG_OK;
   if (k > KSG_RED_MAX) KSG_FAIL(KSG_ERR_UNSUPPORTED, "ksg_bv_dotvec: %d active columns", k);
-  KSG_CHK(ksg_op_begin(c, KSG_EV_DOTVEC));
-  KSG_CHK(ksg_launch_dotvec(c, bv_col(X, X->l), X->ld, k, y, X->n, c->d_red));
-  KSG_CHK(ksg_op_end(c, KSG_EV_DOTVEC, 8.0 * (double)X->n * (k + 1), 2.0 * (double)X->n * k));
-  if (global) return ksg_comm_allreduce(c, c->d_red, q_host, k, 0);
-  KSG_HIP(hipMemcpyAsync(c->h_red, c->d_red, (size_t)k * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  double *d_res = c->d_red;
+  if (spec_matches(c, X, y, k)) {
+    KSG_HIP(hipSetDevice(c->device));
+    d_res = c->d_spec;                      /* no kernel, no bytes: computed by the preceding multvec */
+    c->stats.calls[KSG_EV_DOTVEC_FUSED] += 1;
+    c->stats.flops[KSG_EV_DOTVEC_FUSED] += 2.0 * (double)X->n * k;
+  } else {
+    KSG_CHK(ksg_op_begin(c, KSG_EV_DOTVEC));
+    KSG_CHK(ksg_launch_dotvec(c, bv_col(X, X->l), X->ld, k, y, X->n, c->d_red));
+    KSG_CHK(ksg_op_end(c, KSG_EV_DOTVEC, 8.0 * (double)X->n * (k + 1), 2.0 * (double)X->n * k));
+  }
+  if (global) return ksg_comm_allreduce(c, d_res, q_host, k, 0);
+  KSG_HIP(hipMemcpyAsync(c->h_red, d_res, (size_t)k * sizeof(double), hipMemcpyDeviceToHost, c->stream));
   KSG_HIP(hipStreamSynchronize(c->stream));
   memcpy(q_host, c->h_red, (size_t)k * sizeof(double));
   return KSG_OK;
@@ -530,6 +684,7 @@ extern "C" int ksg_bv_multvec(ksg_bv X, double alpha, double beta, double *y, co
   ksg_ctx c = X->ctx;
   const int k = X->k - X->l;
   KSG_CHK(ksg_op_begin(c, KSG_EV_MULTVEC));
+  int fused = 0;
   if (k == 0) {
     if (beta != 1.0 && X->n > 0) {
       if (beta == 0.0) hipLaunchKernelGGL(k_set_cols, dim3(ksg_grid_for(X->n), 1), dim3(KSG_BLOCK), 0, c->stream, y, X->ld, X->n, 0.0);
@@ -537,9 +692,25 @@ extern "C" int ksg_bv_multvec(ksg_bv X, double alpha, double beta, double *y, co
     }
   } else {
     if (!q_host) KSG_FAIL(KSG_ERR_ARG, "ksg_bv_multvec: NULL coefficients");
-    KSG_CHK(launch_multvec(c, bv_col(X, X->l), X->ld, k, q_host, alpha, beta, y, X->n));
+    /* y is the column right after the active ones: the update step of Gram-Schmidt on that
+     * column (bvorthog.c:262-268); the next thing asked for will be its products with the
+     * same columns and with itself, so they are formed while the columns are in registers */
+    const bool gs_column = c->fuse_dots && X->k < X->m && y == bv_col(X, X->k);
+    KSG_CHK(launch_multvec(c, bv_col(X, X->l), X->ld, k, q_host, alpha, beta, y, X->n, gs_column ? c->d_spec : NULL, &fused));
   }
-  KSG_CHK(ksg_op_end(c, KSG_EV_MULTVEC, 8.0 * (double)X->n * (k + 2), 2.0 * (double)X->n * k));
+  KSG_CHK(ksg_op_end(c, KSG_EV_MULTVEC, 8.0 * (double)X->n * (k + 2), (fused ? 4.0 : 2.0) * (double)X->n * k));
+  if (fused) {
+    ksg_spec &sp = c->spec;
+    sp.valid = true; sp.gen = c->gen; sp.X = bv_col(X, X->l); sp.ld = X->ld; sp.n = X->n; sp.k = k; sp.y = y;
+  }
+  return KSG_OK;
+}
+
+/* Column storage was modified by something other than this library (a kernel of the
+ * caller writing through a pointer obtained from ksg_bv_column, a host copy, ...). */
+extern "C" int ksg_bv_touch(ksg_bv bv) {
+  BV_CHECK(bv, "ksg_bv_touch");
+  bv->ctx->gen++;
   return KSG_OK;
 }
 
@@ -738,7 +909,7 @@ extern "C" int ksg_bv_mult(ksg_bv Y, double alpha, double beta, ksg_bv X, const 
   /* column by column through the GEMV kernel: Y(:,ly+j) = beta*Y(:,ly+j) + alpha*X*Q(lx:kx, ly+j) */
   for (int j = 0; j < ky; j++)
     KSG_CHK(launch_multvec(c, bv_col(X, X->l), X->ld, kx, Q + (size_t)(Y->l + j) * ldq + X->l, alpha, beta,
-                           bv_col(Y, Y->l + j), Y->n));
+                           bv_col(Y, Y->l + j), Y->n, NULL, NULL));
   KSG_CHK(ksg_op_end(c, KSG_EV_MULT, 8.0 * (double)Y->n * ky * (kx + 2), 2.0 * (double)Y->n * ky * kx));
   return KSG_OK;
 }

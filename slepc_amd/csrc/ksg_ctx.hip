@@ -33,6 +33,12 @@ extern "C" int ksg_ctx_create(int device, ksg_ctx *out) {
   c->d_q = NULL; c->q_cap = 0;
   c->d_work = NULL; c->work_cap = 0;
   c->timing = 0;
+  c->d_spec = NULL;
+  c->spec.valid = false;
+  c->gen = 0;
+  c->fuse_dots = 1;
+  c->dot_grid = KSG_DOT_GRID;
+  c->mv_grid = KSG_MV_GRID;
   memset(&c->stats, 0, sizeof(c->stats));
   KSG_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
   KSG_HIP(hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking));
@@ -40,6 +46,7 @@ extern "C" int ksg_ctx_create(int device, ksg_ctx *out) {
   KSG_HIP(hipEventCreateWithFlags(&c->ev_halo_done, hipEventDisableTiming));
   KSG_HIP(hipMalloc(&c->d_red, KSG_RED_MAX * sizeof(double)));
   KSG_HIP(hipHostMalloc(&c->h_red, KSG_RED_MAX * sizeof(double), hipHostMallocDefault));
+  KSG_HIP(hipMalloc(&c->d_spec, (KSG_QMAX + 1) * sizeof(double)));
   *out = c;
   return KSG_OK;
 }
@@ -53,6 +60,19 @@ extern "C" int ksg_ctx_sync(ksg_ctx c) {
 }
 
 extern "C" void *ksg_ctx_stream(ksg_ctx c) { return c ? (void *)c->stream : NULL; }
+
+extern "C" int ksg_ctx_set_option(ksg_ctx c, int option, int value) {
+  if (!c) KSG_FAIL(KSG_ERR_ARG, "ksg_ctx_set_option: NULL context");
+  switch (option) {
+    case KSG_OPT_FUSE_DOTS: c->fuse_dots = value ? 1 : 0; c->spec.valid = false; return KSG_OK;
+    case KSG_OPT_DOT_GRID:
+    case KSG_OPT_MV_GRID:
+      if (value < 1 || value > 65535) KSG_FAIL(KSG_ERR_ARG, "ksg_ctx_set_option: grid %d out of range", value);
+      (option == KSG_OPT_DOT_GRID ? c->dot_grid : c->mv_grid) = value;
+      return KSG_OK;
+    default: KSG_FAIL(KSG_ERR_ARG, "ksg_ctx_set_option: unknown option %d", option);
+  }
+}
 
 int ksg_comm_destroy(ksg_ctx c);
 
@@ -68,6 +88,7 @@ extern "C" int ksg_ctx_destroy(ksg_ctx c) {
   if (c->d_q) hipFree(c->d_q);
   if (c->d_work) hipFree(c->d_work);
   hipFree(c->d_red);
+  hipFree(c->d_spec);
   hipHostFree(c->h_red);
   hipEventDestroy(c->ev_x_ready);
   hipEventDestroy(c->ev_halo_done);
@@ -114,6 +135,8 @@ static int drain_timers(ksg_ctx c) {
 
 int ksg_op_begin(ksg_ctx c, int ev) {
   KSG_HIP(hipSetDevice(c->device));
+  /* everything but the pure reductions may write vectors */
+  if (ev != KSG_EV_DOTVEC && ev != KSG_EV_NORM && ev != KSG_EV_DOT) c->gen++;
   if (c->timing) {
     ksg_timer t; t.ev = ev;
     KSG_CHK(get_event(c, &t.e0));

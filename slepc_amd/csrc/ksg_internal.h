@@ -14,6 +14,8 @@
 #define KSG_MAXGRID    2048         /* 256 CUs x 8 workgroups: grid-stride beyond   */
 #define KSG_QMAX       128          /* coefficients passed by value to one launch   */
 #define KSG_RED_MAX    8192         /* doubles in the reduction buffers             */
+#define KSG_DOT_GRID   256          /* row workgroups of the read-only reductions   */
+#define KSG_MV_GRID    1024         /* row workgroups of the GEMV (read + write)    */
 
 void ksg_set_error(const char *fmt, ...);
 
@@ -26,6 +28,15 @@ void ksg_set_error(const char *fmt, ...);
 enum { KSG_COMM_NONE = 0, KSG_COMM_RCCL = 1, KSG_COMM_CALLBACKS = 2 };
 
 struct ksg_timer { hipEvent_t e0, e1; int ev; };
+
+/* Result of the reduction a fused multvec computed ahead of the request for it. */
+struct ksg_spec {
+  bool valid;
+  uint64_t gen;              /* value of ksg_ctx_s::gen when it was produced */
+  const double *X, *y;       /* first active column, updated vector */
+  int64_t ld, n;
+  int k;                     /* active columns; d_spec holds k+1 values */
+};
 
 struct ksg_ctx_s {
   int device;
@@ -40,6 +51,11 @@ struct ksg_ctx_s {
   size_t q_cap;
   double *d_work;            /* scratch panel for out-of-place fallbacks */
   size_t work_cap;
+  double *d_spec;            /* KSG_QMAX+1 doubles: reduction left by a fused multvec */
+  ksg_spec spec;
+  uint64_t gen;              /* bumped by every operation that may write device data */
+  int fuse_dots;             /* 0 disables the fused reduction (ksg_ctx_set_option) */
+  int dot_grid, mv_grid;     /* row workgroups of the reduction / update kernels */
   /* communicator */
   int comm_kind, rank, nranks, cb_on_device;
   void *rccl_comm;

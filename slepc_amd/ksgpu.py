@@ -24,9 +24,9 @@ class KsgError(RuntimeError):
 
 class Stats(C.Structure):
     EVENTS = ["dotvec", "multvec", "multinplace", "scale", "norm", "copy", "matmult",
-              "mult", "dot", "vecops"]
-    _fields_ = [("calls", c_i64 * 10), ("bytes", C.c_double * 10), ("flops", C.c_double * 10),
-                ("ms", C.c_double * 10)]
+              "mult", "dot", "vecops", "dotvec_fused"]
+    _fields_ = [("calls", c_i64 * 11), ("bytes", C.c_double * 11), ("flops", C.c_double * 11),
+                ("ms", C.c_double * 11)]
 
     def as_dict(self):
         return {ev: {"calls": int(self.calls[i]), "bytes": float(self.bytes[i]),
@@ -44,6 +44,7 @@ SIGNATURES = {
     "ksg_ctx_destroy": (C.c_int, [C.c_void_p]),
     "ksg_ctx_sync": (C.c_int, [C.c_void_p]),
     "ksg_ctx_stream": (C.c_void_p, [C.c_void_p]),
+    "ksg_ctx_set_option": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "ksg_last_error": (C.c_char_p, []),
     "ksg_comm_unique_id": (C.c_int, [C.c_void_p]),
     "ksg_ctx_comm_init_rccl": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
@@ -68,6 +69,7 @@ SIGNATURES = {
     "ksg_bv_sizes": (C.c_int, [C.c_void_p, C.POINTER(c_i64), C.POINTER(c_i64), C.POINTER(C.c_int),
                                C.POINTER(c_i64)]),
     "ksg_bv_column": (C.c_void_p, [C.c_void_p, C.c_int]),
+    "ksg_bv_touch": (C.c_int, [C.c_void_p]),
     "ksg_bv_dotvec": (C.c_int, [C.c_void_p, C.c_void_p, c_dp]),
     "ksg_bv_dotvec_local": (C.c_int, [C.c_void_p, C.c_void_p, c_dp]),
     "ksg_bv_multvec": (C.c_int, [C.c_void_p, C.c_double, C.c_double, C.c_void_p, c_dp]),
@@ -118,6 +120,11 @@ def check(rc):
 
 def _dptr(a):
     return a.ctypes.data_as(c_dp)
+
+
+OPT_FUSE_DOTS = 1
+OPT_DOT_GRID = 2
+OPT_MV_GRID = 3
 
 
 class Context:
@@ -229,6 +236,9 @@ class Context:
     def stats_reset(self):
         check(self.lib.ksg_stats_reset(self.h))
 
+    def set_option(self, option, value):
+        check(self.lib.ksg_ctx_set_option(self.h, option, int(value)))
+
     def enable_timing(self, on=True):
         check(self.lib.ksg_stats_enable_timing(self.h, 1 if on else 0))
 
@@ -259,6 +269,9 @@ class DeviceBV:
         if not p:
             raise KsgError(1, self.lib.ksg_last_error().decode())
         return p
+
+    def touch(self):
+        check(self.lib.ksg_bv_touch(self.h))
 
     def set_column(self, j, arr):
         self.ctx.upload(self.column(j), arr)

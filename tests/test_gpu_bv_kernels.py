@@ -167,3 +167,78 @@ def test_bv_mult_dot_general(gpu_ctx):
     assert _close(M, Mo, scale=n)
     X.destroy()
     Y.destroy()
+
+
+@pytest.mark.parametrize("n,m,k", [(1000, 5, 4), (4097, 34, 33), (100003, 65, 64), (2, 3, 2), (1, 3, 2),
+                                    (63, 18, 9), (50001, 130, 128), (200000, 101, 100), (30000, 140, 139)])
+def test_multvec_fused_dots(gpu_ctx, n, m, k):
+    """The Gram-Schmidt update of column k by columns [0,k) also leaves the next
+    pass's reduction behind; the dotvec that follows must return it (same values as
+    a fresh reduction, to rounding) and anything that writes in between must
+    invalidate it."""
+    G, O, rng = _mk(gpu_ctx, n, m, seed=3)
+    q = rng.standard_normal(k) * 0.1
+    G.set_active(0, k)
+    O.set_active_columns(0, k)
+    ycol = O.col(k)
+    gpu_ctx.stats_reset()
+    G.multvec(-1.0, 1.0, G.column(k), q)
+    O.op_multvec(-1.0, 1.0, ycol, q)
+    assert _close(G.get_column(k), ycol, scale=10 * np.sqrt(k))
+    G.set_active(0, k + 1)
+    O.set_active_columns(0, k + 1)
+    got = G.dotvec(G.column(k))
+    want = np.zeros(k + 1)
+    O.op_dotvec(ycol, want)
+    st = gpu_ctx.stats()
+    fused = k <= 128
+    assert st["dotvec_fused"]["calls"] == (1 if fused else 0)
+    assert st["dotvec"]["calls"] == (0 if fused else 1)
+    assert _close(got, want, scale=n)
+    # a second identical request is still valid
+    assert _close(G.dotvec(G.column(k)), want, scale=n)
+    # different active range: a real reduction
+    G.set_active(1 if k > 1 else 0, k + 1)
+    O.set_active_columns(1 if k > 1 else 0, k + 1)
+    want2 = np.zeros(k + 1 - (1 if k > 1 else 0))
+    O.op_dotvec(ycol, want2)
+    assert _close(G.dotvec(G.column(k)), want2, scale=n)
+    # a write in between invalidates
+    G.set_active(0, k)
+    O.set_active_columns(0, k)
+    G.multvec(-1.0, 1.0, G.column(k), q)
+    O.op_multvec(-1.0, 1.0, ycol, q)
+    G.scale(k, 0.5)
+    ycol *= 0.5
+    G.set_active(0, k + 1)
+    O.set_active_columns(0, k + 1)
+    before = gpu_ctx.stats()["dotvec_fused"]["calls"]
+    O.op_dotvec(ycol, want)
+    assert _close(G.dotvec(G.column(k)), want, scale=n)
+    assert gpu_ctx.stats()["dotvec_fused"]["calls"] == before
+    # a foreign write announced with touch() invalidates too
+    G.set_active(0, k)
+    G.multvec(-1.0, 1.0, G.column(k), q)
+    G.touch()
+    G.set_active(0, k + 1)
+    G.dotvec(G.column(k))
+    assert gpu_ctx.stats()["dotvec_fused"]["calls"] == before
+    G.destroy()
+
+
+def test_fused_dots_option_off(gpu_ctx):
+    from slepc_amd import ksgpu
+    G, O, rng = _mk(gpu_ctx, 5000, 9, seed=4)
+    q = rng.standard_normal(8)
+    gpu_ctx.set_option(ksgpu.OPT_FUSE_DOTS, 0)
+    try:
+        gpu_ctx.stats_reset()
+        G.set_active(0, 8)
+        G.multvec(-1.0, 1.0, G.column(8), q)
+        G.set_active(0, 9)
+        G.dotvec(G.column(8))
+        st = gpu_ctx.stats()
+        assert st["dotvec_fused"]["calls"] == 0 and st["dotvec"]["calls"] == 1
+    finally:
+        gpu_ctx.set_option(ksgpu.OPT_FUSE_DOTS, 1)
+    G.destroy()
