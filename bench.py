@@ -81,6 +81,11 @@ def main():
     ap.add_argument("--cpu-restarts", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--to-convergence", action="store_true",
+                    help="time the whole EPSSolve until nev eigenpairs converge (or --max-restarts); "
+                         "--steps/--warmup are ignored and `steps` reports the restarts it took")
+    ap.add_argument("--max-restarts", type=int, default=20000)
+    ap.add_argument("--tol", type=float, default=0.0, help="0 = the default 1e-8")
     args = ap.parse_args()
 
     from slepc_amd import dist as kdist, ksgpu, kseps as K, matgen
@@ -115,14 +120,20 @@ def main():
     del rp, ci, va
 
     W, Ksteps = args.warmup, args.steps
+    if args.to_convergence:
+        W, Ksteps = 0, args.max_restarts
     eps = K.EPS(ctx.h)
     eps.set_operators(A)
     eps.set_problem_type(K.EPS_HEP)
     eps.set_dimensions(args.nev)
-    eps.set_tolerances(0.0, W + Ksteps)          # default tol 1e-8; stop after W+K restarts
+    eps.set_tolerances(args.tol, W + Ksteps)     # default tol 1e-8; stop after W+K restarts
     eps.set_bv_type("hip")
 
     marks = {}
+    # Profiler markers: a 3-element k_vec_set (one workgroup) is launched right before
+    # and right after the timed region, so that a rocprofv3 trace of this command can be
+    # cut to exactly the launches the JSON line reports (tools/prof_summary.py).
+    marker = ctx.vec_alloc(8)
 
     def fence():
         ctx.sync()
@@ -131,39 +142,56 @@ def main():
         ctx.sync()
         return time.perf_counter()
 
+    def end_timed():
+        marks["t1"] = fence()
+        marks["stats"] = ctx.stats()
+        marks["c1"] = eps.counters()
+        ctx.enable_timing(False)
+        ctx.vec_set(marker, 1.0, 3)
+
     def monitor(its, nconv, eigr, eigi, errest, nest):
         if its == W:
             fence()
+            ctx.vec_set(marker, 0.0, 3)
             ctx.stats_reset()
             if not args.no_kernel_timing:
                 ctx.enable_timing(True)
             marks["t0"] = fence()
             marks["c0"] = eps.counters()
         elif its == W + Ksteps:
-            marks["t1"] = fence()
-            marks["stats"] = ctx.stats()
-            marks["c1"] = eps.counters()
-            ctx.enable_timing(False)
+            end_timed()
+        if args.to_convergence and rank == 0 and its % 50 == 0:
+            print("restart %d: nconv %d, first unconverged %.12g errest %.3e, %.1f s" % (
+                its, nconv, float(eigr[min(nconv, nest - 1)]), float(errest[min(nconv, nest - 1)]),
+                time.perf_counter() - marks.get("t0", time.perf_counter())), file=sys.stderr, flush=True)
         marks["last"] = (its, nconv, float(eigr[0]), float(errest[0]))
 
     eps.set_monitor(monitor)
     if W == 0:
         monitor(0, 0, np.zeros(1), np.zeros(1), np.zeros(1), 1)
     eps.solve()
+    if args.to_convergence and "t1" not in marks:
+        # converged before the restart bound: the timed region ends with the solve
+        Ksteps = eps.its
+        end_timed()
     if "t1" not in marks:
         raise SystemExit("the solver stopped after %d restarts, before the %d requested" % (eps.its, W + Ksteps))
 
     dt = marks["t1"] - marks["t0"]
     st = marks["stats"]
     nbytes = sum(v["bytes"] for v in st.values())
+    # what the reference's op sequence would have moved: there every dotvec is a pass over
+    # the basis, 8 n (k+1) bytes, also the ones the fused multvec answered here for free
+    fz = st["dotvec_fused"]
+    unfused = nbytes + 4.0 * fz["flops"] + 8.0 * (row1 - row0) * fz["calls"]
     if dist:
         import torch
         t = torch.tensor([dt], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t[0])
-        b = torch.tensor([nbytes], dtype=torch.float64)
+        b = torch.tensor([nbytes, unfused], dtype=torch.float64)
         dist.all_reduce(b, op=dist.ReduceOp.SUM)
-        nbytes = float(b[0])
+        nbytes, unfused = float(b[0]), float(b[1])
     value = nbytes / dt / 1e9
 
     if rank == 0:
@@ -177,12 +205,26 @@ def main():
                   key=lambda e: st[e]["ms"], default=None)
         roofline = None
         if dom:
+            kname = {"dotvec": "k_dotw", "multvec": "k_multvec_dot", "matmult": "k_spmv_tiles"}[dom]
             ach = st[dom]["bytes"] / st[dom]["ms"] / 1e6
-            roofline = {"bound": "hbm", "kernel": {"dotvec": "k_dotvec", "multvec": "k_multvec", "matmult": "k_spmv_tiles"}[dom],
+            per_launch = st[dom]["bytes"] / st[dom]["calls"]
+            roofline = {"bound": "hbm", "kernel": kname,
                         "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
                         "traffic": None, "launches": st[dom]["calls"],
                         "avg_launch_ms": round(st[dom]["ms"] / st[dom]["calls"], 4),
-                        "bytes_per_launch": round(st[dom]["bytes"] / st[dom]["calls"])}
+                        "bytes_per_launch": round(per_launch)}
+            # HBM bytes per launch from the PMC passes (cannot be collected from inside this
+            # process: they come from the committed rocprofv3 summary of this same command)
+            try:
+                with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+                    pmc = json.load(f)
+                k = pmc["kernels"].get(kname)
+                if k and k.get("traffic_over_algorithmic") and pmc.get("workload") == wname:
+                    roofline["traffic"] = round(k["traffic_over_algorithmic"] * per_launch)
+                    roofline["traffic_source"] = "profiles/pmc_traffic.json: measured traffic/algorithmic = %.4f over %d launches" % (
+                        k["traffic_over_algorithmic"], k["launches"])
+            except (OSError, ValueError, KeyError):
+                pass
         mv = marks["c1"][0] - marks["c0"][0]
         gs = marks["c1"][1] - marks["c0"][1]
         out = {
@@ -196,9 +238,13 @@ def main():
                        "transport": args.transport if size > 1 else "none",
                        "spmv_per_step": mv / Ksteps, "gs_passes_per_step": gs / Ksteps},
             "frac_of_hbm_peak": round(value / (HBM_PEAK_GBS * size), 4),
+            "unfused_model_GBps": round(unfused / dt / 1e9, 1),
             "roofline": roofline, "kernels": kernels,
-            "solver_state": {"restarts": eps.its, "last": marks["last"]},
+            "solver_state": {"restarts": eps.its, "last": marks["last"], "nconv": eps.nconv,
+                             "reason": eps.reason},
         }
+        if args.to_convergence:
+            out["time_to_convergence_s"] = round(dt, 3)
         if not args.no_cpu_baseline and size == 1:
             threads = min(16, os.cpu_count() or 1)
             out["cpu_baseline"] = cpu_baseline(args.cpu_grid, args.nev, args.cpu_restarts, threads)

@@ -1,0 +1,21 @@
+#!/bin/bash
+# Profiles `bench.py` on the GPU box: kernel trace + stats, then FETCH_SIZE and
+# WRITE_SIZE in separate counter passes.  Usage: tools/profile_bench.sh <tag>
+set -e -o pipefail
+TAG=${1:-r01}
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$R/gpurun_out/prof_$TAG
+mkdir -p $OUT
+export TMPDIR=/tmp
+cd /tmp
+ARGS="--steps 5 --warmup 2 --no-cpu-baseline"
+timeout -k 10 400 rocprofv3 --kernel-trace --stats -d $OUT -o trace --output-format csv -- python3 $R/bench.py $ARGS > $OUT/bench_trace.json 2> $OUT/trace.err
+timeout -s KILL 400 rocprofv3 --pmc FETCH_SIZE -d $OUT -o fetch --output-format csv -- python3 $R/bench.py $ARGS > $OUT/bench_fetch.json 2> $OUT/fetch.err
+timeout -s KILL 400 rocprofv3 --pmc WRITE_SIZE -d $OUT -o write --output-format csv -- python3 $R/bench.py $ARGS > $OUT/bench_write.json 2> $OUT/write.err
+cd $R
+python3 tools/prof_summary.py trace $OUT/trace_kernel_trace.csv > $OUT/summary_trace.txt
+python3 tools/prof_summary.py pmc $OUT/fetch_counter_collection.csv $OUT/write_counter_collection.csv $OUT/bench_trace.json > $OUT/summary_pmc.txt
+rm -f $OUT/fetch_counter_collection.csv $OUT/write_counter_collection.csv
+tail -3 $OUT/bench_trace.json | cut -c1-600
+cat $OUT/summary_trace.txt | head -20
+cat $OUT/summary_pmc.txt | head -20

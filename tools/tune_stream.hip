@@ -189,7 +189,7 @@ __global__ __launch_bounds__(256) void k_mvdot(const double *__restrict__ X, int
     r.x = beta * yv.x + ((s0.x + s1.x) + (s2.x + s3.x));
     r.y = beta * yv.y + ((s0.y + s1.y) + (s2.y + s3.y));
     if (!live) { r.x = 0; r.y = 0; }
-    if (w == 0) { if (live && DIAG != 1) { if (DIAG == 5) { ((double2 *)g_yout)[p] = r; } else if (DIAG == 3 || DIAG == 6) { __builtin_nontemporal_store(r.x, &y2[p].x); __builtin_nontemporal_store(r.y, &y2[p].y); } else y2[p] = r; } self = fma(r.x, r.x, self); self = fma(r.y, r.y, self); }
+    if (w == 0) { if (live && DIAG != 1 && !(DIAG == 7 && ((p0 / step) & 3)) && !(DIAG == 8 && ((p0 / step) & 15))) { if (DIAG == 5) { ((double2 *)g_yout)[p] = r; } else if (DIAG == 9) { ((double2 *)g_yout)[p & 0xFFFF] = r; } else if (DIAG == 10) { typedef double v2d __attribute__((ext_vector_type(2))); v2d rv = {r.x, r.y}; asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" :: "v"(&y2[p]), "v"(rv) : "memory"); } else if (DIAG == 3 || DIAG == 6) { __builtin_nontemporal_store(r.x, &y2[p].x); __builtin_nontemporal_store(r.y, &y2[p].y); } else y2[p] = r; } self = fma(r.x, r.x, self); self = fma(r.y, r.y, self); }
 #pragma unroll
     for (int c = 0; c < CW; c++) { acc[c] = fma(xv[c].x, r.x, acc[c]); acc[c] = fma(xv[c].y, r.y, acc[c]); }
   }
@@ -262,6 +262,147 @@ __global__ __launch_bounds__(320) void k_mvdot5(const double *__restrict__ X, in
     self = wave_sum(self);
     if (lane == 0) partial[(int64_t)k * nb + blockIdx.x] = self;
   }
+}
+
+// fused kernel, contiguous row range per block, y' staged in LDS and written T KiB at a time
+template <int CW, int T, bool STORE>
+__global__ __launch_bounds__(256) void k_mvdot_b(const double *__restrict__ X, int64_t ld, int k, qarg q, double beta,
+                                                 double *__restrict__ y, int64_t n, double *__restrict__ partial, int nb) {
+  __shared__ double2 sm[2][4][64];
+  __shared__ double2 ybuf[T][64];
+  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int c0 = w * CW;
+  const int kc = max(0, min(CW, k - c0));
+  const double2 *col[CW];
+  double qc[CW];
+#pragma unroll
+  for (int c = 0; c < CW; c++) {
+    const int cc = c0 + (c < kc ? c : (kc > 0 ? kc - 1 : -c0));
+    col[c] = (const double2 *)(X + (int64_t)cc * ld);
+    qc[c] = c < kc ? q.v[c0 + c] : 0.0;
+  }
+  double acc[CW];
+#pragma unroll
+  for (int c = 0; c < CW; c++) acc[c] = 0.0;
+  double self = 0.0;
+  const int64_t npair = n >> 1;
+  double2 *y2 = (double2 *)y;
+  const int64_t chunk = (((npair + gridDim.x - 1) / gridDim.x) + 63) / 64 * 64;
+  const int64_t pbeg = (int64_t)blockIdx.x * chunk;
+  const int64_t pend = min(npair, pbeg + chunk);
+  int buf = 0, it = 0;
+  for (int64_t p0 = pbeg; p0 < pend; p0 += 64, buf ^= 1, it++) {
+    const int64_t p = p0 + lane;
+    const bool live = p < pend;
+    const int64_t pc = live ? p : pend - 1;
+    double2 xv[CW];
+#pragma unroll
+    for (int c = 0; c < CW; c++) xv[c] = ld2<true>(col[c] + pc);
+    double2 yv = y2[pc];
+#pragma unroll
+    for (int c = 0; c < CW; c++) asm volatile("" : "+v"(xv[c].x), "+v"(xv[c].y));
+    double2 a = make_double2(0, 0);
+#pragma unroll
+    for (int c = 0; c < CW; c++) { a.x = fma(xv[c].x, qc[c], a.x); a.y = fma(xv[c].y, qc[c], a.y); }
+    sm[buf][w][lane] = a;
+    __syncthreads();
+    const double2 s0 = sm[buf][0][lane], s1 = sm[buf][1][lane], s2 = sm[buf][2][lane], s3 = sm[buf][3][lane];
+    double2 r;
+    r.x = beta * yv.x + ((s0.x + s1.x) + (s2.x + s3.x));
+    r.y = beta * yv.y + ((s0.y + s1.y) + (s2.y + s3.y));
+    if (!live) { r.x = 0; r.y = 0; }
+    if (w == 0) {
+      if (T == 1) { if (live && STORE) y2[p] = r; }
+      else ybuf[it % T][lane] = r;
+      self = fma(r.x, r.x, self); self = fma(r.y, r.y, self);
+    }
+#pragma unroll
+    for (int c = 0; c < CW; c++) { acc[c] = fma(xv[c].x, r.x, acc[c]); acc[c] = fma(xv[c].y, r.y, acc[c]); }
+    if (T > 1 && ((it % T) == T - 1 || p0 + 64 >= pend)) {
+      __syncthreads();
+      const int cnt = (it % T) + 1;
+      const int64_t base = p0 - (int64_t)(cnt - 1) * 64;
+      if (STORE)
+        for (int e = threadIdx.x; e < cnt * 64; e += 256)
+          if (base + e < pend) y2[base + e] = ybuf[e >> 6][e & 63];
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < CW; c++) { const double v = wave_sum(acc[c]); if (lane == 0 && c < kc) partial[(int64_t)(c0 + c) * nb + blockIdx.x] = v; }
+  self = wave_sum(self);
+  if (w == 0 && lane == 0) partial[(int64_t)k * nb + blockIdx.x] = self;
+}
+
+// fused kernel, one big workgroup per CU: 4 column groups x RG row groups, y' staged in LDS
+// and written in bursts of T*RG KiB
+template <int CW, int RG, int T>
+__global__ __launch_bounds__(256 * RG) void k_mvdot_c(const double *__restrict__ X, int64_t ld, int k, qarg q, double beta,
+                                                      double *__restrict__ y, int64_t n, double *__restrict__ partial, int nb) {
+  extern __shared__ double2 dyn[];
+  double2 (*sm)[RG][4][64] = (double2 (*)[RG][4][64])dyn;                 // [2][RG][4][64]
+  double2 *ybuf = dyn + 2 * RG * 4 * 64;                                   // [T][RG*64]
+  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int cg = w & 3, rg = w >> 2;
+  const int c0 = cg * CW;
+  const int kc = max(0, min(CW, k - c0));
+  const double2 *col[CW];
+  double qc[CW];
+#pragma unroll
+  for (int c = 0; c < CW; c++) {
+    const int cc = c0 + (c < kc ? c : (kc > 0 ? kc - 1 : -c0));
+    col[c] = (const double2 *)(X + (int64_t)cc * ld);
+    qc[c] = c < kc ? q.v[c0 + c] : 0.0;
+  }
+  double acc[CW];
+#pragma unroll
+  for (int c = 0; c < CW; c++) acc[c] = 0.0;
+  double self = 0.0;
+  const int64_t npair = n >> 1;
+  double2 *y2 = (double2 *)y;
+  constexpr int RW = RG * 64;
+  const int64_t chunk = (((npair + gridDim.x - 1) / gridDim.x) + RW - 1) / RW * RW;
+  const int64_t pbeg = (int64_t)blockIdx.x * chunk;
+  const int64_t pend = min(npair, pbeg + chunk);
+  int buf = 0, it = 0;
+  for (int64_t p0 = pbeg; p0 < pend; p0 += RW, buf ^= 1, it++) {
+    const int64_t p = p0 + rg * 64 + lane;
+    const bool live = p < pend;
+    const int64_t pc = live ? p : pend - 1;
+    double2 xv[CW];
+#pragma unroll
+    for (int c = 0; c < CW; c++) xv[c] = ld2<true>(col[c] + pc);
+    double2 yv = y2[pc];
+#pragma unroll
+    for (int c = 0; c < CW; c++) asm volatile("" : "+v"(xv[c].x), "+v"(xv[c].y));
+    double2 a = make_double2(0, 0);
+#pragma unroll
+    for (int c = 0; c < CW; c++) { a.x = fma(xv[c].x, qc[c], a.x); a.y = fma(xv[c].y, qc[c], a.y); }
+    sm[buf][rg][cg][lane] = a;
+    __syncthreads();
+    const double2 s0 = sm[buf][rg][0][lane], s1 = sm[buf][rg][1][lane], s2 = sm[buf][rg][2][lane], s3 = sm[buf][rg][3][lane];
+    double2 r;
+    r.x = beta * yv.x + ((s0.x + s1.x) + (s2.x + s3.x));
+    r.y = beta * yv.y + ((s0.y + s1.y) + (s2.y + s3.y));
+    if (!live) { r.x = 0; r.y = 0; }
+    if (cg == 0) {
+      ybuf[(it % T) * RW + rg * 64 + lane] = r;
+      self = fma(r.x, r.x, self); self = fma(r.y, r.y, self);
+    }
+#pragma unroll
+    for (int c = 0; c < CW; c++) { acc[c] = fma(xv[c].x, r.x, acc[c]); acc[c] = fma(xv[c].y, r.y, acc[c]); }
+    if ((it % T) == T - 1 || p0 + RW >= pend) {
+      __syncthreads();
+      const int cnt = (it % T) + 1;
+      const int64_t base = p0 - (int64_t)(cnt - 1) * RW;
+      for (int e = threadIdx.x; e < cnt * RW; e += 256 * RG)
+        if (base + e < pend) y2[base + e] = ybuf[e];
+    }
+  }
+  // (partials: one slot per (block,row group))
+#pragma unroll
+  for (int c = 0; c < CW; c++) { const double v = wave_sum(acc[c]); if (lane == 0 && c < kc) partial[(int64_t)(c0 + c) * nb + blockIdx.x * RG + rg] = v; }
+  self = wave_sum(self);
+  if (cg == 0 && lane == 0) partial[(int64_t)k * nb + blockIdx.x * RG + rg] = self;
 }
 
 template <class F> float timeit(F f, int reps) {
@@ -340,6 +481,15 @@ int main(int argc, char **argv) {
     printf("mvdot diag=%d grid=%5d : %8.3f ms %8.1f GB/s\n", D, G, ms, 8.0 * n * (64 + 2) / ms / 1e6); }
     { double *yo; CK(hipMalloc(&yo, 8 * n)); CK(hipMemcpyToSymbol(HIP_SYMBOL(g_yout), &yo, sizeof(yo))); }
     for (int g : {512, 1024, 2048}) { MVDD(0, g) MVDD(1, g) }
+#define MVC(RG, TT, G) { size_t lds = sizeof(double2) * (2 * RG * 4 * 64 + (size_t)TT * RG * 64); \
+    CK(hipFuncSetAttribute((const void *)k_mvdot_c<16, RG, TT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+    float ms = timeit([&] { hipLaunchKernelGGL((k_mvdot_c<16, RG, TT>), dim3(G), dim3(256 * RG), lds, 0, X, ld, 64, q, 1.0, y, n, part, G * RG); }, reps); \
+    printf("mvdot_c RG=%d T=%3d lds=%6zu grid=%5d : %8.3f ms %8.1f GB/s\n", RG, TT, lds, G, ms, 8.0 * n * (64 + 2) / ms / 1e6); }
+    for (int g : {256, 512}) { MVC(4, 1, g) MVC(4, 8, g) MVC(4, 24, g) MVC(2, 8, g) MVC(2, 32, g) MVC(2, 64, g) }
+    MVC(1, 8, 1024) MVC(1, 32, 1024) MVC(3, 32, 256) MVC(3, 40, 256)
+#define MVB(TT, ST, G) { float ms = timeit([&] { hipLaunchKernelGGL((k_mvdot_b<16, TT, ST>), dim3(G), dim3(256), 0, 0, X, ld, 64, q, 1.0, y, n, part, G); }, reps); \
+    printf("mvdot_b T=%2d store=%d grid=%5d : %8.3f ms %8.1f GB/s\n", TT, (int)ST, G, ms, 8.0 * n * (64 + 2) / ms / 1e6); }
+    for (int g : {512, 1024, 2048}) { MVB(1, false, g) MVB(1, true, g) MVB(8, true, g) MVB(32, true, g) }
     for (int g : {512, 768, 1024, 1536, 2048}) { float ms = timeit([&] { hipLaunchKernelGGL((k_mvdot5<16, true>), dim3(g), dim3(320), 0, 0, X, ld, 64, q, 1.0, y, n, part, g); }, reps);
       printf("mvdot5 grid=%5d : %8.3f ms %8.1f GB/s\n", g, ms, 8.0 * n * (64 + 2) / ms / 1e6); }
     for (int g : {256, 384, 512, 768, 1024, 1280, 1536, 1792, 2048, 3072}) { DOTWK(13, 5, g, 65) }
