@@ -56,9 +56,14 @@ void *ksg_ctx_stream(ksg_ctx ctx);
  * and with itself, and the ksg_bv_dotvec that asks for them next costs no pass over
  * the basis.  No counterpart in the reference (its two GEMVs are separate BLAS calls,
  * bvblas.c:65-76,242-266); results are the same reductions in a different order.
+ * KSG_OPT_LAZY_UPDATE (default 1): when the column before needed a refinement pass, the
+ * first Gram-Schmidt update of a column only forms those products; its result is written
+ * together with the second update (one pass over the basis, one store of the column) or,
+ * if no second update follows, by the next call that touches device data.  The stored
+ * values are bit for bit those of two separate updates.
  * KSG_OPT_DOT_GRID / KSG_OPT_MV_GRID: upper bound on the workgroups along the rows of
  * the reduction (default 256, one per CU) and update (default 1024) kernels. */
-enum { KSG_OPT_FUSE_DOTS = 1, KSG_OPT_DOT_GRID = 2, KSG_OPT_MV_GRID = 3 };
+enum { KSG_OPT_FUSE_DOTS = 1, KSG_OPT_DOT_GRID = 2, KSG_OPT_MV_GRID = 3, KSG_OPT_LAZY_UPDATE = 4 };
 int ksg_ctx_set_option(ksg_ctx ctx, int option, int value);
 const char *ksg_last_error(void);
 
@@ -106,7 +111,10 @@ int ksg_bv_destroy(ksg_bv bv);                                                  
 int ksg_bv_resize(ksg_bv bv, int m, int copy);                                  /* BVResize_Svec svec.c:280 */
 int ksg_bv_set_active(ksg_bv bv, int l, int k);
 int ksg_bv_sizes(ksg_bv bv, int64_t *n_local, int64_t *N, int *m, int64_t *ld);
-/* Device address of column j (BVGetColumn_Svec, svec.c:312-324: pv+(nc+j)*n). */
+/* Device address of column j (BVGetColumn_Svec, svec.c:312-324: pv+(nc+j)*n).  Every
+ * entry point of this library sees the column up to date; code of the caller that reads
+ * it through this pointer on its own (a kernel on ksg_ctx_stream, hipMemcpy) must call
+ * ksg_ctx_sync first, which also applies an update deferred under KSG_OPT_LAZY_UPDATE. */
 double *ksg_bv_column(ksg_bv bv, int j);
 /* Must be called after column storage was written by anything other than this
  * library (a kernel of the caller, hipMemcpy) through a pointer from ksg_bv_column:

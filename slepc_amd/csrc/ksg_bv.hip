@@ -199,11 +199,16 @@ struct ksg_qarg { double v[KSG_QMAX]; };
  * `dots` set the wave then multiplies the columns it still holds in registers by
  * y': when the kernel ends, partial[] holds the pieces of X^T y' (k values) and of
  * y'^T y' (slot k) -- the coefficients the next classical Gram-Schmidt pass would
- * otherwise re-read the whole basis for.  Requires 16-byte aligned columns. */
-template <int CW, int NC, int NW>
-__device__ __forceinline__ void mvd_rows(const double2 *const (&col)[CW], const double (&qc)[CW], double beta,
-                                         double2 *__restrict__ y2, int64_t npair, int w, int lane, int dots,
-                                         double2 (&sm)[2][NW][64], double (&acc)[CW], double &self) {
+ * otherwise re-read the whole basis for.  With `store` clear y' is not written
+ * (only its products are wanted for now).  TWO applies two updates in one pass,
+ * y'' = beta2*(beta*y + X q) + X q2, each rounded exactly as two separate
+ * launches would round it.  Requires 16-byte aligned columns. */
+template <int CW, int NC, int NW, bool TWO>
+__device__ __forceinline__ void mvd_rows(const double2 *const (&col)[CW], const double (&qc)[CW],
+                                         const double (&qd)[TWO ? CW : 1], double beta, double beta2,
+                                         double2 *__restrict__ y2, int64_t npair, int w, int lane, int dots, int store,
+                                         double2 (&sm)[2][NW][64], double2 (&sm2)[TWO ? 2 : 1][TWO ? NW : 1][TWO ? 64 : 1],
+                                         double (&acc)[CW], double &self) {
   const int64_t step = (int64_t)gridDim.x * 64;
   int buf = 0;
   /* the trip count is the same for every thread of the workgroup: the barrier inside is safe */
@@ -222,6 +227,12 @@ __device__ __forceinline__ void mvd_rows(const double2 *const (&col)[CW], const 
 #pragma unroll
     for (int c = 0; c < NC; c++) axpy_acc(xv[c], qc[c], a);
     sm[buf][w][lane] = a;
+    if (TWO) {
+      double2 a2 = make_double2(0.0, 0.0);
+#pragma unroll
+      for (int c = 0; c < NC; c++) axpy_acc(xv[c], qd[c], a2);
+      sm2[buf][w][lane] = a2;
+    }
     __syncthreads();
     double2 s = sm[buf][0][lane];
 #pragma unroll
@@ -229,8 +240,15 @@ __device__ __forceinline__ void mvd_rows(const double2 *const (&col)[CW], const 
     double2 r;
     r.x = fma(beta, yv.x, s.x);
     r.y = fma(beta, yv.y, s.y);
+    if (TWO) {
+      double2 s2 = sm2[buf][0][lane];
+#pragma unroll
+      for (int ww = 1; ww < NW; ww++) { const double2 t = sm2[buf][ww][lane]; s2.x += t.x; s2.y += t.y; }
+      r.x = fma(beta2, r.x, s2.x);
+      r.y = fma(beta2, r.y, s2.y);
+    }
     if (!live) r = make_double2(0.0, 0.0);
-    if (w == 0 && live) y2[p] = r;
+    if (w == 0 && live && store) y2[p] = r;
     if (dots) {
       if (w == 0) self = dot_acc(r, r, self);
 #pragma unroll
@@ -239,35 +257,42 @@ __device__ __forceinline__ void mvd_rows(const double2 *const (&col)[CW], const 
   }
 }
 
-template <int CW, int NW>
+template <int CW, int NW, bool TWO>
 __global__ __launch_bounds__(64 * NW) void k_multvec_dot(const double *__restrict__ X, int64_t ld, int k, ksg_qarg q,
-                                                          double beta, double *__restrict__ y, int64_t n,
-                                                          double *__restrict__ partial, int nb, int dots) {
+                                                          double beta, ksg_qarg q2, double beta2,
+                                                          double *__restrict__ y, int64_t n,
+                                                          double *__restrict__ partial, int nb, int dots, int store) {
   __shared__ double2 sm[2][NW][64];
+  __shared__ double2 sm2[TWO ? 2 : 1][TWO ? NW : 1][TWO ? 64 : 1];
   const int lane = threadIdx.x & 63;
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   int c0, kc;                                   /* wave-uniform; kc may be 0 */
   group_columns(w, k, CW, NW, c0, kc);
   const double2 *col[CW];
-  double qc[CW];
+  double qc[CW], qd[TWO ? CW : 1];
 #pragma unroll
   for (int c = 0; c < CW; c++) {
     col[c] = reinterpret_cast<const double2 *>(X + (int64_t)(c < kc ? c0 + c : 0) * ld);
     qc[c] = c < kc ? q.v[c0 + c] : 0.0;
+    if (TWO) qd[c] = c < kc ? q2.v[c0 + c] : 0.0;
   }
   double acc[CW];
 #pragma unroll
   for (int c = 0; c < CW; c++) acc[c] = 0.0;
   double self = 0.0;
   double2 *y2 = reinterpret_cast<double2 *>(y);
-  if (kc == CW) mvd_rows<CW, CW, NW>(col, qc, beta, y2, n >> 1, w, lane, dots, sm, acc, self);
-  else          mvd_rows<CW, CW - 1, NW>(col, qc, beta, y2, n >> 1, w, lane, dots, sm, acc, self);
+  if (kc == CW) mvd_rows<CW, CW, NW, TWO>(col, qc, qd, beta, beta2, y2, n >> 1, w, lane, dots, store, sm, sm2, acc, self);
+  else          mvd_rows<CW, CW - 1, NW, TWO>(col, qc, qd, beta, beta2, y2, n >> 1, w, lane, dots, store, sm, sm2, acc, self);
   if ((n & 1) && blockIdx.x == 0) {               /* last row of an odd-length vector */
     const int64_t rl = n - 1;
     double t = (beta != 0.0) ? beta * y[rl] : 0.0;
     for (int j = 0; j < k; j++) t = fma(X[(int64_t)j * ld + rl], q.v[j], t);
+    if (TWO) {
+      t *= beta2;
+      for (int j = 0; j < k; j++) t = fma(X[(int64_t)j * ld + rl], q2.v[j], t);
+    }
     __syncthreads();                              /* every thread has read y[rl] */
-    if (threadIdx.x == 0) { y[rl] = t; self = fma(t, t, self); }
+    if (threadIdx.x == 0) { if (store) y[rl] = t; self = fma(t, t, self); }
     if (lane == 0) {
 #pragma unroll
       for (int c = 0; c < CW; c++)
@@ -306,17 +331,36 @@ __global__ __launch_bounds__(KSG_BLOCK) void k_multvec_scalar(const double *__re
   }
 }
 
-template <int NW>
+template <int NW, bool TWO>
 static void launch_mvd(int CW, int nb, hipStream_t st, const double *X, int64_t ld, int k, const ksg_qarg &q, double beta,
-                       double *y, int64_t n, double *partial, int dots) {
-#define KSG_MVD_CASE(C) case C: hipLaunchKernelGGL((k_multvec_dot<C, NW>), dim3(nb), dim3(64 * NW), 0, st, X, ld, k, q, beta, y, n, partial, nb, dots); break;
+                       const ksg_qarg &q2, double beta2, double *y, int64_t n, double *partial, int dots, int store) {
+#define KSG_MVD_CASE(C) case C: hipLaunchKernelGGL((k_multvec_dot<C, NW, TWO>), dim3(nb), dim3(64 * NW), 0, st, X, ld, k, q, beta, q2, beta2, y, n, partial, nb, dots, store); break;
   switch (CW) {
     KSG_MVD_CASE(1) KSG_MVD_CASE(2) KSG_MVD_CASE(3) KSG_MVD_CASE(4) KSG_MVD_CASE(5) KSG_MVD_CASE(6)
     KSG_MVD_CASE(7) KSG_MVD_CASE(8) KSG_MVD_CASE(9) KSG_MVD_CASE(10) KSG_MVD_CASE(11) KSG_MVD_CASE(12)
     KSG_MVD_CASE(13) KSG_MVD_CASE(14) KSG_MVD_CASE(15)
-    default: hipLaunchKernelGGL((k_multvec_dot<16, NW>), dim3(nb), dim3(64 * NW), 0, st, X, ld, k, q, beta, y, n, partial, nb, dots); break;
+    default: hipLaunchKernelGGL((k_multvec_dot<16, NW, TWO>), dim3(nb), dim3(64 * NW), 0, st, X, ld, k, q, beta, q2, beta2, y, n, partial, nb, dots, store); break;
   }
 #undef KSG_MVD_CASE
+}
+
+static inline bool mv_vec2(const double *X, int64_t ld, const double *y) { return aligned16(X) && aligned16(y) && (ld % 2 == 0); }
+static inline int mv_grid(ksg_ctx c, int64_t n) {
+  int64_t nb = ((n + 1) / 2 + 63) / 64;
+  return (int)(nb > c->mv_grid ? c->mv_grid : nb);
+}
+
+/* One launch of the fused kernel on k <= 64 aligned columns with pre-scaled coefficients:
+ * y' = b1*y + X q1, then (q2 != NULL) y'' = b2*y' + X q2; dots -> d_dots (k+1 values). */
+static int launch_fused(ksg_ctx c, const double *X, int64_t ld, int k, const ksg_qarg &q1, double b1,
+                        const ksg_qarg *q2, double b2, double *y, int64_t n, double *d_dots, int store) {
+  const int nb = mv_grid(c, n);
+  if (d_dots) KSG_CHK(ksg_ensure_partial(c, (size_t)(k + 1) * nb));
+  if (q2) launch_mvd<4, true>((k + 3) / 4, nb, c->stream, X, ld, k, q1, b1, *q2, b2, y, n, c->d_partial, d_dots ? 1 : 0, store);
+  else    launch_mvd<4, false>((k + 3) / 4, nb, c->stream, X, ld, k, q1, b1, q1, 1.0, y, n, c->d_partial, d_dots ? 1 : 0, store);
+  if (d_dots) hipLaunchKernelGGL((k_reduce_partials<0>), dim3(k + 1), dim3(KSG_BLOCK), 0, c->stream, c->d_partial, nb, d_dots);
+  KSG_HIP(hipGetLastError());
+  return KSG_OK;
 }
 
 /* y = beta*y + alpha * X(:,0:k) q.  With d_dots != NULL (and k <= KSG_QMAX, aligned
@@ -326,10 +370,9 @@ static int launch_multvec(ksg_ctx c, const double *X, int64_t ld, int k, const d
                           double alpha, double beta, double *y, int64_t n, double *d_dots, int *fused) {
   if (fused) *fused = 0;
   if (n <= 0) return KSG_OK;
-  const bool vec2 = aligned16(X) && aligned16(y) && (ld % 2 == 0);
+  const bool vec2 = mv_vec2(X, ld, y);
   const bool dots = d_dots && vec2 && k <= KSG_QMAX;
-  int nb = (int)((((vec2 ? (n + 1) / 2 : n)) + 63) / 64);
-  if (nb > c->mv_grid) nb = c->mv_grid;
+  const int nb = vec2 ? mv_grid(c, n) : 0;
   if (dots) KSG_CHK(ksg_ensure_partial(c, (size_t)(k + 1) * nb));
   int done = 0;
   do {   /* at most KSG_QMAX coefficients travel with one launch */
@@ -339,8 +382,8 @@ static int launch_multvec(ksg_ctx c, const double *X, int64_t ld, int k, const d
     const double b = done ? 1.0 : beta;
     const double *Xc = X + (int64_t)done * ld;
     if (vec2) {
-      if (kk <= 64) launch_mvd<4>((kk + 3) / 4, nb, c->stream, Xc, ld, kk, q, b, y, n, c->d_partial, dots ? 1 : 0);
-      else          launch_mvd<8>((kk + 7) / 8, nb, c->stream, Xc, ld, kk, q, b, y, n, c->d_partial, dots ? 1 : 0);
+      if (kk <= 64) launch_mvd<4, false>((kk + 3) / 4, nb, c->stream, Xc, ld, kk, q, b, q, 1.0, y, n, c->d_partial, dots ? 1 : 0, 1);
+      else          launch_mvd<8, false>((kk + 7) / 8, nb, c->stream, Xc, ld, kk, q, b, q, 1.0, y, n, c->d_partial, dots ? 1 : 0, 1);
     } else {
       hipLaunchKernelGGL(k_multvec_scalar, dim3(ksg_grid_for(n)), dim3(KSG_BLOCK), 0, c->stream, Xc, ld, kk, q, b, y, n);
     }
@@ -586,6 +629,7 @@ extern "C" int ksg_bv_create(ksg_ctx ctx, int64_t n, int64_t N, int m, ksg_bv *o
 extern "C" int ksg_bv_destroy(ksg_bv bv) {
   if (!bv) return KSG_OK;
   hipSetDevice(bv->ctx->device);
+  ksg_flush_pending(bv->ctx);
   hipStreamSynchronize(bv->ctx->stream);
   hipFree(bv->d);
   bv->ctx->gen++;
@@ -599,6 +643,7 @@ extern "C" int ksg_bv_resize(ksg_bv bv, int m, int copy) {
   if (m == bv->m) return KSG_OK;
   ksg_ctx c = bv->ctx;
   KSG_HIP(hipSetDevice(c->device));
+  KSG_CHK(ksg_flush_pending(c));
   double *nd = NULL;
   const size_t bytes = (size_t)bv->ld * (bv->nc + m) * sizeof(double);
   hipError_t e = hipMalloc(&nd, bytes);
@@ -677,32 +722,88 @@ static int dotvec_impl(ksg_bv X, const double *y, double *q_host, int global) {
 extern "C" int ksg_bv_dotvec(ksg_bv X, const double *y, double *q) { return dotvec_impl(X, y, q, 1); }
 extern "C" int ksg_bv_dotvec_local(ksg_bv X, const double *y, double *q) { return dotvec_impl(X, y, q, 0); }
 
+/* Applies the deferred update on its own.  The values written are bit for bit the ones
+ * whose products ksg_spec holds: same kernel, same column groups, same order of sums. */
+int ksg_flush_pending(ksg_ctx c) {
+  if (!c->pend.active) return KSG_OK;
+  const ksg_pending pd = c->pend;
+  c->pend.active = false;
+  KSG_CHK(ksg_op_begin_ex(c, KSG_EV_MULTVEC, KSG_OPB_NOFLUSH | KSG_OPB_NOBUMP));
+  ksg_qarg q1;
+  for (int j = 0; j < pd.k; j++) q1.v[j] = pd.q[j];
+  KSG_CHK(launch_fused(c, pd.X, pd.ld, pd.k, q1, pd.beta, NULL, 1.0, pd.y, pd.n, NULL, 1));
+  KSG_CHK(ksg_op_end(c, KSG_EV_MULTVEC, 8.0 * (double)pd.n * (pd.k + 2), 2.0 * (double)pd.n * pd.k));
+  return KSG_OK;
+}
+
+static void set_spec(ksg_ctx c, ksg_bv X, int k, const double *y) {
+  ksg_spec &sp = c->spec;
+  sp.valid = true; sp.gen = c->gen; sp.X = bv_col(X, X->l); sp.ld = X->ld; sp.n = X->n; sp.k = k; sp.y = y;
+}
+
 extern "C" int ksg_bv_multvec(ksg_bv X, double alpha, double beta, double *y, const double *q_host) {
   BV_CHECK(X, "ksg_bv_multvec");
   if (!y) KSG_FAIL(KSG_ERR_ARG, "ksg_bv_multvec: NULL vector");
   KSG_CHK(check_active(X, "ksg_bv_multvec"));
   ksg_ctx c = X->ctx;
   const int k = X->k - X->l;
+  const double *Xb = bv_col(X, X->l);
+  const int64_t n = X->n;
+  if (k > 0 && !q_host) KSG_FAIL(KSG_ERR_ARG, "ksg_bv_multvec: NULL coefficients");
+  /* y is the column right after the active ones: the update step of Gram-Schmidt on that
+   * column (bvorthog.c:262-268); the next thing asked for will be its products with the
+   * same columns and with itself, so they are formed while the columns are in registers */
+  const bool gs_column = c->fuse_dots && k > 0 && n > 0 && X->k < X->m && y == bv_col(X, X->k);
+  const bool one_launch = gs_column && k <= 64 && mv_vec2(Xb, X->ld, y);
+
+  /* second update of a column whose first one is still pending: both in one pass */
+  if (c->pend.active && one_launch && c->pend.X == Xb && c->pend.y == y && c->pend.k == k &&
+      c->pend.ld == X->ld && c->pend.n == n) {
+    const ksg_pending pd = c->pend;
+    c->pend.active = false;
+    KSG_CHK(ksg_op_begin_ex(c, KSG_EV_MULTVEC, KSG_OPB_NOFLUSH));
+    ksg_qarg q1, q2;
+    for (int j = 0; j < k; j++) { q1.v[j] = pd.q[j]; q2.v[j] = alpha * q_host[j]; }
+    KSG_CHK(launch_fused(c, Xb, X->ld, k, q1, pd.beta, &q2, beta, y, n, c->d_spec, 1));
+    KSG_CHK(ksg_op_end(c, KSG_EV_MULTVEC, 8.0 * (double)n * (k + 2), 6.0 * (double)n * k));
+    set_spec(c, X, k, y);
+    c->gs_count++;
+    return KSG_OK;
+  }
+
   KSG_CHK(ksg_op_begin(c, KSG_EV_MULTVEC));
   int fused = 0;
+  double bytes = 8.0 * (double)n * (k + 2);
   if (k == 0) {
-    if (beta != 1.0 && X->n > 0) {
-      if (beta == 0.0) hipLaunchKernelGGL(k_set_cols, dim3(ksg_grid_for(X->n), 1), dim3(KSG_BLOCK), 0, c->stream, y, X->ld, X->n, 0.0);
-      else hipLaunchKernelGGL(k_axpby_cols, dim3(ksg_grid_for(X->n), 1), dim3(KSG_BLOCK), 0, c->stream, y, X->ld, y, X->ld, X->n, 0.0, beta);
+    if (beta != 1.0 && n > 0) {
+      if (beta == 0.0) hipLaunchKernelGGL(k_set_cols, dim3(ksg_grid_for(n), 1), dim3(KSG_BLOCK), 0, c->stream, y, X->ld, n, 0.0);
+      else hipLaunchKernelGGL(k_axpby_cols, dim3(ksg_grid_for(n), 1), dim3(KSG_BLOCK), 0, c->stream, y, X->ld, y, X->ld, n, 0.0, beta);
     }
   } else {
-    if (!q_host) KSG_FAIL(KSG_ERR_ARG, "ksg_bv_multvec: NULL coefficients");
-    /* y is the column right after the active ones: the update step of Gram-Schmidt on that
-     * column (bvorthog.c:262-268); the next thing asked for will be its products with the
-     * same columns and with itself, so they are formed while the columns are in registers */
-    const bool gs_column = c->fuse_dots && X->k < X->m && y == bv_col(X, X->k);
-    KSG_CHK(launch_multvec(c, bv_col(X, X->l), X->ld, k, q_host, alpha, beta, y, X->n, gs_column ? c->d_spec : NULL, &fused));
+    bool defer = false;
+    if (gs_column) {
+      /* how many updates in a row this column has had; a new column inherits the
+       * expectation that it will need as many passes as the one before it */
+      if (c->gs_y == y && c->gs_k == k) c->gs_count++;
+      else { c->gs_two_pass = c->gs_count >= 2; c->gs_y = y; c->gs_k = k; c->gs_count = 1; }
+      defer = c->lazy_update && one_launch && c->gs_count == 1 && c->gs_two_pass;
+    }
+    if (defer) {
+      /* products now, store later: the refinement pass that is expected to follow
+       * applies both updates while it streams the basis (one store of y instead of two) */
+      ksg_pending &pd = c->pend;
+      ksg_qarg q1;
+      for (int j = 0; j < k; j++) pd.q[j] = q1.v[j] = alpha * q_host[j];
+      KSG_CHK(launch_fused(c, Xb, X->ld, k, q1, beta, NULL, 1.0, y, n, c->d_spec, 0));
+      pd.X = Xb; pd.y = y; pd.ld = X->ld; pd.n = n; pd.k = k; pd.beta = beta; pd.active = true;
+      fused = 1;
+      bytes = 8.0 * (double)n * (k + 1);
+    } else {
+      KSG_CHK(launch_multvec(c, Xb, X->ld, k, q_host, alpha, beta, y, n, gs_column ? c->d_spec : NULL, &fused));
+    }
   }
-  KSG_CHK(ksg_op_end(c, KSG_EV_MULTVEC, 8.0 * (double)X->n * (k + 2), (fused ? 4.0 : 2.0) * (double)X->n * k));
-  if (fused) {
-    ksg_spec &sp = c->spec;
-    sp.valid = true; sp.gen = c->gen; sp.X = bv_col(X, X->l); sp.ld = X->ld; sp.n = X->n; sp.k = k; sp.y = y;
-  }
+  KSG_CHK(ksg_op_end(c, KSG_EV_MULTVEC, bytes, (fused ? 4.0 : 2.0) * (double)n * k));
+  if (fused) set_spec(c, X, k, y);
   return KSG_OK;
 }
 
@@ -710,6 +811,7 @@ extern "C" int ksg_bv_multvec(ksg_bv X, double alpha, double beta, double *y, co
  * caller writing through a pointer obtained from ksg_bv_column, a host copy, ...). */
 extern "C" int ksg_bv_touch(ksg_bv bv) {
   BV_CHECK(bv, "ksg_bv_touch");
+  KSG_CHK(ksg_flush_pending(bv->ctx));
   bv->ctx->gen++;
   return KSG_OK;
 }

@@ -37,6 +37,9 @@ extern "C" int ksg_ctx_create(int device, ksg_ctx *out) {
   c->spec.valid = false;
   c->gen = 0;
   c->fuse_dots = 1;
+  c->lazy_update = 1;
+  c->pend.active = false;
+  c->gs_y = NULL; c->gs_k = 0; c->gs_count = 0; c->gs_two_pass = 0;
   c->dot_grid = KSG_DOT_GRID;
   c->mv_grid = KSG_MV_GRID;
   memset(&c->stats, 0, sizeof(c->stats));
@@ -54,6 +57,7 @@ extern "C" int ksg_ctx_create(int device, ksg_ctx *out) {
 extern "C" int ksg_ctx_sync(ksg_ctx c) {
   if (!c) KSG_FAIL(KSG_ERR_ARG, "ksg_ctx_sync: NULL context");
   KSG_HIP(hipSetDevice(c->device));
+  KSG_CHK(ksg_flush_pending(c));
   KSG_HIP(hipStreamSynchronize(c->comm_stream));
   KSG_HIP(hipStreamSynchronize(c->stream));
   return KSG_OK;
@@ -64,7 +68,8 @@ extern "C" void *ksg_ctx_stream(ksg_ctx c) { return c ? (void *)c->stream : NULL
 extern "C" int ksg_ctx_set_option(ksg_ctx c, int option, int value) {
   if (!c) KSG_FAIL(KSG_ERR_ARG, "ksg_ctx_set_option: NULL context");
   switch (option) {
-    case KSG_OPT_FUSE_DOTS: c->fuse_dots = value ? 1 : 0; c->spec.valid = false; return KSG_OK;
+    case KSG_OPT_FUSE_DOTS: KSG_CHK(ksg_flush_pending(c)); c->fuse_dots = value ? 1 : 0; c->spec.valid = false; return KSG_OK;
+    case KSG_OPT_LAZY_UPDATE: KSG_CHK(ksg_flush_pending(c)); c->lazy_update = value ? 1 : 0; return KSG_OK;
     case KSG_OPT_DOT_GRID:
     case KSG_OPT_MV_GRID:
       if (value < 1 || value > 65535) KSG_FAIL(KSG_ERR_ARG, "ksg_ctx_set_option: grid %d out of range", value);
@@ -133,10 +138,13 @@ static int drain_timers(ksg_ctx c) {
   return KSG_OK;
 }
 
-int ksg_op_begin(ksg_ctx c, int ev) {
+int ksg_op_begin(ksg_ctx c, int ev) { return ksg_op_begin_ex(c, ev, 0); }
+
+int ksg_op_begin_ex(ksg_ctx c, int ev, int flags) {
   KSG_HIP(hipSetDevice(c->device));
+  if (!(flags & KSG_OPB_NOFLUSH) && c->pend.active) KSG_CHK(ksg_flush_pending(c));
   /* everything but the pure reductions may write vectors */
-  if (ev != KSG_EV_DOTVEC && ev != KSG_EV_NORM && ev != KSG_EV_DOT) c->gen++;
+  if (!(flags & KSG_OPB_NOBUMP) && ev != KSG_EV_DOTVEC && ev != KSG_EV_NORM && ev != KSG_EV_DOT) c->gen++;
   if (c->timing) {
     ksg_timer t; t.ev = ev;
     KSG_CHK(get_event(c, &t.e0));

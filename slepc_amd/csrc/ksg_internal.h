@@ -38,6 +38,19 @@ struct ksg_spec {
   int k;                     /* active columns; d_spec holds k+1 values */
 };
 
+/* A Gram-Schmidt update y <- beta*y + X q whose products are known (ksg_spec) but whose
+ * result has not been written yet: it is applied together with the next update of the
+ * same column, or on its own as soon as anything else needs device data. */
+struct ksg_pending {
+  bool active;
+  const double *X;
+  double *y;
+  int64_t ld, n;
+  int k;
+  double beta;
+  double q[64];              /* coefficients, already multiplied by alpha */
+};
+
 struct ksg_ctx_s {
   int device;
   hipStream_t stream;        /* compute */
@@ -56,6 +69,11 @@ struct ksg_ctx_s {
   uint64_t gen;              /* bumped by every operation that may write device data */
   int fuse_dots;             /* 0 disables the fused reduction (ksg_ctx_set_option) */
   int dot_grid, mv_grid;     /* row workgroups of the reduction / update kernels */
+  ksg_pending pend;
+  int lazy_update;           /* 0: never defer the store of a Gram-Schmidt update */
+  const double *gs_y;        /* column the last Gram-Schmidt update worked on ...  */
+  int gs_k, gs_count;        /* ... its width and how many updates it has had      */
+  int gs_two_pass;           /* the column before it needed a second pass          */
   /* communicator */
   int comm_kind, rank, nranks, cb_on_device;
   void *rccl_comm;
@@ -107,7 +125,11 @@ struct ksg_mat_s {
 };
 
 /* statistics / timing brackets */
-int ksg_op_begin(ksg_ctx ctx, int ev);
+int ksg_op_begin(ksg_ctx ctx, int ev);            /* applies a pending update first */
+#define KSG_OPB_NOFLUSH 1
+#define KSG_OPB_NOBUMP  2
+int ksg_op_begin_ex(ksg_ctx ctx, int ev, int flags);
+int ksg_flush_pending(ksg_ctx ctx);               /* ksg_bv.hip */
 int ksg_op_end(ksg_ctx ctx, int ev, double bytes, double flops);
 
 /* communicator primitives (ksg_comm.hip) */

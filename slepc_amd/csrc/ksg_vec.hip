@@ -58,6 +58,7 @@ extern "C" int ksg_vec_upload(ksg_ctx c, double *xd, const double *xh, int64_t n
   if (!n) return KSG_OK;
   if (!xd || !xh) KSG_FAIL(KSG_ERR_ARG, "ksg_vec_upload: NULL pointer");
   KSG_HIP(hipSetDevice(c->device));
+  KSG_CHK(ksg_flush_pending(c));
   c->gen++;
   KSG_HIP(hipMemcpyAsync(xd, xh, (size_t)n * sizeof(double), hipMemcpyHostToDevice, c->stream));
   KSG_HIP(hipStreamSynchronize(c->stream));
@@ -69,6 +70,7 @@ extern "C" int ksg_vec_download(ksg_ctx c, double *xh, const double *xd, int64_t
   if (!n) return KSG_OK;
   if (!xd || !xh) KSG_FAIL(KSG_ERR_ARG, "ksg_vec_download: NULL pointer");
   KSG_HIP(hipSetDevice(c->device));
+  KSG_CHK(ksg_flush_pending(c));
   KSG_HIP(hipMemcpyAsync(xh, xd, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
   KSG_HIP(hipStreamSynchronize(c->stream));
   return KSG_OK;

@@ -125,6 +125,7 @@ def _dptr(a):
 OPT_FUSE_DOTS = 1
 OPT_DOT_GRID = 2
 OPT_MV_GRID = 3
+OPT_LAZY_UPDATE = 4
 
 
 class Context:
@@ -291,6 +292,11 @@ class DeviceBV:
         fn = self.lib.ksg_bv_dotvec_local if local else self.lib.ksg_bv_dotvec
         check(fn(self.h, y_dev, _dptr(q)))
         return q[:self.k - self.l]
+
+    def dotvec_cols(self, l, k, j):
+        """Products of columns [l,k) with column j."""
+        self.set_active(l, k)
+        return self.dotvec(self.column(j))
 
     def multvec(self, alpha, beta, y_dev, q):
         q = np.ascontiguousarray(q, dtype=np.float64)

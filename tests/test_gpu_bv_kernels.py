@@ -242,3 +242,65 @@ def test_fused_dots_option_off(gpu_ctx):
     finally:
         gpu_ctx.set_option(ksgpu.OPT_FUSE_DOTS, 1)
     G.destroy()
+
+
+def _cgs2_columns(ctx, A, lazy, passes=2, peek=None):
+    """Classical Gram-Schmidt with `passes` passes per column, driven through the C ABI the
+    way BVOrthogonalizeGS drives the op table; returns the basis and the statistics."""
+    from slepc_amd import ksgpu
+    n, m = A.shape
+    ctx.set_option(ksgpu.OPT_LAZY_UPDATE, 1 if lazy else 0)
+    G = ksgpu.DeviceBV(ctx, n, m)
+    G.from_numpy(A)
+    ctx.stats_reset()
+    seen = {}
+    try:
+        G.scale(0, 1.0 / np.sqrt(G.dotvec_cols(0, 1, 0)[0]))
+        for j in range(1, m):
+            for p in range(passes):
+                c = G.dotvec_cols(0, j + 1, j)
+                G.set_active(0, j)
+                G.multvec(-1.0, 1.0, G.column(j), c[:j])
+                if peek is not None and p == 0 and j == peek:
+                    seen[j] = G.get_column(j)          # forces the deferred update out
+            c = G.dotvec_cols(0, j + 1, j)
+            G.scale(j, 1.0 / np.sqrt(c[j]))
+        out = G.to_numpy()
+        st = ctx.stats()
+    finally:
+        ctx.set_option(ksgpu.OPT_LAZY_UPDATE, 1)
+        G.destroy()
+    return out, st, seen
+
+
+@pytest.mark.parametrize("n,m", [(100003, 40), (4096, 66), (2, 2), (777, 5)])
+def test_lazy_update_bitwise(gpu_ctx, n, m):
+    """Deferring the store of the first update changes which kernel writes the column,
+    never a bit of what is written."""
+    rng = np.random.default_rng(11)
+    A = rng.standard_normal((n, m))
+    eager, st_e, _ = _cgs2_columns(gpu_ctx, A, lazy=False)
+    lazy, st_l, _ = _cgs2_columns(gpu_ctx, A, lazy=True)
+    assert np.array_equal(eager, lazy)
+    # the basis is orthonormal to working accuracy
+    if n > m:
+        assert np.abs(lazy.T @ lazy - np.eye(m)).max() < 1e-12
+    # from the third column on the first update of each column is deferred: fewer bytes
+    if m > 3:
+        assert st_l["multvec"]["bytes"] < st_e["multvec"]["bytes"]
+        assert st_l["multvec"]["calls"] == st_e["multvec"]["calls"]
+    assert st_l["dotvec_fused"]["calls"] == st_e["dotvec_fused"]["calls"]
+
+
+def test_lazy_update_flush_paths(gpu_ctx):
+    rng = np.random.default_rng(12)
+    A = rng.standard_normal((50001, 12))
+    eager, _, seen_e = _cgs2_columns(gpu_ctx, A, lazy=False, peek=7)
+    lazy, st, seen_l = _cgs2_columns(gpu_ctx, A, lazy=True, peek=7)
+    assert np.array_equal(seen_e[7], seen_l[7])
+    assert np.array_equal(eager, lazy)
+    # single-pass Gram-Schmidt: the prediction turns deferral off after one miss
+    e1, st_e1, _ = _cgs2_columns(gpu_ctx, A, lazy=False, passes=1)
+    l1, st_l1, _ = _cgs2_columns(gpu_ctx, A, lazy=True, passes=1)
+    assert np.array_equal(e1, l1)
+    assert st_l1["multvec"]["calls"] == st_e1["multvec"]["calls"]
