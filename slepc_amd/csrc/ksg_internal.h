@@ -101,6 +101,7 @@ struct ksg_csr_dev {
   int32_t *colidx;
   double *val;
   int32_t *tiles;    /* ntiles+1 row boundaries */
+  int64_t *tile_p;   /* rowptr at those boundaries */
   int64_t ntiles;
   int64_t n_stream, n_group, n_long;
 };

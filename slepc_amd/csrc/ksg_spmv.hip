@@ -21,15 +21,25 @@
 
 #include "ksg_internal.h"
 
-#define KSG_TILE_NNZ  2048     /* products held in LDS per workgroup (16 KiB)   */
-#define KSG_TILE_ROWS 256      /* rows per stream tile = threads per workgroup  */
+#ifndef KSG_TILE_NNZ
+#define KSG_TILE_NNZ  4096     /* products held in LDS per workgroup (32 KiB)   */
+#endif
+#ifndef KSG_TILE_ROWS
+#define KSG_TILE_ROWS 512      /* rows per stream tile: a multiple of the workgroup size */
+#endif
 
 __device__ __forceinline__ double wave_sum_width(double v, int width) {
   for (int off = width >> 1; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
   return v;
 }
 
+__device__ __forceinline__ void fence_d(double &v) { asm volatile("" : "+v"(v)); }
+__device__ __forceinline__ void fence_i(int32_t &v) { asm volatile("" : "+v"(v)); }
+
+#define KSG_TILE_PER_THREAD (KSG_TILE_NNZ / KSG_BLOCK)    /* entries of a tile per thread: 8 */
+
 __global__ __launch_bounds__(KSG_BLOCK) void k_spmv_tiles(const int32_t *__restrict__ tiles,
+                                                           const int64_t *__restrict__ tile_p,
                                                            const int64_t *__restrict__ rowptr,
                                                            const int32_t *__restrict__ colidx,
                                                            const double *__restrict__ val,
@@ -37,15 +47,18 @@ __global__ __launch_bounds__(KSG_BLOCK) void k_spmv_tiles(const int32_t *__restr
                                                            double *__restrict__ y) {
   __shared__ double prod[KSG_TILE_NNZ];
   __shared__ double red[KSG_BLOCK / 64];
+  /* row and entry ranges of the tile come from two independent tables (no dependent
+   * load of rowptr[tiles[b]] before the streaming can start) */
   const int r0 = tiles[blockIdx.x], r1 = tiles[blockIdx.x + 1];
+  const int64_t p0 = tile_p[blockIdx.x], p1 = tile_p[blockIdx.x + 1];
   const int nrows = r1 - r0;
-  const int64_t p0 = rowptr[r0], p1 = rowptr[r1];
   const int64_t nnz = p1 - p0;
 
   if (nnz > KSG_TILE_NNZ) {
     /* long row (nrows == 1): the whole workgroup strides over it */
     double a = 0.0;
-    for (int64_t p = p0 + threadIdx.x; p < p1; p += KSG_BLOCK) a = fma(val[p], x[colidx[p]], a);
+    for (int64_t p = p0 + threadIdx.x; p < p1; p += KSG_BLOCK)
+      a = fma(__builtin_nontemporal_load(val + p), x[__builtin_nontemporal_load(colidx + p)], a);
     a = wave_sum_width(a, 64);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = a;
     __syncthreads();
@@ -58,18 +71,58 @@ __global__ __launch_bounds__(KSG_BLOCK) void k_spmv_tiles(const int32_t *__restr
     return;
   }
 
-  /* stream the tile's entries: coalesced val/colidx, x gathered through L2 */
-  for (int t = threadIdx.x; t < (int)nnz; t += KSG_BLOCK) prod[t] = val[p0 + t] * x[colidx[p0 + t]];
+  /* this thread's row bounds, requested before the entry stream so that their latency
+   * hides behind it */
+  constexpr int RPT = KSG_TILE_ROWS / KSG_BLOCK;          /* rows per thread */
+  int64_t rb[RPT], re[RPT];
+#pragma unroll
+  for (int j = 0; j < RPT; j++) {
+    const int lr = threadIdx.x + j * KSG_BLOCK;
+    rb[j] = re[j] = 0;
+    if (lr < nrows) { rb[j] = rowptr[r0 + lr]; re[j] = rowptr[r0 + lr + 1]; }
+  }
+
+  /* stream the tile's entries: val/colidx are read once (coalesced, non-temporal, all of
+   * a thread's requests in flight together), x is gathered through L2 */
+  {
+    const int n_ = (int)nnz;
+    int32_t ci[KSG_TILE_PER_THREAD];
+    double v[KSG_TILE_PER_THREAD], xv[KSG_TILE_PER_THREAD];
+#pragma unroll
+    for (int i = 0; i < KSG_TILE_PER_THREAD; i++) {
+      const int t = threadIdx.x + i * KSG_BLOCK;
+      ci[i] = 0; v[i] = 0.0;
+      if (t < n_) { ci[i] = __builtin_nontemporal_load(colidx + p0 + t); v[i] = __builtin_nontemporal_load(val + p0 + t); }
+    }
+#pragma unroll
+    for (int i = 0; i < KSG_TILE_PER_THREAD; i++) fence_i(ci[i]);
+#pragma unroll
+    for (int i = 0; i < KSG_TILE_PER_THREAD; i++) {
+      const int t = threadIdx.x + i * KSG_BLOCK;
+      xv[i] = 0.0;
+      if (t < n_) xv[i] = x[ci[i]];
+    }
+#pragma unroll
+    for (int i = 0; i < KSG_TILE_PER_THREAD; i++) fence_d(xv[i]);
+#pragma unroll
+    for (int i = 0; i < KSG_TILE_PER_THREAD; i++) {
+      const int t = threadIdx.x + i * KSG_BLOCK;
+      if (t < n_) prod[t] = v[i] * xv[i];
+    }
+  }
   __syncthreads();
 
   if (nrows > KSG_BLOCK / 2) {
     /* one lane per row, products added in storage order */
-    if ((int)threadIdx.x < nrows) {
-      const int r = r0 + threadIdx.x;
-      const int b = (int)(rowptr[r] - p0), e = (int)(rowptr[r + 1] - p0);
-      double s = 0.0;
-      for (int t = b; t < e; t++) s += prod[t];
-      y[r] = s;
+#pragma unroll
+    for (int j = 0; j < RPT; j++) {
+      const int lr = threadIdx.x + j * KSG_BLOCK;
+      if (lr < nrows) {
+        const int b = (int)(rb[j] - p0), e = (int)(re[j] - p0);
+        double s = 0.0;
+        for (int t = b; t < e; t++) s += prod[t];
+        y[r0 + lr] = s;
+      }
     }
   } else {
     /* G lanes per row, G = largest power of two with nrows*G <= 256 (at most 64) */
@@ -149,6 +202,9 @@ static int csr_to_device(ksg_csr_dev *D, int64_t nrows, const int64_t *rowptr, c
   KSG_CHK(upload(&D->colidx, colidx, (size_t)D->nnz));
   KSG_CHK(upload(&D->val, val, (size_t)D->nnz));
   KSG_CHK(upload(&D->tiles, tiles.data(), tiles.size()));
+  std::vector<int64_t> tile_p(tiles.size());
+  for (size_t i = 0; i < tiles.size(); i++) tile_p[i] = rowptr[tiles[i]];
+  KSG_CHK(upload(&D->tile_p, tile_p.data(), tile_p.size()));
   return KSG_OK;
 }
 
@@ -157,6 +213,7 @@ static void csr_free(ksg_csr_dev *D) {
   if (D->colidx) hipFree(D->colidx);
   if (D->val) hipFree(D->val);
   if (D->tiles) hipFree(D->tiles);
+  if (D->tile_p) hipFree(D->tile_p);
   memset(D, 0, sizeof(*D));
 }
 
@@ -333,7 +390,7 @@ static int mat_mult_raw(ksg_mat A, const double *x, double *y) {
   }
   if (A->diag.ntiles)
     hipLaunchKernelGGL(k_spmv_tiles, dim3((unsigned)A->diag.ntiles), dim3(KSG_BLOCK), 0, c->stream,
-                       A->diag.tiles, A->diag.rowptr, A->diag.colidx, A->diag.val, x, y);
+                       A->diag.tiles, A->diag.tile_p, A->diag.rowptr, A->diag.colidx, A->diag.val, x, y);
   KSG_HIP(hipGetLastError());
   if (halo) {
     KSG_CHK(ksg_comm_exchange(c, A));

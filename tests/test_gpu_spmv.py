@@ -75,9 +75,9 @@ def test_golden_bv_test7(gpu_ctx):
 def test_irregular_rows(gpu_ctx):
     """R-MAT graph Laplacian: grouped tiles and long rows."""
     from slepc_amd import matgen as mg
-    rp, ci, va = mg.rmat_laplacian(15)
+    rp, ci, va = mg.rmat_laplacian(16)
     n = len(rp) - 1
-    assert np.diff(rp).max() > 2048
+    assert np.diff(rp).max() > 4096          # longer than one LDS tile
     x = np.random.default_rng(1).standard_normal(n)
     y, info = _run(gpu_ctx, rp, ci, va, x)
     assert info["long_rows"] > 0 and info["group_tiles"] > 0
