@@ -705,6 +705,10 @@ static int dotvec_impl(ksg_bv X, const double *y, double *q_host, int global) {
   if (spec_matches(c, X, y, k)) {
     KSG_HIP(hipSetDevice(c->device));
     d_res = c->d_spec;                      /* no kernel, no bytes: computed by the preceding multvec */
+    if (c->nranks > 1) {                    /* the reduction over ranks works in place: keep the local values */
+      KSG_HIP(hipMemcpyAsync(c->d_red, c->d_spec, (size_t)k * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+      d_res = c->d_red;
+    }
     c->stats.calls[KSG_EV_DOTVEC_FUSED] += 1;
     c->stats.flops[KSG_EV_DOTVEC_FUSED] += 2.0 * (double)X->n * k;
   } else {
