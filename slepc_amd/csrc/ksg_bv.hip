@@ -410,7 +410,7 @@ template <int E, int R>
 __global__ __launch_bounds__(KSG_BLOCK) void k_multinplace(const double *__restrict__ Vin, int64_t ld, int K,
                                                             const double *__restrict__ Bq,
                                                             double *__restrict__ Vout, int64_t ldo, int ne,
-                                                            int64_t n) {
+                                                            int64_t n, double beta) {
   __shared__ double Bs[KSG_MIP_LDS];
   constexpr int KT = KSG_MIP_LDS / E;            /* panel rows per LDS fill */
   const int64_t ngroups = (n + R - 1) / R;
@@ -470,11 +470,19 @@ __global__ __launch_bounds__(KSG_BLOCK) void k_multinplace(const double *__restr
       if (R == 2 && r0 + 1 < n) {
 #pragma unroll
         for (int e = 0; e < E; e++)
-          if (e < ne) *reinterpret_cast<double2 *>(Vout + (int64_t)e * ldo + r0) = make_double2(acc[0][e], acc[R - 1][e]);
+          if (e < ne) {
+            double2 *o = reinterpret_cast<double2 *>(Vout + (int64_t)e * ldo + r0);
+            double2 v = make_double2(acc[0][e], acc[R - 1][e]);
+            if (beta != 0.0) { const double2 old = *o; v.x = fma(beta, old.x, v.x); v.y = fma(beta, old.y, v.y); }
+            *o = v;
+          }
       } else {
 #pragma unroll
         for (int e = 0; e < E; e++)
-          if (e < ne) Vout[(int64_t)e * ldo + r0] = acc[0][e];
+          if (e < ne) {
+            double *o = Vout + (int64_t)e * ldo + r0;
+            *o = (beta != 0.0) ? fma(beta, *o, acc[0][e]) : acc[0][e];
+          }
       }
     }
   }
@@ -482,20 +490,20 @@ __global__ __launch_bounds__(KSG_BLOCK) void k_multinplace(const double *__restr
 
 template <int E, int R>
 static void launch_mip(ksg_ctx c, const double *Vin, int64_t ld, int K, const double *Bq, double *Vout,
-                       int64_t ldo, int ne, int64_t n) {
+                       int64_t ldo, int ne, int64_t n, double beta) {
   const int nb = ksg_grid_for((n + R - 1) / R);
-  hipLaunchKernelGGL((k_multinplace<E, R>), dim3(nb), dim3(KSG_BLOCK), 0, c->stream, Vin, ld, K, Bq, Vout, ldo, ne, n);
+  hipLaunchKernelGGL((k_multinplace<E, R>), dim3(nb), dim3(KSG_BLOCK), 0, c->stream, Vin, ld, K, Bq, Vout, ldo, ne, n, beta);
 }
 
 /* out(:,0:ne) = Vin(:,0:K) * B, B given on the device as K x E row-major panel. */
 static int mip_panel(ksg_ctx c, const double *Vin, int64_t ld, int K, const double *Bq, int E, double *Vout,
-                     int64_t ldo, int ne, int64_t n) {
+                     int64_t ldo, int ne, int64_t n, double beta = 0.0) {
   const bool two = aligned16(Vin) && aligned16(Vout) && (ld % 2 == 0) && (ldo % 2 == 0);
   switch (E) {
-    case 8:  if (two) launch_mip<8, 2>(c, Vin, ld, K, Bq, Vout, ldo, ne, n);  else launch_mip<8, 1>(c, Vin, ld, K, Bq, Vout, ldo, ne, n);  break;
-    case 16: if (two) launch_mip<16, 2>(c, Vin, ld, K, Bq, Vout, ldo, ne, n); else launch_mip<16, 1>(c, Vin, ld, K, Bq, Vout, ldo, ne, n); break;
-    case 32: if (two) launch_mip<32, 2>(c, Vin, ld, K, Bq, Vout, ldo, ne, n); else launch_mip<32, 1>(c, Vin, ld, K, Bq, Vout, ldo, ne, n); break;
-    default: launch_mip<64, 1>(c, Vin, ld, K, Bq, Vout, ldo, ne, n); break;
+    case 8:  if (two) launch_mip<8, 2>(c, Vin, ld, K, Bq, Vout, ldo, ne, n, beta);  else launch_mip<8, 1>(c, Vin, ld, K, Bq, Vout, ldo, ne, n, beta);  break;
+    case 16: if (two) launch_mip<16, 2>(c, Vin, ld, K, Bq, Vout, ldo, ne, n, beta); else launch_mip<16, 1>(c, Vin, ld, K, Bq, Vout, ldo, ne, n, beta); break;
+    case 32: if (two) launch_mip<32, 2>(c, Vin, ld, K, Bq, Vout, ldo, ne, n, beta); else launch_mip<32, 1>(c, Vin, ld, K, Bq, Vout, ldo, ne, n, beta); break;
+    default: launch_mip<64, 1>(c, Vin, ld, K, Bq, Vout, ldo, ne, n, beta); break;
   }
   KSG_HIP(hipGetLastError());
   return KSG_OK;
@@ -583,6 +591,83 @@ __global__ __launch_bounds__(KSG_BLOCK) void k_rowabs_max(const double *__restri
     for (int w = 1; w < KSG_BLOCK / 64; w++) s = fmax(s, sm[w]);
     partial[blockIdx.x] = s;
   }
+}
+
+/* ------------------------------------------------------------------------ */
+/* Gram block: M = Y^T X  (tall-skinny GEMM^T)                                 */
+/* ------------------------------------------------------------------------ */
+/* A wave owns an 8 x 8 tile of the result (8 columns of Y, 8 of X) and walks 64 row
+ * pairs per step with all 16 loads in flight; the WY x WX waves of a workgroup walk the
+ * same rows, so within a workgroup every column comes from HBM once and the other waves
+ * find it in cache.  Columns past the end of a ragged tile re-read the tile's first
+ * column (a cache hit) and their results are dropped.  partial[(j*ky + i)*nb + row block]. */
+#define KSG_GT 8
+__global__ __launch_bounds__(512) void k_gram(const double *__restrict__ Y, int64_t ldy, int ky,
+                                              const double *__restrict__ X, int64_t ldx, int kx, int64_t n,
+                                              double *__restrict__ partial, int nb, int WY, int ngy, int ngx) {
+  const int lane = threadIdx.x & 63;
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int WX = (blockDim.x >> 6) / WY;
+  const int tiles_y = (ngy + WY - 1) / WY;
+  const int gy = (blockIdx.y % tiles_y) * WY + w % WY;
+  const int gx = (blockIdx.y / tiles_y) * WX + w / WY;
+  if (gy >= ngy || gx >= ngx) return;             /* no barriers in this kernel */
+  const int i0 = gy * KSG_GT, j0 = gx * KSG_GT;
+  const int ni = min(KSG_GT, ky - i0), nj = min(KSG_GT, kx - j0);
+  const double2 *yc[KSG_GT], *xc[KSG_GT];
+#pragma unroll
+  for (int t = 0; t < KSG_GT; t++) {
+    yc[t] = reinterpret_cast<const double2 *>(Y + (int64_t)(i0 + (t < ni ? t : 0)) * ldy);
+    xc[t] = reinterpret_cast<const double2 *>(X + (int64_t)(j0 + (t < nj ? t : 0)) * ldx);
+  }
+  double acc[KSG_GT][KSG_GT];
+#pragma unroll
+  for (int a = 0; a < KSG_GT; a++)
+#pragma unroll
+    for (int b = 0; b < KSG_GT; b++) acc[a][b] = 0.0;
+  const int64_t npair = n >> 1;
+  for (int64_t p = (int64_t)blockIdx.x * 64 + lane; p < npair; p += (int64_t)gridDim.x * 64) {
+    double2 yv[KSG_GT], xv[KSG_GT];
+#pragma unroll
+    for (int t = 0; t < KSG_GT; t++) { yv[t] = yc[t][p]; xv[t] = xc[t][p]; }
+#pragma unroll
+    for (int t = 0; t < KSG_GT; t++) { ld_fence(yv[t]); ld_fence(xv[t]); }
+#pragma unroll
+    for (int a = 0; a < KSG_GT; a++)
+#pragma unroll
+      for (int b = 0; b < KSG_GT; b++) acc[a][b] = dot_acc(yv[a], xv[b], acc[a][b]);
+  }
+  if ((n & 1) && blockIdx.x == 0 && lane == 0) {
+#pragma unroll
+    for (int a = 0; a < KSG_GT; a++)
+#pragma unroll
+      for (int b = 0; b < KSG_GT; b++)
+        acc[a][b] = fma(Y[(int64_t)(i0 + (a < ni ? a : 0)) * ldy + n - 1], X[(int64_t)(j0 + (b < nj ? b : 0)) * ldx + n - 1], acc[a][b]);
+  }
+#pragma unroll
+  for (int a = 0; a < KSG_GT; a++)
+#pragma unroll
+    for (int b = 0; b < KSG_GT; b++) {
+      const double v = wave_sum(acc[a][b]);
+      if (lane == 0 && a < ni && b < nj) partial[((int64_t)(j0 + b) * ky + i0 + a) * nb + blockIdx.x] = v;
+    }
+}
+
+/* d_out[j*ky + i] = Y(:,i)^T X(:,j) over the local rows; needs 16-byte aligned columns */
+static int launch_gram(ksg_ctx c, const double *Y, int64_t ldy, int ky, const double *X, int64_t ldx, int kx,
+                       int64_t n, double *d_out) {
+  const int ngy = (ky + KSG_GT - 1) / KSG_GT, ngx = (kx + KSG_GT - 1) / KSG_GT;
+  int WY = ngy < 8 ? ngy : 8;
+  int WX = 8 / WY; if (WX > ngx) WX = ngx;
+  const int tiles_y = (ngy + WY - 1) / WY, tiles_x = (ngx + WX - 1) / WX;
+  int64_t nbl = ((n + 1) / 2 + 63) / 64;
+  const int nb = (int)(nbl > 256 ? 256 : nbl);
+  KSG_CHK(ksg_ensure_partial(c, (size_t)kx * ky * nb));
+  hipLaunchKernelGGL(k_gram, dim3(nb, tiles_y * tiles_x), dim3(64 * WY * WX), 0, c->stream, Y, ldy, ky, X, ldx, kx, n,
+                     c->d_partial, nb, WY, ngy, ngx);
+  hipLaunchKernelGGL((k_reduce_partials<0>), dim3(kx * ky), dim3(KSG_BLOCK), 0, c->stream, c->d_partial, nb, d_out);
+  KSG_HIP(hipGetLastError());
+  return KSG_OK;
 }
 
 /* d_out[j] = sum_r X[r + j*ld]^2, j < ncols */
@@ -832,46 +917,41 @@ static int ensure_hq(size_t doubles) {
   return KSG_OK;
 }
 
-/* out(:, 0:ne) = Vin(:,0:K) * B where B[i][c] is produced by `coef(i,c)`; handles
- * any ne by panels of 64 columns through a scratch copy when it cannot be done
- * in place. */
+/* out(:, 0:ne) = beta*out + Vin(:,0:K) * B where B[i][c] is produced by `coef(i,c)`.
+ * In place (output columns among the input columns, beta = 0): one launch holds up to 64
+ * output columns per row in registers; wider results go through a scratch copy.  Out of
+ * place: panels of 32 output columns (the fastest width), the input streamed once per
+ * panel. */
 template <class F>
 static int mip_general(ksg_ctx c, const double *Vin, int64_t ld, int K, int ne, F coef, double *Vout,
-                       int64_t ldo, int64_t n, bool inplace_overlap) {
+                       int64_t ldo, int64_t n, bool inplace_overlap, double beta = 0.0) {
   if (ne <= 0 || n <= 0) return KSG_OK;
-  if (ne <= 64) {
-    const int E = mip_width(ne);
-    KSG_CHK(ksg_ensure_q(c, (size_t)K * E));
-    KSG_HIP(hipStreamSynchronize(c->stream));
-    KSG_CHK(ensure_hq((size_t)K * E));
-    for (int i = 0; i < K; i++)
-      for (int e = 0; e < E; e++) g_hq[(size_t)i * E + e] = e < ne ? coef(i, e) : 0.0;
-    KSG_HIP(hipMemcpyAsync(c->d_q, g_hq, (size_t)K * E * sizeof(double), hipMemcpyHostToDevice, c->stream));
-    return mip_panel(c, Vin, ld, K, c->d_q, E, Vout, ldo, ne, n);
-  }
-  /* wide result: panels of 64 columns; via scratch if the output overlaps the input */
-  const int npan = (ne + 63) / 64;
+  const int PW = inplace_overlap ? 64 : 32;             /* panel width */
+  const int npan = (ne + PW - 1) / PW;
+  const int E = npan == 1 ? mip_width(ne) : PW;          /* padded width of a panel in d_q */
   double *dst = Vout;
   int64_t ldd = ldo;
-  if (inplace_overlap) {
+  const bool scratch = inplace_overlap && npan > 1;
+  if (scratch) {
     KSG_CHK(ksg_ensure_work(c, (size_t)ld * ne));
     dst = c->d_work; ldd = ld;
   }
-  KSG_CHK(ksg_ensure_q(c, (size_t)K * 64 * npan));
-  KSG_HIP(hipStreamSynchronize(c->stream));
-  KSG_CHK(ensure_hq((size_t)K * 64 * npan));
+  KSG_CHK(ksg_ensure_q(c, (size_t)K * E * npan));
+  KSG_HIP(hipStreamSynchronize(c->stream));               /* the staging buffer may still be in use */
+  KSG_CHK(ensure_hq((size_t)K * E * npan));
   for (int pnl = 0; pnl < npan; pnl++) {
-    const int w = (ne - pnl * 64 < 64) ? ne - pnl * 64 : 64;
-    double *h = g_hq + (size_t)pnl * K * 64;
+    const int w = (ne - pnl * PW < PW) ? ne - pnl * PW : PW;
+    double *h = g_hq + (size_t)pnl * K * E;
     for (int i = 0; i < K; i++)
-      for (int e = 0; e < 64; e++) h[(size_t)i * 64 + e] = e < w ? coef(i, pnl * 64 + e) : 0.0;
+      for (int e = 0; e < E; e++) h[(size_t)i * E + e] = e < w ? coef(i, pnl * PW + e) : 0.0;
   }
-  KSG_HIP(hipMemcpyAsync(c->d_q, g_hq, (size_t)K * 64 * npan * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  KSG_HIP(hipMemcpyAsync(c->d_q, g_hq, (size_t)K * E * npan * sizeof(double), hipMemcpyHostToDevice, c->stream));
   for (int pnl = 0; pnl < npan; pnl++) {
-    const int w = (ne - pnl * 64 < 64) ? ne - pnl * 64 : 64;
-    KSG_CHK(mip_panel(c, Vin, ld, K, c->d_q + (size_t)pnl * K * 64, 64, dst + (int64_t)pnl * 64 * ldd, ldd, w, n));
+    const int w = (ne - pnl * PW < PW) ? ne - pnl * PW : PW;
+    KSG_CHK(mip_panel(c, Vin, ld, K, c->d_q + (size_t)pnl * K * E, E, dst + (int64_t)pnl * PW * ldd, ldd, w, n,
+                      scratch ? 0.0 : beta));
   }
-  if (inplace_overlap)
+  if (scratch)
     KSG_HIP(hipMemcpy2DAsync(Vout, (size_t)ldo * sizeof(double), dst, (size_t)ldd * sizeof(double),
                              (size_t)n * sizeof(double), (size_t)ne, hipMemcpyDeviceToDevice, c->stream));
   return KSG_OK;
@@ -1012,11 +1092,22 @@ extern "C" int ksg_bv_mult(ksg_bv Y, double alpha, double beta, ksg_bv X, const 
     return KSG_OK;
   }
   if (ldq < 1) KSG_FAIL(KSG_ERR_ARG, "ksg_bv_mult: ldq=%d", ldq);
-  /* column by column through the GEMV kernel: Y(:,ly+j) = beta*Y(:,ly+j) + alpha*X*Q(lx:kx, ly+j) */
-  for (int j = 0; j < ky; j++)
-    KSG_CHK(launch_multvec(c, bv_col(X, X->l), X->ld, kx, Q + (size_t)(Y->l + j) * ldq + X->l, alpha, beta,
-                           bv_col(Y, Y->l + j), Y->n, NULL, NULL));
-  KSG_CHK(ksg_op_end(c, KSG_EV_MULT, 8.0 * (double)Y->n * ky * (kx + 2), 2.0 * (double)Y->n * ky * kx));
+  /* Y(:,ly:ky) = beta*Y + X(:,lx:kx) * (alpha*Q(lx:kx, ly:ky)): the restart kernel, out of place
+   * (BVMult_Svec svec.c:27 -> BVMult_BLAS_Private bvblas.c:34) */
+  const int xl = X->l, yl = Y->l;
+  auto coef = [=](int i, int cc) { return alpha * Q[(size_t)(xl + i) + (size_t)(yl + cc) * ldq]; };
+  if (kx == 0) {
+    if (beta == 0.0)
+      hipLaunchKernelGGL(k_set_cols, dim3(ksg_grid_for(Y->n), ky), dim3(KSG_BLOCK), 0, c->stream, bv_col(Y, Y->l), Y->ld, Y->n, 0.0);
+    else if (beta != 1.0)
+      hipLaunchKernelGGL(k_scale_cols, dim3(ksg_grid_for((Y->n + 1) / 2), ky), dim3(KSG_BLOCK), 0, c->stream, bv_col(Y, Y->l), Y->ld, Y->n, beta);
+  } else {
+    int rc = mip_general(c, bv_col(X, X->l), X->ld, kx, ky, coef, bv_col(Y, Y->l), Y->ld, Y->n, false, beta);
+    if (rc) return rc;
+  }
+  const int npan = (ky + 31) / 32;
+  KSG_CHK(ksg_op_end(c, KSG_EV_MULT, 8.0 * (double)Y->n * ((double)npan * kx + (beta != 0.0 ? 2.0 : 1.0) * ky),
+                     2.0 * (double)Y->n * ky * kx));
   return KSG_OK;
 }
 
@@ -1029,10 +1120,16 @@ extern "C" int ksg_bv_dot(ksg_bv X, ksg_bv Y, double *M, int ldm) {
   if (!kx || !ky) return KSG_OK;
   if ((size_t)kx * ky > KSG_RED_MAX) KSG_FAIL(KSG_ERR_UNSUPPORTED, "ksg_bv_dot: %d x %d result", ky, kx);
   KSG_CHK(ksg_op_begin(c, KSG_EV_DOT));
-  /* M(ly+i, lx+j) = Y(:,ly+i)^T X(:,lx+j): one GEMV^T per column of X, one reduction for all */
-  for (int j = 0; j < kx; j++)
-    KSG_CHK(ksg_launch_dotvec(c, bv_col(Y, Y->l), Y->ld, ky, bv_col(X, X->l + j), X->n, c->d_red + (size_t)j * ky));
-  KSG_CHK(ksg_op_end(c, KSG_EV_DOT, 8.0 * (double)X->n * kx * (ky + 1), 2.0 * (double)X->n * kx * ky));
+  /* M(ly+i, lx+j) = Y(:,ly+i)^T X(:,lx+j) (BVDot_Svec svec.c:102 -> BVDot_BLAS_Private bvblas.c:202):
+   * register-tiled block kernel, one reduction over ranks for the whole matrix */
+  const double *Yb = bv_col(Y, Y->l), *Xb = bv_col(X, X->l);
+  if (X->n > 0 && aligned16(Yb) && aligned16(Xb) && Y->ld % 2 == 0 && X->ld % 2 == 0) {
+    KSG_CHK(launch_gram(c, Yb, Y->ld, ky, Xb, X->ld, kx, X->n, c->d_red));
+  } else {
+    for (int j = 0; j < kx; j++)
+      KSG_CHK(ksg_launch_dotvec(c, Yb, Y->ld, ky, Xb + (int64_t)j * X->ld, X->n, c->d_red + (size_t)j * ky));
+  }
+  KSG_CHK(ksg_op_end(c, KSG_EV_DOT, 8.0 * (double)X->n * (kx + ky), 2.0 * (double)X->n * kx * ky));
   std::vector<double> h((size_t)kx * ky);
   KSG_CHK(ksg_comm_allreduce(c, c->d_red, h.data(), kx * ky, 0));
   for (int j = 0; j < kx; j++)

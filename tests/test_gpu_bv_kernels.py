@@ -304,3 +304,42 @@ def test_lazy_update_flush_paths(gpu_ctx):
     l1, st_l1, _ = _cgs2_columns(gpu_ctx, A, lazy=True, passes=1)
     assert np.array_equal(e1, l1)
     assert st_l1["multvec"]["calls"] == st_e1["multvec"]["calls"]
+
+
+@pytest.mark.parametrize("n,mx,my,lx,kx,ly,ky,alpha,beta", [
+    (30001, 70, 40, 3, 70, 0, 40, 1.0, 0.0),        # two output panels, ragged tiles
+    (4096, 65, 65, 0, 65, 0, 65, -0.5, 1.0),        # wider than 64 both ways
+    (1001, 9, 33, 1, 9, 2, 33, 2.0, -1.0),
+    (2, 3, 2, 0, 3, 0, 2, 1.0, 0.5),
+    (5000, 8, 8, 2, 2, 0, 8, 1.0, 0.0),              # no active columns of X: Y = beta*Y
+])
+def test_bv_mult_dot_block_kernels(gpu_ctx, n, mx, my, lx, kx, ly, ky, alpha, beta):
+    """BVMult / BVDot through the block kernels (restart kernel out of place with beta,
+    register-tiled Gram kernel) against the oracle's GEMMs."""
+    from slepc_amd import ksgpu
+    rng = np.random.default_rng(21)
+    Xa, Ya = rng.standard_normal((n, mx)), rng.standard_normal((n, my))
+    X, Y = ksgpu.DeviceBV(gpu_ctx, n, mx), ksgpu.DeviceBV(gpu_ctx, n, my)
+    X.from_numpy(Xa)
+    Y.from_numpy(Ya)
+    OX, OY = obv.BV(n, mx), obv.BV(n, my)
+    OX.array[:] = Xa
+    OY.array[:] = Ya
+    for b, o, l, k in ((X, OX, lx, kx), (Y, OY, ly, ky)):
+        b.set_active(l, k)
+        o.set_active_columns(l, k)
+    M = np.zeros((my, mx), order="F")
+    Mo = np.zeros((my, mx), order="F")
+    X.dot(Y, M)
+    OX.op_dot(OY, Mo)
+    assert _close(M, Mo, scale=n)
+    Q = np.asfortranarray(rng.standard_normal((mx, my)))
+    if beta == 0.0:
+        nanY = Ya.copy()
+        nanY[:, ly:ky] = np.nan                       # beta = 0 must not read Y
+        Y.from_numpy(nanY)
+    Y.mult(alpha, beta, X, Q)
+    OY.op_mult(alpha, beta, OX, Q)
+    assert _close(Y.to_numpy(), OY.array, scale=10 * np.sqrt(max(kx - lx, 1)))
+    X.destroy()
+    Y.destroy()
