@@ -80,6 +80,12 @@ def main():
                          "ex5 (nonsymmetric, largest real); rmat: --grid is the R-MAT scale (graph Laplacian); "
                          "the last two split one fixed matrix over the ranks")
     ap.add_argument("--transport", default="rccl", choices=["rccl", "gloo"])
+    ap.add_argument("--mv-grid", type=int, default=0, help="tuning: KSG_OPT_MV_GRID")
+    ap.add_argument("--dot-grid", type=int, default=0, help="tuning: KSG_OPT_DOT_GRID")
+    ap.add_argument("--no-lazy", action="store_true", help="tuning: KSG_OPT_LAZY_UPDATE off")
+    ap.add_argument("--no-fuse", action="store_true", help="tuning: KSG_OPT_FUSE_DOTS off")
+    ap.add_argument("--share-device", action="store_true",
+                    help="rehearsal on a one-GPU box: every rank opens device 0 (gloo transport only)")
     ap.add_argument("--cpu-grid", type=int, default=1536)
     ap.add_argument("--cpu-restarts", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -100,9 +106,19 @@ def main():
         args.gpus = size
     dist = kdist.init_process_group() if size > 1 else None
 
-    ctx = ksgpu.Context(local_rank)
+    if args.share_device and args.transport != "gloo":
+        raise SystemExit("--share-device needs --transport gloo (RCCL refuses two ranks on one device)")
+    ctx = ksgpu.Context(0 if args.share_device else local_rank)
     if size > 1:
         kdist.init_comm(ctx, transport=args.transport)
+    if args.mv_grid:
+        ctx.set_option(ksgpu.OPT_MV_GRID, args.mv_grid)
+    if args.dot_grid:
+        ctx.set_option(ksgpu.OPT_DOT_GRID, args.dot_grid)
+    if args.no_lazy:
+        ctx.set_option(ksgpu.OPT_LAZY_UPDATE, 0)
+    if args.no_fuse:
+        ctx.set_option(ksgpu.OPT_FUSE_DOTS, 0)
 
     # ---- operator: rows [row0,row1) of the global matrix ----------------------------
     g = args.grid

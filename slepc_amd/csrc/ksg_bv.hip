@@ -206,7 +206,7 @@ struct ksg_qarg { double v[KSG_QMAX]; };
 template <int CW, int NC, int NW, bool TWO>
 __device__ __forceinline__ void mvd_rows(const double2 *const (&col)[CW], const double (&qc)[CW],
                                          const double (&qd)[TWO ? CW : 1], double beta, double beta2,
-                                         double2 *__restrict__ y2, int64_t npair, int w, int lane, int dots, int store,
+                                         double post, double2 *__restrict__ y2, int64_t npair, int w, int lane, int dots, int store,
                                          double2 (&sm)[2][NW][64], double2 (&sm2)[TWO ? 2 : 1][TWO ? NW : 1][TWO ? 64 : 1],
                                          double (&acc)[CW], double &self) {
   const int64_t step = (int64_t)gridDim.x * 64;
@@ -247,6 +247,7 @@ __device__ __forceinline__ void mvd_rows(const double2 *const (&col)[CW], const 
       r.x = fma(beta2, r.x, s2.x);
       r.y = fma(beta2, r.y, s2.y);
     }
+    if (post != 1.0) { r.x *= post; r.y *= post; }
     if (!live) r = make_double2(0.0, 0.0);
     if (w == 0 && live && store) y2[p] = r;
     if (dots) {
@@ -259,7 +260,7 @@ __device__ __forceinline__ void mvd_rows(const double2 *const (&col)[CW], const 
 
 template <int CW, int NW, bool TWO>
 __global__ __launch_bounds__(64 * NW) void k_multvec_dot(const double *__restrict__ X, int64_t ld, int k, ksg_qarg q,
-                                                          double beta, ksg_qarg q2, double beta2,
+                                                          double beta, ksg_qarg q2, double beta2, double post,
                                                           double *__restrict__ y, int64_t n,
                                                           double *__restrict__ partial, int nb, int dots, int store) {
   __shared__ double2 sm[2][NW][64];
@@ -281,8 +282,8 @@ __global__ __launch_bounds__(64 * NW) void k_multvec_dot(const double *__restric
   for (int c = 0; c < CW; c++) acc[c] = 0.0;
   double self = 0.0;
   double2 *y2 = reinterpret_cast<double2 *>(y);
-  if (kc == CW) mvd_rows<CW, CW, NW, TWO>(col, qc, qd, beta, beta2, y2, n >> 1, w, lane, dots, store, sm, sm2, acc, self);
-  else          mvd_rows<CW, CW - 1, NW, TWO>(col, qc, qd, beta, beta2, y2, n >> 1, w, lane, dots, store, sm, sm2, acc, self);
+  if (kc == CW) mvd_rows<CW, CW, NW, TWO>(col, qc, qd, beta, beta2, post, y2, n >> 1, w, lane, dots, store, sm, sm2, acc, self);
+  else          mvd_rows<CW, CW - 1, NW, TWO>(col, qc, qd, beta, beta2, post, y2, n >> 1, w, lane, dots, store, sm, sm2, acc, self);
   if ((n & 1) && blockIdx.x == 0) {               /* last row of an odd-length vector */
     const int64_t rl = n - 1;
     double t = (beta != 0.0) ? beta * y[rl] : 0.0;
@@ -291,6 +292,7 @@ __global__ __launch_bounds__(64 * NW) void k_multvec_dot(const double *__restric
       t *= beta2;
       for (int j = 0; j < k; j++) t = fma(X[(int64_t)j * ld + rl], q2.v[j], t);
     }
+    if (post != 1.0) t *= post;
     __syncthreads();                              /* every thread has read y[rl] */
     if (threadIdx.x == 0) { if (store) y[rl] = t; self = fma(t, t, self); }
     if (lane == 0) {
@@ -333,13 +335,13 @@ __global__ __launch_bounds__(KSG_BLOCK) void k_multvec_scalar(const double *__re
 
 template <int NW, bool TWO>
 static void launch_mvd(int CW, int nb, hipStream_t st, const double *X, int64_t ld, int k, const ksg_qarg &q, double beta,
-                       const ksg_qarg &q2, double beta2, double *y, int64_t n, double *partial, int dots, int store) {
-#define KSG_MVD_CASE(C) case C: hipLaunchKernelGGL((k_multvec_dot<C, NW, TWO>), dim3(nb), dim3(64 * NW), 0, st, X, ld, k, q, beta, q2, beta2, y, n, partial, nb, dots, store); break;
+                       const ksg_qarg &q2, double beta2, double post, double *y, int64_t n, double *partial, int dots, int store) {
+#define KSG_MVD_CASE(C) case C: hipLaunchKernelGGL((k_multvec_dot<C, NW, TWO>), dim3(nb), dim3(64 * NW), 0, st, X, ld, k, q, beta, q2, beta2, post, y, n, partial, nb, dots, store); break;
   switch (CW) {
     KSG_MVD_CASE(1) KSG_MVD_CASE(2) KSG_MVD_CASE(3) KSG_MVD_CASE(4) KSG_MVD_CASE(5) KSG_MVD_CASE(6)
     KSG_MVD_CASE(7) KSG_MVD_CASE(8) KSG_MVD_CASE(9) KSG_MVD_CASE(10) KSG_MVD_CASE(11) KSG_MVD_CASE(12)
     KSG_MVD_CASE(13) KSG_MVD_CASE(14) KSG_MVD_CASE(15)
-    default: hipLaunchKernelGGL((k_multvec_dot<16, NW, TWO>), dim3(nb), dim3(64 * NW), 0, st, X, ld, k, q, beta, q2, beta2, y, n, partial, nb, dots, store); break;
+    default: hipLaunchKernelGGL((k_multvec_dot<16, NW, TWO>), dim3(nb), dim3(64 * NW), 0, st, X, ld, k, q, beta, q2, beta2, post, y, n, partial, nb, dots, store); break;
   }
 #undef KSG_MVD_CASE
 }
@@ -353,11 +355,12 @@ static inline int mv_grid(ksg_ctx c, int64_t n) {
 /* One launch of the fused kernel on k <= 64 aligned columns with pre-scaled coefficients:
  * y' = b1*y + X q1, then (q2 != NULL) y'' = b2*y' + X q2; dots -> d_dots (k+1 values). */
 static int launch_fused(ksg_ctx c, const double *X, int64_t ld, int k, const ksg_qarg &q1, double b1,
-                        const ksg_qarg *q2, double b2, double *y, int64_t n, double *d_dots, int store) {
+                        const ksg_qarg *q2, double b2, double *y, int64_t n, double *d_dots, int store,
+                        double post = 1.0) {
   const int nb = mv_grid(c, n);
   if (d_dots) KSG_CHK(ksg_ensure_partial(c, (size_t)(k + 1) * nb));
-  if (q2) launch_mvd<4, true>((k + 3) / 4, nb, c->stream, X, ld, k, q1, b1, *q2, b2, y, n, c->d_partial, d_dots ? 1 : 0, store);
-  else    launch_mvd<4, false>((k + 3) / 4, nb, c->stream, X, ld, k, q1, b1, q1, 1.0, y, n, c->d_partial, d_dots ? 1 : 0, store);
+  if (q2) launch_mvd<4, true>((k + 3) / 4, nb, c->stream, X, ld, k, q1, b1, *q2, b2, post, y, n, c->d_partial, d_dots ? 1 : 0, store);
+  else    launch_mvd<4, false>((k + 3) / 4, nb, c->stream, X, ld, k, q1, b1, q1, 1.0, post, y, n, c->d_partial, d_dots ? 1 : 0, store);
   if (d_dots) hipLaunchKernelGGL((k_reduce_partials<0>), dim3(k + 1), dim3(KSG_BLOCK), 0, c->stream, c->d_partial, nb, d_dots);
   KSG_HIP(hipGetLastError());
   return KSG_OK;
@@ -382,8 +385,8 @@ static int launch_multvec(ksg_ctx c, const double *X, int64_t ld, int k, const d
     const double b = done ? 1.0 : beta;
     const double *Xc = X + (int64_t)done * ld;
     if (vec2) {
-      if (kk <= 64) launch_mvd<4, false>((kk + 3) / 4, nb, c->stream, Xc, ld, kk, q, b, q, 1.0, y, n, c->d_partial, dots ? 1 : 0, 1);
-      else          launch_mvd<8, false>((kk + 7) / 8, nb, c->stream, Xc, ld, kk, q, b, q, 1.0, y, n, c->d_partial, dots ? 1 : 0, 1);
+      if (kk <= 64) launch_mvd<4, false>((kk + 3) / 4, nb, c->stream, Xc, ld, kk, q, b, q, 1.0, 1.0, y, n, c->d_partial, dots ? 1 : 0, 1);
+      else          launch_mvd<8, false>((kk + 7) / 8, nb, c->stream, Xc, ld, kk, q, b, q, 1.0, 1.0, y, n, c->d_partial, dots ? 1 : 0, 1);
     } else {
       hipLaunchKernelGGL(k_multvec_scalar, dim3(ksg_grid_for(n)), dim3(KSG_BLOCK), 0, c->stream, Xc, ld, kk, q, b, y, n);
     }
@@ -813,16 +816,20 @@ extern "C" int ksg_bv_dotvec_local(ksg_bv X, const double *y, double *q) { retur
 
 /* Applies the deferred update on its own.  The values written are bit for bit the ones
  * whose products ksg_spec holds: same kernel, same column groups, same order of sums. */
+static int apply_pending(ksg_ctx c, const ksg_pending &pd, double post) {
+  KSG_CHK(ksg_op_begin_ex(c, KSG_EV_MULTVEC, KSG_OPB_NOFLUSH | KSG_OPB_NOBUMP));
+  ksg_qarg q1, q2;
+  for (int j = 0; j < pd.k; j++) { q1.v[j] = pd.q[j]; q2.v[j] = pd.q2[j]; }
+  KSG_CHK(launch_fused(c, pd.X, pd.ld, pd.k, q1, pd.beta, pd.stage == 2 ? &q2 : NULL, pd.beta2, pd.y, pd.n, NULL, 1, post));
+  KSG_CHK(ksg_op_end(c, KSG_EV_MULTVEC, 8.0 * (double)pd.n * (pd.k + 2), (pd.stage == 2 ? 4.0 : 2.0) * (double)pd.n * pd.k));
+  return KSG_OK;
+}
+
 int ksg_flush_pending(ksg_ctx c) {
   if (!c->pend.active) return KSG_OK;
   const ksg_pending pd = c->pend;
   c->pend.active = false;
-  KSG_CHK(ksg_op_begin_ex(c, KSG_EV_MULTVEC, KSG_OPB_NOFLUSH | KSG_OPB_NOBUMP));
-  ksg_qarg q1;
-  for (int j = 0; j < pd.k; j++) q1.v[j] = pd.q[j];
-  KSG_CHK(launch_fused(c, pd.X, pd.ld, pd.k, q1, pd.beta, NULL, 1.0, pd.y, pd.n, NULL, 1));
-  KSG_CHK(ksg_op_end(c, KSG_EV_MULTVEC, 8.0 * (double)pd.n * (pd.k + 2), 2.0 * (double)pd.n * pd.k));
-  return KSG_OK;
+  return apply_pending(c, pd, 1.0);
 }
 
 static void set_spec(ksg_ctx c, ksg_bv X, int k, const double *y) {
@@ -845,17 +852,17 @@ extern "C" int ksg_bv_multvec(ksg_bv X, double alpha, double beta, double *y, co
   const bool gs_column = c->fuse_dots && k > 0 && n > 0 && X->k < X->m && y == bv_col(X, X->k);
   const bool one_launch = gs_column && k <= 64 && mv_vec2(Xb, X->ld, y);
 
-  /* second update of a column whose first one is still pending: both in one pass */
-  if (c->pend.active && one_launch && c->pend.X == Xb && c->pend.y == y && c->pend.k == k &&
+  /* second update of a column whose first one is still pending: both will be applied in one
+   * pass, which is launched by what comes next -- normally the scaling that normalises the
+   * column (bvorthog.c:561-568), folded into the same pass */
+  if (c->pend.active && c->pend.stage == 1 && one_launch && c->pend.X == Xb && c->pend.y == y && c->pend.k == k &&
       c->pend.ld == X->ld && c->pend.n == n) {
-    const ksg_pending pd = c->pend;
-    c->pend.active = false;
-    KSG_CHK(ksg_op_begin_ex(c, KSG_EV_MULTVEC, KSG_OPB_NOFLUSH));
-    ksg_qarg q1, q2;
-    for (int j = 0; j < k; j++) { q1.v[j] = pd.q[j]; q2.v[j] = alpha * q_host[j]; }
-    KSG_CHK(launch_fused(c, Xb, X->ld, k, q1, pd.beta, &q2, beta, y, n, c->d_spec, 1));
-    KSG_CHK(ksg_op_end(c, KSG_EV_MULTVEC, 8.0 * (double)n * (k + 2), 6.0 * (double)n * k));
-    set_spec(c, X, k, y);
+    KSG_HIP(hipSetDevice(c->device));
+    ksg_pending &pd = c->pend;
+    for (int j = 0; j < k; j++) pd.q2[j] = alpha * q_host[j];
+    pd.beta2 = beta;
+    pd.stage = 2;
+    c->gen++;                                     /* y has changed as far as any reader can tell */
     c->gs_count++;
     return KSG_OK;
   }
@@ -884,7 +891,7 @@ extern "C" int ksg_bv_multvec(ksg_bv X, double alpha, double beta, double *y, co
       ksg_qarg q1;
       for (int j = 0; j < k; j++) pd.q[j] = q1.v[j] = alpha * q_host[j];
       KSG_CHK(launch_fused(c, Xb, X->ld, k, q1, beta, NULL, 1.0, y, n, c->d_spec, 0));
-      pd.X = Xb; pd.y = y; pd.ld = X->ld; pd.n = n; pd.k = k; pd.beta = beta; pd.active = true;
+      pd.X = Xb; pd.y = y; pd.ld = X->ld; pd.n = n; pd.k = k; pd.beta = beta; pd.stage = 1; pd.active = true;
       fused = 1;
       bytes = 8.0 * (double)n * (k + 1);
     } else {
@@ -988,6 +995,17 @@ extern "C" int ksg_bv_scale(ksg_bv bv, int j, double alpha) {
   if (j < 0) { KSG_CHK(check_active(bv, "ksg_bv_scale")); base = bv_col(bv, bv->l); ncols = bv->k - bv->l; }
   else { if (j >= bv->m) KSG_FAIL(KSG_ERR_ARG, "ksg_bv_scale: column %d out of range", j); base = bv_col(bv, j); ncols = 1; }
   if (ncols == 0 || bv->n == 0 || alpha == 1.0) return KSG_OK;
+  if (c->pend.active && j >= 0 && alpha != 0.0 && c->pend.y == base) {
+    /* the column's pending update(s) and this scaling in one pass, one store */
+    const ksg_pending pd = c->pend;
+    c->pend.active = false;
+    KSG_HIP(hipSetDevice(c->device));
+    c->gen++;
+    KSG_CHK(apply_pending(c, pd, alpha));
+    c->stats.calls[KSG_EV_SCALE] += 1;
+    c->stats.flops[KSG_EV_SCALE] += (double)bv->n;
+    return KSG_OK;
+  }
   KSG_CHK(ksg_op_begin(c, KSG_EV_SCALE));
   dim3 grid(ksg_grid_for((bv->n + 1) / 2), ncols);
   if (alpha == 0.0) hipLaunchKernelGGL(k_set_cols, dim3(ksg_grid_for(bv->n), ncols), dim3(KSG_BLOCK), 0, c->stream, base, bv->ld, bv->n, 0.0);

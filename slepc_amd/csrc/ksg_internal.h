@@ -47,8 +47,9 @@ struct ksg_pending {
   double *y;
   int64_t ld, n;
   int k;
-  double beta;
-  double q[64];              /* coefficients, already multiplied by alpha */
+  int stage;                 /* 1: one update pending, 2: a second one on top of it */
+  double beta, beta2;
+  double q[64], q2[64];      /* coefficients, already multiplied by alpha */
 };
 
 struct ksg_ctx_s {

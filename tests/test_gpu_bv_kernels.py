@@ -244,7 +244,7 @@ def test_fused_dots_option_off(gpu_ctx):
     G.destroy()
 
 
-def _cgs2_columns(ctx, A, lazy, passes=2, peek=None):
+def _cgs2_columns(ctx, A, lazy, passes=2, peek=None, estimate=False):
     """Classical Gram-Schmidt with `passes` passes per column, driven through the C ABI the
     way BVOrthogonalizeGS drives the op table; returns the basis and the statistics."""
     from slepc_amd import ksgpu
@@ -263,8 +263,14 @@ def _cgs2_columns(ctx, A, lazy, passes=2, peek=None):
                 G.multvec(-1.0, 1.0, G.column(j), c[:j])
                 if peek is not None and p == 0 and j == peek:
                     seen[j] = G.get_column(j)          # forces the deferred update out
-            c = G.dotvec_cols(0, j + 1, j)
-            G.scale(j, 1.0 / np.sqrt(c[j]))
+            if estimate:
+                # norm from the coefficients of the last pass, as bvorthog.c:268-273 does:
+                # the scaling follows the update directly
+                G.scale(j, 1.0 / np.sqrt(c[j] - np.sum(c[:j] ** 2)))
+            else:
+                G.touch()          # norm from a fresh reduction in every mode (same order of sums)
+                c = G.dotvec_cols(0, j + 1, j)
+                G.scale(j, 1.0 / np.sqrt(c[j]))
         out = G.to_numpy()
         st = ctx.stats()
     finally:
@@ -282,6 +288,14 @@ def test_lazy_update_bitwise(gpu_ctx, n, m):
     eager, st_e, _ = _cgs2_columns(gpu_ctx, A, lazy=False)
     lazy, st_l, _ = _cgs2_columns(gpu_ctx, A, lazy=True)
     assert np.array_equal(eager, lazy)
+    # the reference's flow (estimated norm, scaling right after the second update): the two
+    # updates and the scaling become one pass, still the same bits
+    e2, st_e2, _ = _cgs2_columns(gpu_ctx, A, lazy=False, estimate=True)
+    l2, st_l2, _ = _cgs2_columns(gpu_ctx, A, lazy=True, estimate=True)
+    assert np.array_equal(e2, l2)
+    if m > 3:
+        assert st_l2["scale"]["bytes"] < st_e2["scale"]["bytes"]
+        assert st_l2["scale"]["calls"] == st_e2["scale"]["calls"]
     # the basis is orthonormal to working accuracy
     if n > m:
         assert np.abs(lazy.T @ lazy - np.eye(m)).max() < 1e-12
@@ -289,7 +303,7 @@ def test_lazy_update_bitwise(gpu_ctx, n, m):
     if m > 3:
         assert st_l["multvec"]["bytes"] < st_e["multvec"]["bytes"]
         assert st_l["multvec"]["calls"] == st_e["multvec"]["calls"]
-    assert st_l["dotvec_fused"]["calls"] == st_e["dotvec_fused"]["calls"]
+    assert st_l["dotvec_fused"]["calls"] == st_e["dotvec_fused"]["calls"] > 0
 
 
 def test_lazy_update_flush_paths(gpu_ctx):
@@ -304,6 +318,10 @@ def test_lazy_update_flush_paths(gpu_ctx):
     l1, st_l1, _ = _cgs2_columns(gpu_ctx, A, lazy=True, passes=1)
     assert np.array_equal(e1, l1)
     assert st_l1["multvec"]["calls"] == st_e1["multvec"]["calls"]
+    # three passes per column: the third update finds two pending ones
+    e3, _, _ = _cgs2_columns(gpu_ctx, A, lazy=False, passes=3, estimate=True)
+    l3, _, _ = _cgs2_columns(gpu_ctx, A, lazy=True, passes=3, estimate=True)
+    assert np.array_equal(e3, l3)
 
 
 @pytest.mark.parametrize("n,mx,my,lx,kx,ly,ky,alpha,beta", [
