@@ -56,11 +56,12 @@ void *ksg_ctx_stream(ksg_ctx ctx);
  * and with itself, and the ksg_bv_dotvec that asks for them next costs no pass over
  * the basis.  No counterpart in the reference (its two GEMVs are separate BLAS calls,
  * bvblas.c:65-76,242-266); results are the same reductions in a different order.
- * KSG_OPT_LAZY_UPDATE (default 1): when the column before needed a refinement pass, the
- * first Gram-Schmidt update of a column only forms those products; its result is written
- * together with the second update (one pass over the basis, one store of the column) or,
- * if no second update follows, by the next call that touches device data.  The stored
- * values are bit for bit those of two separate updates.
+ * KSG_OPT_LAZY_UPDATE (default 1): such an update is not launched at once.  If the caller
+ * next asks for the updated column's products (a refinement pass) they are formed in one
+ * read-only pass and the column stays pending; a second update joins the first; the scaling
+ * that normalises the column is folded in, and one pass applies everything with a single
+ * store of the column.  Any other call that touches device data applies what is pending
+ * first.  The stored values are bit for bit those of separate launches.
  * KSG_OPT_DOT_GRID / KSG_OPT_MV_GRID: upper bound on the workgroups along the rows of
  * the reduction (default 256, one per CU) and update (default 1024) kernels. */
 enum { KSG_OPT_FUSE_DOTS = 1, KSG_OPT_DOT_GRID = 2, KSG_OPT_MV_GRID = 3, KSG_OPT_LAZY_UPDATE = 4 };

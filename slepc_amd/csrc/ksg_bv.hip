@@ -781,6 +781,14 @@ static bool spec_matches(ksg_ctx c, ksg_bv X, const double *y, int k) {
          sp.k + 1 == k && sp.y == y && y == sp.X + (int64_t)sp.k * sp.ld;
 }
 
+static int pending_products(ksg_ctx c);
+
+static bool pending_matches(ksg_ctx c, ksg_bv X, const double *y, int k) {
+  const ksg_pending &pd = c->pend;
+  return pd.active && c->fuse_dots && pd.X == bv_col(X, X->l) && pd.ld == X->ld && pd.n == X->n &&
+         pd.k + 1 == k && pd.y == y && y == pd.X + (int64_t)pd.k * pd.ld;
+}
+
 static int dotvec_impl(ksg_bv X, const double *y, double *q_host, int global) {
   BV_CHECK(X, "ksg_bv_dotvec");
   if (!y || !q_host) KSG_FAIL(KSG_ERR_ARG, "ksg_bv_dotvec: NULL vector");
@@ -790,9 +798,16 @@ static int dotvec_impl(ksg_bv X, const double *y, double *q_host, int global) {
   if (k == 0) return KSG_OK;
   if (k > KSG_RED_MAX) KSG_FAIL(KSG_ERR_UNSUPPORTED, "ksg_bv_dotvec: %d active columns", k);
   double *d_res = c->d_red;
-  if (spec_matches(c, X, y, k)) {
+  bool hit = spec_matches(c, X, y, k);
+  if (!hit && pending_matches(c, X, y, k)) {
+    /* a refinement pass on a column whose update is still pending: one pass over the basis
+     * forms the updated column in registers and its products, which is what is asked for */
+    KSG_CHK(pending_products(c));
+    hit = true;
+  }
+  if (hit) {
     KSG_HIP(hipSetDevice(c->device));
-    d_res = c->d_spec;                      /* no kernel, no bytes: computed by the preceding multvec */
+    d_res = c->d_spec;                      /* no reduction kernel: the update kernel formed the products */
     if (c->nranks > 1) {                    /* the reduction over ranks works in place: keep the local values */
       KSG_HIP(hipMemcpyAsync(c->d_red, c->d_spec, (size_t)k * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
       d_res = c->d_red;
@@ -832,6 +847,27 @@ int ksg_flush_pending(ksg_ctx c) {
   return apply_pending(c, pd, 1.0);
 }
 
+/* Products of the pending column (as it will be once updated) with the active columns and
+ * itself -> d_spec.  One update pending: the column is formed in registers only and stays
+ * pending; two pending: both are applied and stored. */
+static int pending_products(ksg_ctx c) {
+  const ksg_pending pd = c->pend;
+  KSG_CHK(ksg_op_begin_ex(c, KSG_EV_MULTVEC, KSG_OPB_NOFLUSH | KSG_OPB_NOBUMP));
+  ksg_qarg q1, q2;
+  for (int j = 0; j < pd.k; j++) { q1.v[j] = pd.q[j]; q2.v[j] = pd.q2[j]; }
+  if (pd.stage == 1) {
+    KSG_CHK(launch_fused(c, pd.X, pd.ld, pd.k, q1, pd.beta, NULL, 1.0, pd.y, pd.n, c->d_spec, 0));
+    KSG_CHK(ksg_op_end(c, KSG_EV_MULTVEC, 8.0 * (double)pd.n * (pd.k + 1), 4.0 * (double)pd.n * pd.k));
+  } else {
+    c->pend.active = false;
+    KSG_CHK(launch_fused(c, pd.X, pd.ld, pd.k, q1, pd.beta, &q2, pd.beta2, pd.y, pd.n, c->d_spec, 1));
+    KSG_CHK(ksg_op_end(c, KSG_EV_MULTVEC, 8.0 * (double)pd.n * (pd.k + 2), 6.0 * (double)pd.n * pd.k));
+  }
+  ksg_spec &sp = c->spec;
+  sp.valid = true; sp.gen = c->gen; sp.X = pd.X; sp.ld = pd.ld; sp.n = pd.n; sp.k = pd.k; sp.y = pd.y;
+  return KSG_OK;
+}
+
 static void set_spec(ksg_ctx c, ksg_bv X, int k, const double *y) {
   ksg_spec &sp = c->spec;
   sp.valid = true; sp.gen = c->gen; sp.X = bv_col(X, X->l); sp.ld = X->ld; sp.n = X->n; sp.k = k; sp.y = y;
@@ -847,23 +883,32 @@ extern "C" int ksg_bv_multvec(ksg_bv X, double alpha, double beta, double *y, co
   const int64_t n = X->n;
   if (k > 0 && !q_host) KSG_FAIL(KSG_ERR_ARG, "ksg_bv_multvec: NULL coefficients");
   /* y is the column right after the active ones: the update step of Gram-Schmidt on that
-   * column (bvorthog.c:262-268); the next thing asked for will be its products with the
-   * same columns and with itself, so they are formed while the columns are in registers */
+   * column (bvorthog.c:262-268); if a refinement pass follows it will ask for the column's
+   * products with the same columns and with itself, which the update kernel can form while
+   * the columns are in registers */
   const bool gs_column = c->fuse_dots && k > 0 && n > 0 && X->k < X->m && y == bv_col(X, X->k);
   const bool one_launch = gs_column && k <= 64 && mv_vec2(Xb, X->ld, y);
 
-  /* second update of a column whose first one is still pending: both will be applied in one
-   * pass, which is launched by what comes next -- normally the scaling that normalises the
-   * column (bvorthog.c:561-568), folded into the same pass */
-  if (c->pend.active && c->pend.stage == 1 && one_launch && c->pend.X == Xb && c->pend.y == y && c->pend.k == k &&
-      c->pend.ld == X->ld && c->pend.n == n) {
-    KSG_HIP(hipSetDevice(c->device));
+  if (c->lazy_update && one_launch) {
+    /* Nothing is launched yet.  What the caller does next decides how the basis is streamed:
+     *  - it asks for the updated column's products (a refinement pass): one read-only pass
+     *    forms them, the column stays pending;
+     *  - it updates the column again: both updates wait together;
+     *  - it scales the column (the normalisation, bvorthog.c:561-568): updates and scaling
+     *    go in one pass with one store;
+     *  - anything else that touches device data: the pending updates are applied first. */
     ksg_pending &pd = c->pend;
-    for (int j = 0; j < k; j++) pd.q2[j] = alpha * q_host[j];
-    pd.beta2 = beta;
-    pd.stage = 2;
+    KSG_HIP(hipSetDevice(c->device));
+    if (pd.active && pd.stage == 1 && pd.X == Xb && pd.y == y && pd.k == k && pd.ld == X->ld && pd.n == n) {
+      for (int j = 0; j < k; j++) pd.q2[j] = alpha * q_host[j];
+      pd.beta2 = beta;
+      pd.stage = 2;
+    } else {
+      KSG_CHK(ksg_flush_pending(c));
+      for (int j = 0; j < k; j++) pd.q[j] = alpha * q_host[j];
+      pd.X = Xb; pd.y = y; pd.ld = X->ld; pd.n = n; pd.k = k; pd.beta = beta; pd.stage = 1; pd.active = true;
+    }
     c->gen++;                                     /* y has changed as far as any reader can tell */
-    c->gs_count++;
     return KSG_OK;
   }
 
@@ -876,27 +921,7 @@ extern "C" int ksg_bv_multvec(ksg_bv X, double alpha, double beta, double *y, co
       else hipLaunchKernelGGL(k_axpby_cols, dim3(ksg_grid_for(n), 1), dim3(KSG_BLOCK), 0, c->stream, y, X->ld, y, X->ld, n, 0.0, beta);
     }
   } else {
-    bool defer = false;
-    if (gs_column) {
-      /* how many updates in a row this column has had; a new column inherits the
-       * expectation that it will need as many passes as the one before it */
-      if (c->gs_y == y && c->gs_k == k) c->gs_count++;
-      else { c->gs_two_pass = c->gs_count >= 2; c->gs_y = y; c->gs_k = k; c->gs_count = 1; }
-      defer = c->lazy_update && one_launch && c->gs_count == 1 && c->gs_two_pass;
-    }
-    if (defer) {
-      /* products now, store later: the refinement pass that is expected to follow
-       * applies both updates while it streams the basis (one store of y instead of two) */
-      ksg_pending &pd = c->pend;
-      ksg_qarg q1;
-      for (int j = 0; j < k; j++) pd.q[j] = q1.v[j] = alpha * q_host[j];
-      KSG_CHK(launch_fused(c, Xb, X->ld, k, q1, beta, NULL, 1.0, y, n, c->d_spec, 0));
-      pd.X = Xb; pd.y = y; pd.ld = X->ld; pd.n = n; pd.k = k; pd.beta = beta; pd.stage = 1; pd.active = true;
-      fused = 1;
-      bytes = 8.0 * (double)n * (k + 1);
-    } else {
-      KSG_CHK(launch_multvec(c, Xb, X->ld, k, q_host, alpha, beta, y, n, gs_column ? c->d_spec : NULL, &fused));
-    }
+    KSG_CHK(launch_multvec(c, Xb, X->ld, k, q_host, alpha, beta, y, n, gs_column ? c->d_spec : NULL, &fused));
   }
   KSG_CHK(ksg_op_end(c, KSG_EV_MULTVEC, bytes, (fused ? 4.0 : 2.0) * (double)n * k));
   if (fused) set_spec(c, X, k, y);

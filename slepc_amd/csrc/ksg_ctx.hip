@@ -39,7 +39,6 @@ extern "C" int ksg_ctx_create(int device, ksg_ctx *out) {
   c->fuse_dots = 1;
   c->lazy_update = 1;
   c->pend.active = false;
-  c->gs_y = NULL; c->gs_k = 0; c->gs_count = 0; c->gs_two_pass = 0;
   c->dot_grid = KSG_DOT_GRID;
   c->mv_grid = KSG_MV_GRID;
   memset(&c->stats, 0, sizeof(c->stats));

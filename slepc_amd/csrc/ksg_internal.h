@@ -72,9 +72,6 @@ struct ksg_ctx_s {
   int dot_grid, mv_grid;     /* row workgroups of the reduction / update kernels */
   ksg_pending pend;
   int lazy_update;           /* 0: never defer the store of a Gram-Schmidt update */
-  const double *gs_y;        /* column the last Gram-Schmidt update worked on ...  */
-  int gs_k, gs_count;        /* ... its width and how many updates it has had      */
-  int gs_two_pass;           /* the column before it needed a second pass          */
   /* communicator */
   int comm_kind, rank, nranks, cb_on_device;
   void *rccl_comm;

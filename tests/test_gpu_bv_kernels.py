@@ -171,11 +171,22 @@ def test_bv_mult_dot_general(gpu_ctx):
 
 @pytest.mark.parametrize("n,m,k", [(1000, 5, 4), (4097, 34, 33), (100003, 65, 64), (2, 3, 2), (1, 3, 2),
                                     (63, 18, 9), (50001, 130, 128), (200000, 101, 100), (30000, 140, 139)])
-def test_multvec_fused_dots(gpu_ctx, n, m, k):
-    """The Gram-Schmidt update of column k by columns [0,k) also leaves the next
-    pass's reduction behind; the dotvec that follows must return it (same values as
+@pytest.mark.parametrize("lazy", [0, 1])
+def test_multvec_fused_dots(gpu_ctx, n, m, k, lazy):
+    """The Gram-Schmidt update of column k by columns [0,k) also yields the next
+    pass's reduction; the dotvec that follows must return it (same values as
     a fresh reduction, to rounding) and anything that writes in between must
-    invalidate it."""
+    invalidate it.  lazy=0: the update is launched at once and leaves the products
+    behind; lazy=1: the update waits and the request for the products launches it."""
+    from slepc_amd import ksgpu
+    gpu_ctx.set_option(ksgpu.OPT_LAZY_UPDATE, lazy)
+    try:
+        _fused_dots_case(gpu_ctx, n, m, k, lazy)
+    finally:
+        gpu_ctx.set_option(ksgpu.OPT_LAZY_UPDATE, 1)
+
+
+def _fused_dots_case(gpu_ctx, n, m, k, lazy):
     G, O, rng = _mk(gpu_ctx, n, m, seed=3)
     q = rng.standard_normal(k) * 0.1
     G.set_active(0, k)
@@ -184,14 +195,16 @@ def test_multvec_fused_dots(gpu_ctx, n, m, k):
     gpu_ctx.stats_reset()
     G.multvec(-1.0, 1.0, G.column(k), q)
     O.op_multvec(-1.0, 1.0, ycol, q)
-    assert _close(G.get_column(k), ycol, scale=10 * np.sqrt(k))
+    if not lazy:
+        assert _close(G.get_column(k), ycol, scale=10 * np.sqrt(k))
     G.set_active(0, k + 1)
     O.set_active_columns(0, k + 1)
     got = G.dotvec(G.column(k))
     want = np.zeros(k + 1)
     O.op_dotvec(ycol, want)
     st = gpu_ctx.stats()
-    fused = k <= 128
+    assert _close(G.get_column(k), ycol, scale=10 * np.sqrt(k))
+    fused = k <= 128                         # beyond 64 columns also a lazy update is launched at once
     assert st["dotvec_fused"]["calls"] == (1 if fused else 0)
     assert st["dotvec"]["calls"] == (0 if fused else 1)
     assert _close(got, want, scale=n)
