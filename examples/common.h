@@ -1,0 +1,79 @@
+/* Helpers shared by the example programs: a minimal command line in the style of the
+ * reference's options (-n 72 -eps_nev 4 -eps_ncv 20 -eps_tol 1e-8 -eps_max_it 100
+ * -eps_largest_real ...), error checking, and the report the reference's examples print
+ * (EPSErrorView with the default ASCII format, e.g.
+ * src/eps/examples/tutorials/output/ex2_1.out). */
+#ifndef EXAMPLES_COMMON_H
+#define EXAMPLES_COMMON_H
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <math.h>
+
+#include "kseps.h"
+
+#define CHK(call) do { PetscErrorCode ierr_ = (call); if (ierr_) { \
+    fprintf(stderr, "%s:%d: error %d: %s\n", __FILE__, __LINE__, (int)ierr_, KSGetLastError()); exit(1); } } while (0)
+#define CHKG(call) do { int rc_ = (call); if (rc_) { \
+    fprintf(stderr, "%s:%d: libksgpu error %d: %s\n", __FILE__, __LINE__, rc_, ksg_last_error()); exit(1); } } while (0)
+
+static int opt_find(int argc, char **argv, const char *name) {
+  for (int i = 1; i < argc; i++) if (!strcmp(argv[i], name)) return i;
+  return 0;
+}
+static long opt_int(int argc, char **argv, const char *name, long dflt) {
+  int i = opt_find(argc, argv, name);
+  return (i && i + 1 < argc) ? atol(argv[i + 1]) : dflt;
+}
+static double opt_real(int argc, char **argv, const char *name, double dflt) {
+  int i = opt_find(argc, argv, name);
+  return (i && i + 1 < argc) ? atof(argv[i + 1]) : dflt;
+}
+
+/* -eps_nev -eps_ncv -eps_mpd -eps_tol -eps_max_it -eps_largest_real ... (EPSSetFromOptions) */
+static void eps_set_from_options(EPS eps, int argc, char **argv) {
+  PetscInt nev, ncv, mpd;
+  CHK(EPSGetDimensions(eps, &nev, &ncv, &mpd));
+  nev = (PetscInt)opt_int(argc, argv, "-eps_nev", nev);
+  CHK(EPSSetDimensions(eps, nev, (PetscInt)opt_int(argc, argv, "-eps_ncv", 0), (PetscInt)opt_int(argc, argv, "-eps_mpd", 0)));
+  CHK(EPSSetTolerances(eps, opt_real(argc, argv, "-eps_tol", 0.0), (PetscInt)opt_int(argc, argv, "-eps_max_it", 0)));
+  if (opt_find(argc, argv, "-eps_largest_magnitude")) CHK(EPSSetWhichEigenpairs(eps, EPS_LARGEST_MAGNITUDE));
+  if (opt_find(argc, argv, "-eps_smallest_magnitude")) CHK(EPSSetWhichEigenpairs(eps, EPS_SMALLEST_MAGNITUDE));
+  if (opt_find(argc, argv, "-eps_largest_real")) CHK(EPSSetWhichEigenpairs(eps, EPS_LARGEST_REAL));
+  if (opt_find(argc, argv, "-eps_smallest_real")) CHK(EPSSetWhichEigenpairs(eps, EPS_SMALLEST_REAL));
+}
+
+/* the report of EPSErrorView(eps,EPS_ERROR_RELATIVE,NULL) */
+static void eps_report(EPS eps) {
+  PetscInt nev, ncv, mpd, nconv, its, maxit;
+  PetscReal tol, err;
+  CHK(EPSGetDimensions(eps, &nev, &ncv, &mpd));
+  CHK(EPSGetConverged(eps, &nconv));
+  CHK(EPSGetIterationNumber(eps, &its));
+  CHK(EPSGetTolerances(eps, &tol, &maxit));
+  printf(" Solution method: krylovschur\n\n");
+  printf(" Number of requested eigenvalues: %d\n", (int)nev);
+  if (nconv < nev) {
+    printf(" Problem: less than %d eigenvalues converged\n\n", (int)nev);
+    return;
+  }
+  for (PetscInt i = 0; i < nev; i++) {
+    CHK(EPSComputeError(eps, i, EPS_ERROR_RELATIVE, &err));
+    if (err > 5.0 * tol) {
+      printf(" Problem: some of the first %d relative errors are higher than the tolerance\n\n", (int)nev);
+      return;
+    }
+  }
+  printf(" All requested eigenvalues computed up to the required tolerance:");
+  for (PetscInt i = 0; i < nev; i++) {
+    PetscScalar re, im;
+    CHK(EPSGetEigenvalue(eps, i, &re, &im));
+    if (i % 8 == 0) printf("\n     ");
+    if (im != 0.0) printf("%.5f%+.5fi", re, im);
+    else printf("%.5f", re);
+    if (i + 1 < nev) printf(", ");
+  }
+  printf("\n\n");
+  if (getenv("KS_EXAMPLE_VERBOSE")) fprintf(stderr, "restarts %d\n", (int)its);
+}
+#endif
