@@ -374,3 +374,23 @@ def test_bv_mult_dot_block_kernels(gpu_ctx, n, mx, my, lx, kx, ly, ky, alpha, be
     assert _close(Y.to_numpy(), OY.array, scale=10 * np.sqrt(max(kx - lx, 1)))
     X.destroy()
     Y.destroy()
+
+
+@pytest.mark.parametrize("n,k", [(4097, 9), (30000, 33), (5, 2)])
+def test_unaligned_vector_fallback(gpu_ctx, n, k):
+    """A vector that starts 8 bytes off a 16-byte boundary takes the scalar-load kernels."""
+    G, O, rng = _mk(gpu_ctx, n, k, seed=9)
+    base = gpu_ctx.vec_alloc(n + 1)
+    yd = base + 8                                    # device address, 8 bytes further
+    y = rng.standard_normal(n)
+    gpu_ctx.upload(yd, y)
+    q = G.dotvec(yd)
+    qo = np.zeros(k)
+    O.op_dotvec(y, qo)
+    assert _close(q, qo, scale=np.sqrt(n) * 10)
+    coef = rng.standard_normal(k)
+    G.multvec(-0.5, 2.0, yd, coef)
+    O.op_multvec(-0.5, 2.0, y, coef)
+    assert _close(gpu_ctx.download(yd, n), y, scale=10 * np.sqrt(k))
+    gpu_ctx.vec_free(base)
+    G.destroy()
