@@ -231,6 +231,10 @@ def main():
         nbytes, unfused = float(b[0]), float(b[1])
     value = nbytes / dt / 1e9
 
+    max_res = None
+    if args.to_convergence and eps.nconv > 0:
+        # ||A x - lambda x|| / |lambda| of every converged pair (collective: all ranks take part)
+        max_res = max(eps.compute_error(i) for i in range(min(eps.nconv, args.nev)))
     if rank == 0:
         kernels = {}
         for ev, v in st.items():
@@ -282,6 +286,7 @@ def main():
         }
         if args.to_convergence:
             out["time_to_convergence_s"] = round(dt, 3)
+            out["max_relative_residual"] = max_res
         if not args.no_cpu_baseline and size == 1:
             threads = min(16, os.cpu_count() or 1)
             out["cpu_baseline"] = cpu_baseline(args.cpu_grid, args.nev, args.cpu_restarts, threads)

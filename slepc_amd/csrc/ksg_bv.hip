@@ -605,15 +605,22 @@ __global__ __launch_bounds__(KSG_BLOCK) void k_rowabs_max(const double *__restri
  * find it in cache.  Columns past the end of a ragged tile re-read the tile's first
  * column (a cache hit) and their results are dropped.  partial[(j*ky + i)*nb + row block]. */
 #define KSG_GT 8
-__global__ __launch_bounds__(512) void k_gram(const double *__restrict__ Y, int64_t ldy, int ky,
+__global__ __launch_bounds__(256) void k_gram(const double *__restrict__ Y, int64_t ldy, int ky,
                                               const double *__restrict__ X, int64_t ldx, int kx, int64_t n,
-                                              double *__restrict__ partial, int nb, int WY, int ngy, int ngx) {
+                                              double *__restrict__ partial, int nb, int WY, int ngy, int ngx, int ntb) {
   const int lane = threadIdx.x & 63;
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int WX = (blockDim.x >> 6) / WY;
   const int tiles_y = (ngy + WY - 1) / WY;
-  const int gy = (blockIdx.y % tiles_y) * WY + w % WY;
-  const int gx = (blockIdx.y / tiles_y) * WX + w / WY;
+  /* Workgroups are dealt to the 8 XCDs round robin, each XCD with its own L2.  All the
+   * workgroups that walk the same rows (one per block of tiles) are given ids that land on
+   * one XCD next to each other, so they run together and share those rows through its L2
+   * instead of each fetching them from HBM. */
+  const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
+  const int tb = q % ntb;                          /* which block of tiles */
+  const int rb = (q / ntb) * 8 + xcd;              /* which block of rows  */
+  const int gy = (tb % tiles_y) * WY + w % WY;
+  const int gx = (tb / tiles_y) * WX + w / WY;
   if (gy >= ngy || gx >= ngx) return;             /* no barriers in this kernel */
   const int i0 = gy * KSG_GT, j0 = gx * KSG_GT;
   const int ni = min(KSG_GT, ky - i0), nj = min(KSG_GT, kx - j0);
@@ -629,10 +636,24 @@ __global__ __launch_bounds__(512) void k_gram(const double *__restrict__ Y, int6
 #pragma unroll
     for (int b = 0; b < KSG_GT; b++) acc[a][b] = 0.0;
   const int64_t npair = n >> 1;
-  for (int64_t p = (int64_t)blockIdx.x * 64 + lane; p < npair; p += (int64_t)gridDim.x * 64) {
+  const int64_t stride = (int64_t)nb * 64;
+  int64_t p = (int64_t)rb * 64 + lane;
+  /* one wave per SIMD: the loads of the next step are issued before the 128 FMAs of this
+   * one, so the matrix pipe never waits for memory */
+  double2 yn[KSG_GT], xn[KSG_GT];
+  if (p < npair) {
+#pragma unroll
+    for (int t = 0; t < KSG_GT; t++) { yn[t] = yc[t][p]; xn[t] = xc[t][p]; }
+  }
+  for (; p < npair; p += stride) {
     double2 yv[KSG_GT], xv[KSG_GT];
 #pragma unroll
-    for (int t = 0; t < KSG_GT; t++) { yv[t] = yc[t][p]; xv[t] = xc[t][p]; }
+    for (int t = 0; t < KSG_GT; t++) { yv[t] = yn[t]; xv[t] = xn[t]; }
+    const int64_t pn = p + stride;
+    if (pn < npair) {
+#pragma unroll
+      for (int t = 0; t < KSG_GT; t++) { yn[t] = yc[t][pn]; xn[t] = xc[t][pn]; }
+    }
 #pragma unroll
     for (int t = 0; t < KSG_GT; t++) { ld_fence(yv[t]); ld_fence(xv[t]); }
 #pragma unroll
@@ -640,7 +661,7 @@ __global__ __launch_bounds__(512) void k_gram(const double *__restrict__ Y, int6
 #pragma unroll
       for (int b = 0; b < KSG_GT; b++) acc[a][b] = dot_acc(yv[a], xv[b], acc[a][b]);
   }
-  if ((n & 1) && blockIdx.x == 0 && lane == 0) {
+  if ((n & 1) && rb == 0 && lane == 0) {
 #pragma unroll
     for (int a = 0; a < KSG_GT; a++)
 #pragma unroll
@@ -652,7 +673,7 @@ __global__ __launch_bounds__(512) void k_gram(const double *__restrict__ Y, int6
 #pragma unroll
     for (int b = 0; b < KSG_GT; b++) {
       const double v = wave_sum(acc[a][b]);
-      if (lane == 0 && a < ni && b < nj) partial[((int64_t)(j0 + b) * ky + i0 + a) * nb + blockIdx.x] = v;
+      if (lane == 0 && a < ni && b < nj) partial[((int64_t)(j0 + b) * ky + i0 + a) * nb + rb] = v;
     }
 }
 
@@ -660,14 +681,15 @@ __global__ __launch_bounds__(512) void k_gram(const double *__restrict__ Y, int6
 static int launch_gram(ksg_ctx c, const double *Y, int64_t ldy, int ky, const double *X, int64_t ldx, int kx,
                        int64_t n, double *d_out) {
   const int ngy = (ky + KSG_GT - 1) / KSG_GT, ngx = (kx + KSG_GT - 1) / KSG_GT;
-  int WY = ngy < 8 ? ngy : 8;
-  int WX = 8 / WY; if (WX > ngx) WX = ngx;
+  int WY = ngy < 4 ? ngy : 4;
+  int WX = 4 / WY; if (WX > ngx) WX = ngx;
   const int tiles_y = (ngy + WY - 1) / WY, tiles_x = (ngx + WX - 1) / WX;
   int64_t nbl = ((n + 1) / 2 + 63) / 64;
-  const int nb = (int)(nbl > 256 ? 256 : nbl);
+  const int nb = (int)(nbl > 256 ? 256 : (nbl + 7) / 8 * 8);      /* row blocks: a multiple of the 8 XCDs */
+  const int ntb = tiles_y * tiles_x;
   KSG_CHK(ksg_ensure_partial(c, (size_t)kx * ky * nb));
-  hipLaunchKernelGGL(k_gram, dim3(nb, tiles_y * tiles_x), dim3(64 * WY * WX), 0, c->stream, Y, ldy, ky, X, ldx, kx, n,
-                     c->d_partial, nb, WY, ngy, ngx);
+  hipLaunchKernelGGL(k_gram, dim3(nb * ntb), dim3(64 * WY * WX), 0, c->stream, Y, ldy, ky, X, ldx, kx, n,
+                     c->d_partial, nb, WY, ngy, ngx, ntb);
   hipLaunchKernelGGL((k_reduce_partials<0>), dim3(kx * ky), dim3(KSG_BLOCK), 0, c->stream, c->d_partial, nb, d_out);
   KSG_HIP(hipGetLastError());
   return KSG_OK;

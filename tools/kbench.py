@@ -52,6 +52,17 @@ def main():
     Q = np.asfortranarray(np.eye(64) + 1e-3)
     run("multinplace 64x32", "multinplace", lambda: V.multinplace(Q, 0, 32))
     run("multinplace 64x48", "multinplace", lambda: V.multinplace(Q, 0, 48))
+    # block operations (not on the Krylov-Schur path): Gram matrix and out-of-place product
+    W = ksgpu.DeviceBV(ctx, n, 64)
+    for kk in (16, 32, 64):
+        V.set_active(0, kk)
+        W.set_active(0, kk)
+        M = np.zeros((64, m), order="F")
+        run("dot %dx%d" % (kk, kk), "dot", lambda: V.dot(W, M))
+        Qm = np.asfortranarray(np.eye(m, 64) * 0.5 + 1e-3)
+        run("mult %dx%d" % (kk, kk), "mult", lambda: W.mult(1.0, 0.0, V, Qm))
+    W.destroy()
+    V.set_active(0, 64)
     run("scale", "scale", lambda: V.scale(3, 1.0000001))
     run("norm", "norm", lambda: V.norm(3, 1))
     run("copy", "copy", lambda: V.copy_column(3, 64))
