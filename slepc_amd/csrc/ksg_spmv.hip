@@ -18,6 +18,7 @@
  * exchanged on the communication stream while the diagonal block is multiplied
  * on the compute stream, and then the ghost block is added. */
 #include <algorithm>
+#include <stdlib.h>
 
 #include "ksg_internal.h"
 
@@ -57,7 +58,26 @@ __global__ __launch_bounds__(KSG_BLOCK) void k_spmv_tiles(const int32_t *__restr
   if (nnz > KSG_TILE_NNZ) {
     /* long row (nrows == 1): the whole workgroup strides over it */
     double a = 0.0;
-    for (int64_t p = p0 + threadIdx.x; p < p1; p += KSG_BLOCK)
+    int64_t p = p0 + threadIdx.x;
+    /* eight independent entry/gather pairs in flight per thread */
+    for (; p + 7 * KSG_BLOCK < p1; p += 8 * KSG_BLOCK) {
+      int32_t ci[8];
+      double v[8], xv[8];
+#pragma unroll
+      for (int i = 0; i < 8; i++) {
+        ci[i] = __builtin_nontemporal_load(colidx + p + i * KSG_BLOCK);
+        v[i] = __builtin_nontemporal_load(val + p + i * KSG_BLOCK);
+      }
+#pragma unroll
+      for (int i = 0; i < 8; i++) fence_i(ci[i]);
+#pragma unroll
+      for (int i = 0; i < 8; i++) xv[i] = x[ci[i]];
+#pragma unroll
+      for (int i = 0; i < 8; i++) fence_d(xv[i]);
+#pragma unroll
+      for (int i = 0; i < 8; i++) a = fma(v[i], xv[i], a);
+    }
+    for (; p < p1; p += KSG_BLOCK)
       a = fma(__builtin_nontemporal_load(val + p), x[__builtin_nontemporal_load(colidx + p)], a);
     a = wave_sum_width(a, 64);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = a;
@@ -164,16 +184,40 @@ __global__ __launch_bounds__(KSG_BLOCK) void k_gather(const double *__restrict__
 /* ------------------------------------------------------------------------ */
 /* host side: tiling, upload, halo plan                                       */
 /* ------------------------------------------------------------------------ */
+/* Lanes a row of `len` entries needs so that no lane adds more than 32 products in the
+ * reduction phase of a tile (a power of two, at most a whole wave). */
+static inline int lanes_for_row(int64_t len) {
+  int g = 1;
+  while (g < 64 && len > 32 * (int64_t)g) g <<= 1;
+  return g;
+}
+
+/* Cuts the rows into tiles: consecutive rows whose entries fit the LDS tile, and few enough
+ * of them that the longest row of the tile still gets its lanes (rows * lanes <= workgroup
+ * size; up to KSG_TILE_ROWS rows when one lane per row is enough).  Power-law matrices thus
+ * get short tiles around their hub rows instead of one lane walking thousands of products
+ * while the rest of the workgroup waits. */
 static void build_tiles(int64_t nrows, const int64_t *rowptr, std::vector<int32_t> &tiles,
                         int64_t *n_stream, int64_t *n_group, int64_t *n_long) {
+  const char *env = getenv("KSG_SPMV_BALANCE");
+  const bool balance = !(env && env[0] == '0');
   tiles.clear();
   tiles.push_back(0);
   *n_stream = *n_group = *n_long = 0;
   int64_t r = 0;
   while (r < nrows) {
-    int64_t e = r;
+    int64_t e = r, maxlen = 0;
     const int64_t base = rowptr[r];
-    while (e < nrows && e - r < KSG_TILE_ROWS && rowptr[e + 1] - base <= KSG_TILE_NNZ) e++;
+    while (e < nrows && e - r < KSG_TILE_ROWS && rowptr[e + 1] - base <= KSG_TILE_NNZ) {
+      if (balance) {
+        const int64_t len = rowptr[e + 1] - rowptr[e];
+        const int g = lanes_for_row(len > maxlen ? len : maxlen);
+        const int64_t allowed = g == 1 ? KSG_TILE_ROWS : KSG_BLOCK / g;
+        if (e - r + 1 > allowed && e > r) break;
+        if (len > maxlen) maxlen = len;
+      }
+      e++;
+    }
     if (e == r) { e = r + 1; (*n_long)++; }          /* a single row longer than the tile */
     else if (e - r > KSG_BLOCK / 2) (*n_stream)++;
     else (*n_group)++;
