@@ -85,7 +85,8 @@ def main():
     ap.add_argument("--no-lazy", action="store_true", help="tuning: KSG_OPT_LAZY_UPDATE off")
     ap.add_argument("--no-fuse", action="store_true", help="tuning: KSG_OPT_FUSE_DOTS off")
     ap.add_argument("--share-device", action="store_true",
-                    help="rehearsal on a one-GPU box: every rank opens device 0 (gloo transport only)")
+                    help="rehearsal on a one-GPU box: every rank opens device 0 (RCCL refuses two ranks on one "
+                         "device, so the run ends up on the gloo transport)")
     ap.add_argument("--cpu-grid", type=int, default=1536)
     ap.add_argument("--cpu-restarts", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -106,11 +107,9 @@ def main():
         args.gpus = size
     dist = kdist.init_process_group() if size > 1 else None
 
-    if args.share_device and args.transport != "gloo":
-        raise SystemExit("--share-device needs --transport gloo (RCCL refuses two ranks on one device)")
     ctx = ksgpu.Context(0 if args.share_device else local_rank)
     if size > 1:
-        kdist.init_comm(ctx, transport=args.transport)
+        _, _, args.transport = kdist.init_comm(ctx, transport=args.transport)
     if args.mv_grid:
         ctx.set_option(ksgpu.OPT_MV_GRID, args.mv_grid)
     if args.dot_grid:

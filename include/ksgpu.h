@@ -82,6 +82,8 @@ typedef int (*ksg_exchange_fn)(void *user, const double *sendbuf, const int64_t 
                                double *recvbuf, const int64_t *recvoff);
 int ksg_ctx_comm_init_callbacks(ksg_ctx ctx, int rank, int nranks, int on_device,
                                 ksg_allreduce_fn allreduce, ksg_exchange_fn exchange, void *user);
+/* Leaves the communicator (collective, like ncclCommDestroy / MPI_Comm_free). */
+int ksg_ctx_comm_finalize(ksg_ctx ctx);
 int ksg_ctx_comm_rank(ksg_ctx ctx, int *rank, int *nranks);
 
 /* --------------------------------------------------------- device vectors */

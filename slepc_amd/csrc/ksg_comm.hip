@@ -96,6 +96,22 @@ extern "C" int ksg_ctx_comm_init_callbacks(ksg_ctx c, int rank, int nranks, int 
   return KSG_OK;
 }
 
+int ksg_comm_destroy(ksg_ctx c);
+
+/* Leaves the communicator (collective); the context is single-rank again and may join
+ * another one. */
+extern "C" int ksg_ctx_comm_finalize(ksg_ctx c) {
+  if (!c) KSG_FAIL(KSG_ERR_ARG, "NULL context");
+  KSG_HIP(hipSetDevice(c->device));
+  KSG_CHK(ksg_flush_pending(c));
+  KSG_HIP(hipStreamSynchronize(c->comm_stream));
+  KSG_HIP(hipStreamSynchronize(c->stream));
+  ksg_comm_destroy(c);
+  c->rank = 0;
+  c->nranks = 1;
+  return KSG_OK;
+}
+
 extern "C" int ksg_ctx_comm_rank(ksg_ctx c, int *rank, int *nranks) {
   if (!c) KSG_FAIL(KSG_ERR_ARG, "NULL context");
   if (rank) *rank = c->rank;

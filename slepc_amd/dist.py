@@ -62,19 +62,62 @@ def gloo_callbacks(dist):
     return allreduce, exchange
 
 
-def init_comm(ctx, transport="rccl"):
-    """Joins `ctx` to the communicator of all ranks.  Returns (rank, nranks)."""
+def _check_allreduce(ctx, dist, size):
+    """One reduction through the library's communicator against the known answer."""
+    n = 1000
+    x = ctx.vec_alloc(n)
+    ctx.vec_set(x, 1.0, n)
+    got = ctx.vec_dot(x, x, n)
+    ctx.vec_free(x)
+    if abs(got - float(n * size)) > 1e-9 * n * size:
+        raise RuntimeError("communicator self-test: sum over %d ranks gave %r" % (size, got))
+
+
+def init_comm(ctx, transport="rccl", fallback=True):
+    """Joins `ctx` to the communicator of all ranks.  Returns (rank, nranks, transport used).
+
+    With transport "rccl" every rank reports over gloo whether it joined the RCCL communicator
+    and passed a one-reduction self-test; unless all did, and `fallback` is set, all of them
+    leave it and the collectives are served by gloo on host buffers instead (slower, correct),
+    so that a multi-GPU run is not lost to a communicator that will not come up."""
     rank, _, size = env_rank()
     if size == 1 and transport != "rccl-force":
-        return 0, 1
+        return 0, 1, "none"
     dist = init_process_group()
     if transport.startswith("rccl"):
-        uid = [ctx.unique_id() if rank == 0 else None]
+        import torch
+        ok = 1
+        try:
+            uid = [ctx.unique_id() if rank == 0 else None]
+        except Exception as e:           # RCCL not loadable on rank 0
+            uid, ok = [None], 0
+            print("rank %d: %s" % (rank, e), flush=True)
         dist.broadcast_object_list(uid, src=0)
-        ctx.comm_init_rccl(rank, size, uid[0])
-    elif transport == "gloo":
+        if uid[0] is None:
+            ok = 0
+        joined = False
+        if ok:
+            try:
+                ctx.comm_init_rccl(rank, size, uid[0])
+                joined = True
+                _check_allreduce(ctx, dist, size)
+            except Exception as e:
+                ok = 0
+                print("rank %d: RCCL communicator unusable: %s" % (rank, e), flush=True)
+        flag = torch.tensor([ok], dtype=torch.int32)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag[0]) == 1:
+            return rank, size, "rccl"
+        if joined:
+            try:
+                ctx.comm_finalize()
+            except Exception as e:       # pragma: no cover
+                print("rank %d: leaving the RCCL communicator failed: %s" % (rank, e), flush=True)
+        if not fallback:
+            raise RuntimeError("RCCL communicator could not be set up on every rank")
+        transport = "gloo"
+    if transport == "gloo":
         ar, ex = gloo_callbacks(dist)
         ctx.comm_init_callbacks(rank, size, ar, ex, on_device=False)
-    else:
-        raise ValueError("unknown transport " + transport)
-    return rank, size
+        return rank, size, "gloo"
+    raise ValueError("unknown transport " + transport)

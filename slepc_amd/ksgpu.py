@@ -50,6 +50,7 @@ SIGNATURES = {
     "ksg_ctx_comm_init_rccl": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "ksg_ctx_comm_init_callbacks": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, ALLREDUCE_FN,
                                               EXCHANGE_FN, C.c_void_p]),
+    "ksg_ctx_comm_finalize": (C.c_int, [C.c_void_p]),
     "ksg_ctx_comm_rank": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "ksg_vec_alloc": (C.c_int, [C.c_void_p, c_i64, C.POINTER(C.c_void_p)]),
     "ksg_vec_free": (C.c_int, [C.c_void_p, C.c_void_p]),
@@ -151,6 +152,9 @@ class Context:
     def comm_init_rccl(self, rank, nranks, uid):
         buf = C.create_string_buffer(bytes(uid), 128)
         check(self.lib.ksg_ctx_comm_init_rccl(self.h, rank, nranks, buf))
+
+    def comm_finalize(self):
+        check(self.lib.ksg_ctx_comm_finalize(self.h))
 
     def unique_id(self):
         buf = C.create_string_buffer(128)
