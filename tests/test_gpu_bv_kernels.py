@@ -394,3 +394,27 @@ def test_unaligned_vector_fallback(gpu_ctx, n, k):
     assert _close(gpu_ctx.download(yd, n), y, scale=10 * np.sqrt(k))
     gpu_ctx.vec_free(base)
     G.destroy()
+
+
+def test_empty_local_block(gpu_ctx):
+    """A rank that owns no rows (more ranks than rows): every op is a no-op that still
+    returns its zeros, so the collective call sequence stays the same on all ranks."""
+    from slepc_amd import ksgpu
+    G = ksgpu.DeviceBV(gpu_ctx, 0, 5, N=3)
+    G.set_active(0, 4)
+    y = G.column(4)
+    assert np.array_equal(G.dotvec(y), np.zeros(4))
+    G.multvec(-1.0, 1.0, y, np.ones(4))
+    G.set_active(0, 5)
+    assert np.array_equal(G.dotvec(y), np.zeros(5))
+    assert G.norm(2, 1) == 0.0 and G.norm(-1, 2) == 0.0
+    G.scale(1, 3.0)
+    G.multinplace(np.asfortranarray(np.eye(5)), 0, 3)
+    W = ksgpu.DeviceBV(gpu_ctx, 0, 5, N=3)
+    G.copy_to(W)
+    M = np.ones((5, 5), order="F")
+    G.dot(W, M)
+    assert np.array_equal(M, np.zeros((5, 5)))
+    W.mult(1.0, 0.0, G, np.asfortranarray(np.eye(5)))
+    G.destroy()
+    W.destroy()
