@@ -87,8 +87,8 @@ def main():
     ap.add_argument("--share-device", action="store_true",
                     help="rehearsal on a one-GPU box: every rank opens device 0 (RCCL refuses two ranks on one "
                          "device, so the run ends up on the gloo transport)")
-    ap.add_argument("--cpu-grid", type=int, default=1536)
-    ap.add_argument("--cpu-restarts", type=int, default=2)
+    ap.add_argument("--cpu-grid", type=int, default=2048)
+    ap.add_argument("--cpu-restarts", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--to-convergence", action="store_true",
