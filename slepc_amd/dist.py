@@ -13,6 +13,7 @@ RANK, WORLD_SIZE, MASTER_ADDR, MASTER_PORT as set by ``torch.distributed.run``):
 """
 import ctypes as C
 import os
+import sys
 
 import numpy as np
 
@@ -91,7 +92,7 @@ def init_comm(ctx, transport="rccl", fallback=True):
             uid = [ctx.unique_id() if rank == 0 else None]
         except Exception as e:           # RCCL not loadable on rank 0
             uid, ok = [None], 0
-            print("rank %d: %s" % (rank, e), flush=True)
+            print("rank %d: %s" % (rank, e), file=sys.stderr, flush=True)
         dist.broadcast_object_list(uid, src=0)
         if uid[0] is None:
             ok = 0
@@ -103,7 +104,7 @@ def init_comm(ctx, transport="rccl", fallback=True):
                 _check_allreduce(ctx, dist, size)
             except Exception as e:
                 ok = 0
-                print("rank %d: RCCL communicator unusable: %s" % (rank, e), flush=True)
+                print("rank %d: RCCL communicator unusable: %s" % (rank, e), file=sys.stderr, flush=True)
         flag = torch.tensor([ok], dtype=torch.int32)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         if int(flag[0]) == 1:
@@ -112,7 +113,7 @@ def init_comm(ctx, transport="rccl", fallback=True):
             try:
                 ctx.comm_finalize()
             except Exception as e:       # pragma: no cover
-                print("rank %d: leaving the RCCL communicator failed: %s" % (rank, e), flush=True)
+                print("rank %d: leaving the RCCL communicator failed: %s" % (rank, e), file=sys.stderr, flush=True)
         if not fallback:
             raise RuntimeError("RCCL communicator could not be set up on every rank")
         transport = "gloo"
