@@ -960,14 +960,12 @@ extern "C" int ksg_bv_touch(ksg_bv bv) {
 }
 
 /* pinned staging for small host matrices */
-static double *g_hq = NULL;
-static size_t g_hq_cap = 0;
-static int ensure_hq(size_t doubles) {
-  if (g_hq_cap >= doubles) return KSG_OK;
-  if (g_hq) KSG_HIP(hipHostFree(g_hq));
-  g_hq = NULL; g_hq_cap = 0;
-  KSG_HIP(hipHostMalloc(&g_hq, (doubles + 1024) * sizeof(double), hipHostMallocDefault));
-  g_hq_cap = doubles + 1024;
+static int ensure_hq(ksg_ctx c, size_t doubles) {
+  if (c->hq_cap >= doubles) return KSG_OK;
+  if (c->h_q) KSG_HIP(hipHostFree(c->h_q));
+  c->h_q = NULL; c->hq_cap = 0;
+  KSG_HIP(hipHostMalloc(&c->h_q, (doubles + 1024) * sizeof(double), hipHostMallocDefault));
+  c->hq_cap = doubles + 1024;
   return KSG_OK;
 }
 
@@ -992,14 +990,14 @@ static int mip_general(ksg_ctx c, const double *Vin, int64_t ld, int K, int ne, 
   }
   KSG_CHK(ksg_ensure_q(c, (size_t)K * E * npan));
   KSG_HIP(hipStreamSynchronize(c->stream));               /* the staging buffer may still be in use */
-  KSG_CHK(ensure_hq((size_t)K * E * npan));
+  KSG_CHK(ensure_hq(c, (size_t)K * E * npan));
   for (int pnl = 0; pnl < npan; pnl++) {
     const int w = (ne - pnl * PW < PW) ? ne - pnl * PW : PW;
-    double *h = g_hq + (size_t)pnl * K * E;
+    double *h = c->h_q + (size_t)pnl * K * E;
     for (int i = 0; i < K; i++)
       for (int e = 0; e < E; e++) h[(size_t)i * E + e] = e < w ? coef(i, pnl * PW + e) : 0.0;
   }
-  KSG_HIP(hipMemcpyAsync(c->d_q, g_hq, (size_t)K * E * npan * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  KSG_HIP(hipMemcpyAsync(c->d_q, c->h_q, (size_t)K * E * npan * sizeof(double), hipMemcpyHostToDevice, c->stream));
   for (int pnl = 0; pnl < npan; pnl++) {
     const int w = (ne - pnl * PW < PW) ? ne - pnl * PW : PW;
     KSG_CHK(mip_panel(c, Vin, ld, K, c->d_q + (size_t)pnl * K * E, E, dst + (int64_t)pnl * PW * ldd, ldd, w, n,

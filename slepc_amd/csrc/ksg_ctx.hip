@@ -32,6 +32,7 @@ extern "C" int ksg_ctx_create(int device, ksg_ctx *out) {
   c->d_partial = NULL; c->partial_cap = 0;
   c->d_q = NULL; c->q_cap = 0;
   c->d_work = NULL; c->work_cap = 0;
+  c->h_q = NULL; c->hq_cap = 0;
   c->timing = 0;
   c->d_spec = NULL;
   c->spec.valid = false;
@@ -86,11 +87,12 @@ extern "C" int ksg_ctx_destroy(ksg_ctx c) {
   hipStreamSynchronize(c->comm_stream);
   hipStreamSynchronize(c->stream);
   ksg_comm_destroy(c);
-  for (auto &t : c->pending) { hipEventDestroy(t.e0); hipEventDestroy(t.e1); }
+  for (auto &t : c->timers) { hipEventDestroy(t.e0); hipEventDestroy(t.e1); }
   for (auto &e : c->event_pool) hipEventDestroy(e);
   if (c->d_partial) hipFree(c->d_partial);
   if (c->d_q) hipFree(c->d_q);
   if (c->d_work) hipFree(c->d_work);
+  if (c->h_q) hipHostFree(c->h_q);
   hipFree(c->d_red);
   hipFree(c->d_spec);
   hipHostFree(c->h_red);
@@ -125,7 +127,7 @@ static int get_event(ksg_ctx c, hipEvent_t *e) {
 }
 
 static int drain_timers(ksg_ctx c) {
-  for (auto &t : c->pending) {
+  for (auto &t : c->timers) {
     float ms = 0.f;
     KSG_HIP(hipEventSynchronize(t.e1));
     KSG_HIP(hipEventElapsedTime(&ms, t.e0, t.e1));
@@ -133,7 +135,7 @@ static int drain_timers(ksg_ctx c) {
     c->event_pool.push_back(t.e0);
     c->event_pool.push_back(t.e1);
   }
-  c->pending.clear();
+  c->timers.clear();
   return KSG_OK;
 }
 
@@ -149,7 +151,7 @@ int ksg_op_begin_ex(ksg_ctx c, int ev, int flags) {
     KSG_CHK(get_event(c, &t.e0));
     KSG_CHK(get_event(c, &t.e1));
     KSG_HIP(hipEventRecord(t.e0, c->stream));
-    c->pending.push_back(t);
+    c->timers.push_back(t);
   }
   return KSG_OK;
 }
@@ -159,8 +161,8 @@ int ksg_op_end(ksg_ctx c, int ev, double bytes, double flops) {
   c->stats.bytes[ev] += bytes;
   c->stats.flops[ev] += flops;
   if (c->timing) {
-    KSG_HIP(hipEventRecord(c->pending.back().e1, c->stream));
-    if (c->pending.size() > 4096) KSG_CHK(drain_timers(c));
+    KSG_HIP(hipEventRecord(c->timers.back().e1, c->stream));
+    if (c->timers.size() > 4096) KSG_CHK(drain_timers(c));
   }
   return KSG_OK;
 }

@@ -65,6 +65,8 @@ struct ksg_ctx_s {
   size_t q_cap;
   double *d_work;            /* scratch panel for out-of-place fallbacks */
   size_t work_cap;
+  double *h_q;               /* pinned staging of the small host matrices */
+  size_t hq_cap;
   double *d_spec;            /* KSG_QMAX+1 doubles: reduction left by a fused multvec */
   ksg_spec spec;
   uint64_t gen;              /* bumped by every operation that may write device data */
@@ -81,7 +83,7 @@ struct ksg_ctx_s {
   /* statistics */
   ksg_stats stats;
   int timing;
-  std::vector<ksg_timer> pending;
+  std::vector<ksg_timer> timers;   /* event pairs of operations not yet read back */
   std::vector<hipEvent_t> event_pool;
 };
 
