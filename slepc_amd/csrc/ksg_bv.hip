@@ -978,6 +978,30 @@ template <class F>
 static int mip_general(ksg_ctx c, const double *Vin, int64_t ld, int K, int ne, F coef, double *Vout,
                        int64_t ldo, int64_t n, bool inplace_overlap, double beta = 0.0) {
   if (ne <= 0 || n <= 0) return KSG_OK;
+  if (inplace_overlap && ne > 32 && ne <= 64 && beta == 0.0) {
+    /* 33..64 output columns in place: the kernel that holds 64 outputs per row in registers
+     * is slow (one row per thread, 8-byte loads), so the result is formed as two panels of
+     * at most 32 columns with the fast kernel: the second panel goes to scratch first (the
+     * first panel's columns are among its inputs), then the first panel is written in place,
+     * then the scratch panel is copied behind it. */
+    const int n2 = ne - 32;
+    const int E2 = mip_width(n2);
+    KSG_CHK(ksg_ensure_work(c, (size_t)ld * n2));
+    KSG_CHK(ksg_ensure_q(c, (size_t)K * (32 + E2)));
+    KSG_HIP(hipStreamSynchronize(c->stream));
+    KSG_CHK(ensure_hq(c, (size_t)K * (32 + E2)));
+    double *h1 = c->h_q, *h2 = c->h_q + (size_t)K * 32;
+    for (int i = 0; i < K; i++) {
+      for (int e = 0; e < 32; e++) h1[(size_t)i * 32 + e] = coef(i, e);
+      for (int e = 0; e < E2; e++) h2[(size_t)i * E2 + e] = e < n2 ? coef(i, 32 + e) : 0.0;
+    }
+    KSG_HIP(hipMemcpyAsync(c->d_q, c->h_q, (size_t)K * (32 + E2) * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    KSG_CHK(mip_panel(c, Vin, ld, K, c->d_q + (size_t)K * 32, E2, c->d_work, ld, n2, n));
+    KSG_CHK(mip_panel(c, Vin, ld, K, c->d_q, 32, Vout, ldo, 32, n));
+    KSG_HIP(hipMemcpy2DAsync(Vout + (int64_t)32 * ldo, (size_t)ldo * sizeof(double), c->d_work, (size_t)ld * sizeof(double),
+                             (size_t)n * sizeof(double), (size_t)n2, hipMemcpyDeviceToDevice, c->stream));
+    return KSG_OK;
+  }
   const int PW = inplace_overlap ? 64 : 32;             /* panel width */
   const int npan = (ne + PW - 1) / PW;
   const int E = npan == 1 ? mip_width(ne) : PW;          /* padded width of a panel in d_q */
