@@ -49,6 +49,10 @@ int ksg_ctx_create(int device, ksg_ctx *ctx);
 int ksg_ctx_destroy(ksg_ctx ctx);
 /* Blocks until everything enqueued on the context has finished. */
 int ksg_ctx_sync(ksg_ctx ctx);
+/* Enqueues whatever update of a column is still pending (KSG_OPT_LAZY_UPDATE) without
+ * waiting for it: afterwards work enqueued on ksg_ctx_stream() by the caller sees every
+ * column up to date.  Every other entry point does this itself where it matters. */
+int ksg_ctx_flush(ksg_ctx ctx);
 /* The HIP stream (hipStream_t) all kernels are launched on. */
 void *ksg_ctx_stream(ksg_ctx ctx);
 /* Tuning switches.  KSG_OPT_FUSE_DOTS (default 1): ksg_bv_multvec on the column that
@@ -116,8 +120,9 @@ int ksg_bv_set_active(ksg_bv bv, int l, int k);
 int ksg_bv_sizes(ksg_bv bv, int64_t *n_local, int64_t *N, int *m, int64_t *ld);
 /* Device address of column j (BVGetColumn_Svec, svec.c:312-324: pv+(nc+j)*n).  Every
  * entry point of this library sees the column up to date; code of the caller that reads
- * it through this pointer on its own (a kernel on ksg_ctx_stream, hipMemcpy) must call
- * ksg_ctx_sync first, which also applies an update deferred under KSG_OPT_LAZY_UPDATE. */
+ * it through this pointer on its own must call ksg_ctx_flush first (a kernel on
+ * ksg_ctx_stream) or ksg_ctx_sync (anything else, e.g. hipMemcpy on another stream), which
+ * apply an update deferred under KSG_OPT_LAZY_UPDATE. */
 double *ksg_bv_column(ksg_bv bv, int j);
 /* Must be called after column storage was written by anything other than this
  * library (a kernel of the caller, hipMemcpy) through a pointer from ksg_bv_column:

@@ -9,9 +9,14 @@
  *     BVRegister("hip", BVCreate_HIP);          (include/slepcbv.h:196)
  * after SlepcInitialize and select with -bv_type hip.
  *
- * Column views are VECHIP vectors (the device Vec type of the PETSc in use; with the
- * PETSc generation of the reference the equivalent was VECCUDA and
- * VecCUDAPlaceArray, sveccuda.cu:500-525).
+ * Column views are device vectors (with the PETSc generation of the reference the
+ * equivalent was VECCUDA and VecCUDAPlaceArray, sveccuda.cu:500-525).  libksgpu may hold an
+ * update of a column back until the next call decides how to apply it (include/ksgpu.h,
+ * KSG_OPT_LAZY_UPDATE), so the accessors through which code outside this file reaches a
+ * view's device pointer must bracket it: readers call ksg_ctx_flush() first, writers call
+ * ksg_bv_touch() afterwards.  The VecHIP* names below stand for those bracketed accessors
+ * of the view type; the ops in this file use the raw pointer (no bracket needed: they hand
+ * it straight back to libksgpu).
  */
 #include <slepc/private/bvimpl.h>
 #include "ksgpu.h"

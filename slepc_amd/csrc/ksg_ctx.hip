@@ -63,6 +63,12 @@ extern "C" int ksg_ctx_sync(ksg_ctx c) {
   return KSG_OK;
 }
 
+extern "C" int ksg_ctx_flush(ksg_ctx c) {
+  if (!c) KSG_FAIL(KSG_ERR_ARG, "ksg_ctx_flush: NULL context");
+  KSG_HIP(hipSetDevice(c->device));
+  return ksg_flush_pending(c);
+}
+
 extern "C" void *ksg_ctx_stream(ksg_ctx c) { return c ? (void *)c->stream : NULL; }
 
 extern "C" int ksg_ctx_set_option(ksg_ctx c, int option, int value) {

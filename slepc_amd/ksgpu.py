@@ -43,6 +43,7 @@ SIGNATURES = {
     "ksg_ctx_create": (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
     "ksg_ctx_destroy": (C.c_int, [C.c_void_p]),
     "ksg_ctx_sync": (C.c_int, [C.c_void_p]),
+    "ksg_ctx_flush": (C.c_int, [C.c_void_p]),
     "ksg_ctx_stream": (C.c_void_p, [C.c_void_p]),
     "ksg_ctx_set_option": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "ksg_last_error": (C.c_char_p, []),
