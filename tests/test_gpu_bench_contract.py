@@ -36,3 +36,27 @@ def test_bench_line_schema():
     assert abs(rl["frac"] - rl["achieved"] / rl["peak"]) < 1e-3
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and cb["sample"]
+
+
+def test_bench_two_ranks_rehearsal():
+    """The N > 1 code path of bench.py (launcher environment, barriers, max over ranks, sums
+    over ranks) with two ranks sharing the one GPU of the test box over the gloo transport."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(port),
+                        os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--grid", "256", "--transport", "gloo", "--share-device"],
+                       cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert r.returncode == 0, r.stderr.decode(errors="replace")[-3000:]
+    lines = [l for l in r.stdout.decode().splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1, r.stdout.decode()[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["steps"] == 2
+    assert d["config"]["rows_per_gpu"] == 256 * 256 and "2 rank(s)" in d["config"]["partition"]
+    assert d["config"]["transport"] == "gloo"
+    assert "cpu_baseline" not in d            # rank 0 at N = 1 only
+    assert d["value"] > 0
