@@ -141,7 +141,7 @@ __global__ __launch_bounds__(KSG_BLOCK) void k_spmv_tiles(const int32_t *__restr
         const int b = (int)(rb[j] - p0), e = (int)(re[j] - p0);
         double s = 0.0;
         for (int t = b; t < e; t++) s += prod[t];
-        y[r0 + lr] = s;
+        __builtin_nontemporal_store(s, &y[r0 + lr]);
       }
     }
   } else {
