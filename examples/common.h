@@ -1,6 +1,6 @@
 /* Helpers shared by the example programs: a minimal command line in the style of the
  * reference's options (-n 72 -eps_nev 4 -eps_ncv 20 -eps_tol 1e-8 -eps_max_it 100
- * -eps_largest_real ...), error checking, and the report the reference's examples print
+ * -eps_largest_real -eps_type arnoldi ...), error checking, and the report the reference's examples print
  * (EPSErrorView with the default ASCII format, e.g.
  * src/eps/examples/tutorials/output/ex2_1.out). */
 #ifndef EXAMPLES_COMMON_H
@@ -33,6 +33,8 @@ static double opt_real(int argc, char **argv, const char *name, double dflt) {
 /* -eps_nev -eps_ncv -eps_mpd -eps_tol -eps_max_it -eps_largest_real ... (EPSSetFromOptions) */
 static void eps_set_from_options(EPS eps, int argc, char **argv) {
   PetscInt nev, ncv, mpd;
+  int it = opt_find(argc, argv, "-eps_type");
+  if (it && it + 1 < argc) CHK(EPSSetType(eps, argv[it + 1]));       /* krylovschur | arnoldi */
   CHK(EPSGetDimensions(eps, &nev, &ncv, &mpd));
   nev = (PetscInt)opt_int(argc, argv, "-eps_nev", nev);
   CHK(EPSSetDimensions(eps, nev, (PetscInt)opt_int(argc, argv, "-eps_ncv", 0), (PetscInt)opt_int(argc, argv, "-eps_mpd", 0)));
@@ -51,7 +53,9 @@ static void eps_report(EPS eps) {
   CHK(EPSGetConverged(eps, &nconv));
   CHK(EPSGetIterationNumber(eps, &its));
   CHK(EPSGetTolerances(eps, &tol, &maxit));
-  printf(" Solution method: krylovschur\n\n");
+  const char *type;
+  CHK(EPSGetType(eps, &type));
+  printf(" Solution method: %s\n\n", type);
   printf(" Number of requested eigenvalues: %d\n", (int)nev);
   if (nconv < nev) {
     printf(" Problem: less than %d eigenvalues converged\n\n", (int)nev);

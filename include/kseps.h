@@ -45,6 +45,7 @@ typedef int PetscBool;
 #define PETSC_ERR_LIB            76
 #define PETSC_ERR_PLIB           77
 #define PETSC_ERR_USER           83
+#define PETSC_ERR_ARG_UNKNOWN_TYPE 86
 
 const char *KSGetLastError(void);
 
@@ -270,6 +271,10 @@ typedef PetscErrorCode (*EPSMonitorFn)(EPS eps, PetscInt its, PetscInt nconv, Pe
 
 PetscErrorCode EPSCreate(void *ctx, EPS *eps);                                   /* epsbasic.c:60-80 */
 PetscErrorCode EPSSetOperators(EPS eps, Mat A, Mat B);                           /* B must be NULL */
+/* "krylovschur" (default; krylovschur.c, ks-symm.c) or "arnoldi" (explicit restart,
+ * src/eps/impls/krylov/arnoldi/arnoldi.c) */
+PetscErrorCode EPSSetType(EPS eps, const char *type);                            /* epsbasic.c */
+PetscErrorCode EPSGetType(EPS eps, const char **type);
 PetscErrorCode EPSSetProblemType(EPS eps, EPSProblemType type);                  /* epsopts.c:946-989 */
 PetscErrorCode EPSSetDimensions(EPS eps, PetscInt nev, PetscInt ncv, PetscInt mpd);
 PetscErrorCode EPSSetTolerances(EPS eps, PetscReal tol, PetscInt maxits);

@@ -322,6 +322,13 @@ class DSNHEP(DS):
             raise ArithmeticError("Error in Lapack xHSEQR %d" % info)
         self.state = STATE_CONDENSED
 
+    def update_extra_row(self):
+        """``DSUpdateExtraRow_NHEP`` (dsnhep.c:434-456): row n of A times Q."""
+        n = self.n
+        x = self.A[n, :n].copy()
+        self.A[n, :n] = self.Q[:n, :n].T @ x
+        self.k = n
+
     def sort(self, wr, wi):
         """``DSSort_NHEP_Total`` (dsnhep.c:347-432): selection sort with trexc."""
         n, ld = self.n, self.ld

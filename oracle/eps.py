@@ -40,11 +40,14 @@ class EPS:
 
     def __init__(self, matvec, n_local, N=None, hermitian=True, nev=1, ncv=0, mpd=0,
                  tol=1e-8, max_it=0, which=None, keep=0.5, lock=True, comm=None,
-                 row0=0, v0=None, monitor=None):
+                 row0=0, v0=None, monitor=None, solver="krylovschur"):
         self.matvec = matvec
         self.n = int(n_local)
         self.N = int(N if N is not None else n_local)
         self.hermitian = hermitian
+        if solver not in ("krylovschur", "arnoldi"):
+            raise ValueError("unknown solver " + solver)
+        self.solver = solver
         self.nev, self.ncv, self.mpd = nev, ncv, mpd
         self.tol = tol                               # default 1e-8: epssetup.c:184
         self.max_it = max_it
@@ -91,7 +94,7 @@ class EPS:
         self.errest = np.zeros(ncv + 1)
         self.perm = np.arange(ncv + 1)
         cmpf = dsmod.COMPARE[self.which]
-        if self.hermitian:
+        if self.hermitian and self.solver == "krylovschur":
             self.ds = dsmod.DSHEP(ncv + 1, cmpf)
         else:
             self.ds = dsmod.DSNHEP(ncv + 1, cmpf)
@@ -295,13 +298,48 @@ class EPS:
         ds.set_dimensions(self.nconv, 0, 0)
         ds.set_state(dsmod.STATE_RAW)
 
+    def _solve_arnoldi(self):
+        """``EPSSolve_Arnoldi`` (src/eps/impls/krylov/arnoldi/arnoldi.c:78-154): explicitly
+        restarted Arnoldi with locking, Ritz extraction, non-delayed orthogonalisation.  The
+        projected problem is always the non-symmetric one (``EPSSetUp_Arnoldi``, :58)."""
+        ds, V = self.ds, self.V
+        self._get_start_vector(0)
+        while self.reason == ITERATING:
+            self.its += 1
+            nv = min(self.nconv + self.mpd, self.ncv)
+            ds.set_dimensions(nv, self.nconv, 0)
+            H = ds.A
+            nv, beta, breakdown = self._basic_arnoldi(H, self.nconv, nv)
+            ds.set_dimensions(nv, self.nconv, 0)
+            ds.set_state(dsmod.STATE_INTERMEDIATE)
+            V.set_active_columns(self.nconv, nv)
+
+            ds.solve(self.eigr, self.eigi)
+            ds.sort(self.eigr, self.eigi)
+            ds.update_extra_row()
+
+            k = self._krylov_convergence(self.nconv, nv - self.nconv, beta)
+            Qm = ds.get_mat("Q")
+            V.mult_in_place(Qm, self.nconv, min(k + 1, nv))
+            self.reason = self._stopping(k)
+            if self.reason == ITERATING and breakdown:
+                if self._get_start_vector(k):
+                    self.reason = DIVERGED_BREAKDOWN
+            self.nconv = k
+            if self.monitor:
+                self.monitor(self.its, self.nconv, self.eigr, self.eigi, self.errest, nv)
+        ds.set_dimensions(self.nconv, 0, 0)
+        ds.set_state(dsmod.STATE_RAW)
+
     def solve(self):
         """``EPSSolve`` (epssolve.c:63-146)."""
         self.setup()
         self.nconv = 0
         self.its = 0
         self.reason = ITERATING
-        if self.hermitian:
+        if self.solver == "arnoldi":
+            self._solve_arnoldi()
+        elif self.hermitian:
             self._solve_symm()
         else:
             self._solve_default()
@@ -330,7 +368,7 @@ class EPS:
         if self._vectors_done:
             return
         self._vectors_done = True
-        if self.hermitian:
+        if self.hermitian and self.solver == "krylovschur":
             return
         n = self.ds.n
         if n == 0:

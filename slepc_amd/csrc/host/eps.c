@@ -44,6 +44,23 @@ PetscErrorCode EPSSetProblemType(EPS eps, EPSProblemType type) {
   return 0;
 }
 
+/* epsbasic.c (EPSSetType): "krylovschur" (default) or "arnoldi" */
+PetscErrorCode EPSSetType(EPS eps, const char *type) {
+  if (!eps || !type) SETERRQ(PETSC_ERR_ARG_NULL, "Null argument");
+  int t;
+  if (!strcmp(type, "krylovschur")) t = 0;
+  else if (!strcmp(type, "arnoldi")) t = 1;
+  else SETERRQ(PETSC_ERR_ARG_UNKNOWN_TYPE, "Unknown EPS type given: %s", type);
+  if (t != eps->type) { eps->type = t; eps->state = 0; }
+  return 0;
+}
+
+PetscErrorCode EPSGetType(EPS eps, const char **type) {
+  if (!eps || !type) SETERRQ(PETSC_ERR_ARG_NULL, "Null argument");
+  *type = eps->type == 1 ? "arnoldi" : "krylovschur";
+  return 0;
+}
+
 PetscErrorCode EPSSetDimensions(EPS eps, PetscInt nev, PetscInt ncv, PetscInt mpd) {
   if (!eps) SETERRQ(PETSC_ERR_ARG_NULL, "Null EPS");
   if (nev < 1) SETERRQ(PETSC_ERR_ARG_OUTOFRANGE, "Illegal value of nev. Must be > 0");
@@ -165,12 +182,21 @@ PetscErrorCode EPSSetUp(EPS eps) {
     ierr = VecDestroy(&t);CHKERRQ(ierr);
   } else { ierr = BVResize(eps->V, requested, PETSC_FALSE);CHKERRQ(ierr); }
 
-  /* dispatch solve method: DS type */
-  if (eps->ishermitian) {
+  /* dispatch solve method: DS type (EPSSetUp_KrylovSchur krylovschur.c:141-148;
+     EPSSetUp_Arnoldi arnoldi.c:58-64: always the non-symmetric projected problem, extra row) */
+  if (eps->type == 1) {
+    ierr = DSSetType(eps->ds, "nhep");CHKERRQ(ierr);
+    ierr = DSSetCompact(eps->ds, PETSC_FALSE);CHKERRQ(ierr);
+    ierr = DSSetExtraRow(eps->ds, PETSC_TRUE);CHKERRQ(ierr);
+  } else if (eps->ishermitian) {
     ierr = DSSetType(eps->ds, "hep");CHKERRQ(ierr);
     ierr = DSSetCompact(eps->ds, PETSC_TRUE);CHKERRQ(ierr);
     ierr = DSSetExtraRow(eps->ds, PETSC_TRUE);CHKERRQ(ierr);
-  } else { ierr = DSSetType(eps->ds, "nhep");CHKERRQ(ierr); }
+  } else {
+    ierr = DSSetType(eps->ds, "nhep");CHKERRQ(ierr);
+    ierr = DSSetCompact(eps->ds, PETSC_FALSE);CHKERRQ(ierr);
+    ierr = DSSetExtraRow(eps->ds, PETSC_FALSE);CHKERRQ(ierr);
+  }
   ierr = DSAllocate(eps->ds, eps->ncv + 1);CHKERRQ(ierr);
   ierr = DSSetSlepcSC(eps->ds, eps->cmp, NULL);CHKERRQ(ierr);
 
@@ -417,13 +443,52 @@ static PetscErrorCode EPSSolve_KrylovSchur_Default(EPS eps) {
 }
 
 /* ---- epsdefault.c:40-74,136-205 -------------------------------------------------------------------------- */
+/* arnoldi.c:78-154: explicitly restarted Arnoldi with locking (Ritz extraction, the
+ * orthogonalisation of every step completed before the next one starts) */
+static PetscErrorCode EPSSolve_Arnoldi(EPS eps) {
+  PetscErrorCode ierr;
+  PetscInt k, nv, ld;
+  PetscScalar *H;
+  PetscReal beta;
+  PetscBool breakdown;
+  ierr = DSGetLeadingDimension(eps->ds, &ld);CHKERRQ(ierr);
+  ierr = EPSGetStartVector(eps, 0, NULL);CHKERRQ(ierr);
+  while (eps->reason == EPS_CONVERGED_ITERATING) {
+    eps->its++;
+    /* compute an nv-step Arnoldi factorization; the locked Schur vectors stay in front */
+    nv = PetscMin(eps->nconv + eps->mpd, eps->ncv);
+    ierr = DSGetArray(eps->ds, DS_MAT_A, &H);CHKERRQ(ierr);
+    ierr = EPSBasicArnoldi(eps, H, ld, eps->nconv, &nv, &beta, &breakdown);CHKERRQ(ierr);
+    ierr = DSSetDimensions(eps->ds, nv, 0, eps->nconv, 0);CHKERRQ(ierr);
+    ierr = DSSetState(eps->ds, DS_STATE_INTERMEDIATE);CHKERRQ(ierr);
+    ierr = BVSetActiveColumns(eps->V, eps->nconv, nv);CHKERRQ(ierr);
+    /* solve projected problem */
+    ierr = DSSolve(eps->ds, eps->eigr, eps->eigi);CHKERRQ(ierr);
+    ierr = DSSort(eps->ds, eps->eigr, eps->eigi, NULL, NULL, NULL);CHKERRQ(ierr);
+    ierr = DSUpdateExtraRow(eps->ds);CHKERRQ(ierr);
+    /* check convergence, then restart with the first unconverged Schur vector */
+    ierr = EPSKrylovConvergence(eps, eps->nconv, nv - eps->nconv, beta, 1.0, &k);CHKERRQ(ierr);
+    ierr = UpdateBasis(eps, DS_MAT_Q, eps->nconv, PetscMin(k + 1, nv));CHKERRQ(ierr);
+    EPSStoppingBasic(eps, eps->its, eps->max_it, k, eps->nev, &eps->reason);
+    if (eps->reason == EPS_CONVERGED_ITERATING && breakdown) {
+      ierr = EPSGetStartVector(eps, k, &breakdown);CHKERRQ(ierr);
+      if (breakdown) eps->reason = EPS_DIVERGED_BREAKDOWN;
+    }
+    eps->nconv = k;
+    if (eps->monitor) { ierr = eps->monitor(eps, eps->its, eps->nconv, eps->eigr, eps->eigi, eps->errest, nv, eps->monitorctx);CHKERRQ(ierr); }
+  }
+  ierr = DSSetDimensions(eps->ds, eps->nconv, 0, 0, 0);CHKERRQ(ierr);
+  ierr = DSSetState(eps->ds, DS_STATE_RAW);CHKERRQ(ierr);
+  return 0;
+}
+
 static PetscErrorCode EPSComputeVectors(EPS eps) {
   PetscErrorCode ierr;
   PetscInt n;
   EPSCheckSolved(eps);
   if (eps->state == 3) return 0;
   eps->state = 3;
-  if (eps->ishermitian) return 0;              /* Lanczos vectors are the eigenvectors of a standard HEP */
+  if (eps->ishermitian && eps->type == 0) return 0;   /* Lanczos vectors are the eigenvectors of a standard HEP */
   ierr = DSGetDimensions(eps->ds, &n, NULL, NULL, NULL, NULL);CHKERRQ(ierr);
   if (!n) return 0;
   ierr = DSVectors(eps->ds, DS_MAT_X, NULL, NULL);CHKERRQ(ierr);        /* right eigenvectors of T */
@@ -443,7 +508,8 @@ PetscErrorCode EPSSolve(EPS eps) {
   eps->its = 0;
   eps->reason = EPS_CONVERGED_ITERATING;
   for (i = 0; i < eps->ncv; i++) { eps->eigr[i] = 0.0; eps->eigi[i] = 0.0; eps->errest[i] = 0.0; eps->perm[i] = i; }
-  if (eps->ishermitian) { ierr = EPSSolve_KrylovSchur_Symm(eps);CHKERRQ(ierr); }
+  if (eps->type == 1) { ierr = EPSSolve_Arnoldi(eps);CHKERRQ(ierr); }
+  else if (eps->ishermitian) { ierr = EPSSolve_KrylovSchur_Symm(eps);CHKERRQ(ierr); }
   else { ierr = EPSSolve_KrylovSchur_Default(eps);CHKERRQ(ierr); }
   eps->state = 2;
   if (!eps->reason) SETERRQ(PETSC_ERR_PLIB, "Internal error, solver returned without setting converged reason");

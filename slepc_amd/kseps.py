@@ -219,6 +219,8 @@ SIGNATURES = {
     "EPSCreate": (Err, [vp, C.POINTER(vp)]),
     "EPSSetOperators": (Err, [vp, MatP, MatP]),
     "EPSSetProblemType": (Err, [vp, C.c_int]),
+    "EPSSetType": (Err, [vp, C.c_char_p]),
+    "EPSGetType": (Err, [vp, C.POINTER(C.c_char_p)]),
     "EPSSetDimensions": (Err, [vp, C.c_int, C.c_int, C.c_int]),
     "EPSSetTolerances": (Err, [vp, C.c_double, C.c_int]),
     "EPSSetWhichEigenpairs": (Err, [vp, C.c_int]),
@@ -364,6 +366,14 @@ class EPS:
     def set_operators(self, A):
         self.A = A
         check(self.lib.EPSSetOperators(self.h, A.p, None))
+
+    def set_type(self, name):
+        check(self.lib.EPSSetType(self.h, name.encode()))
+
+    def get_type(self):
+        p = C.c_char_p()
+        check(self.lib.EPSGetType(self.h, C.byref(p)))
+        return p.value.decode()
 
     def set_problem_type(self, t):
         check(self.lib.EPSSetProblemType(self.h, t))

@@ -222,13 +222,15 @@ def run_bv_test13(be):
 
 
 def solve_eps(be, csr, hermitian=True, nev=1, ncv=0, mpd=0, tol=0.0, max_it=0, which=None, v0=None,
-              keep=None, lock=True, want_vectors=False):
+              keep=None, lock=True, want_vectors=False, solver=None):
     """EPSCreate / EPSSetOperators / ... / EPSSolve / EPSGetEigenpair / EPSComputeError."""
     rp, ci, va = csr
     A = be.mat_csr(rp, ci, va)
     eps = K.EPS(be.ctx.h if be.ctx else None)
     eps.set_operators(A)
     eps.set_problem_type(K.EPS_HEP if hermitian else K.EPS_NHEP)
+    if solver:
+        eps.set_type(solver)
     eps.set_dimensions(nev, ncv, mpd)
     eps.set_tolerances(tol, max_it)
     if which:

@@ -70,6 +70,9 @@ CASES = {
     "lap2d_300x217": (lambda: mg.laplacian2d(300, 217), True, dict(nev=8, tol=1e-10)),
     "lap3d_40x37x29": (lambda: mg.laplacian3d(40, 37, 29), True, dict(nev=8, tol=1e-10)),
     "markov_120": (lambda: mg.markov(120), False, dict(nev=6, which="largest_real", tol=1e-12)),
+    # explicitly restarted Arnoldi (arnoldi.c) on the same kernels
+    "lap2d_60x45_arnoldi": (lambda: mg.laplacian2d(60, 45), True, dict(nev=4, tol=1e-9, solver="arnoldi")),
+    "markov_60_arnoldi": (lambda: mg.markov(60), False, dict(nev=4, which="largest_real", tol=1e-10, solver="arnoldi")),
 }
 
 

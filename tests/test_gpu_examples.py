@@ -50,3 +50,11 @@ def test_ex2_matches_reference_output():
 
 def test_ex5_matches_reference_output():
     assert _run("ex5", "-eps_nev", "4", "-eps_largest_real") == EX5_1
+
+
+def test_ex2_arnoldi_same_eigenvalues():
+    """runtest-style: the same problem with -eps_type arnoldi prints the same eigenvalues."""
+    out = _run("ex2", "-n", "30", "-m", "20", "-eps_nev", "3", "-eps_type", "arnoldi")
+    ref = _run("ex2", "-n", "30", "-m", "20", "-eps_nev", "3")
+    assert "Solution method: arnoldi" in out and "Solution method: krylovschur" in ref
+    assert out.splitlines()[-2] == ref.splitlines()[-2] and "All requested eigenvalues computed" in out

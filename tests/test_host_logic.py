@@ -268,15 +268,24 @@ def test_eps_goldens(be):
     assert _fmt(r["values"], 4) == g["test2"]["smallest"]
 
 
-@pytest.mark.parametrize("case", ["lap2d", "lap1d_locking_off", "markov", "markov_mag"])
+@pytest.mark.parametrize("case", ["lap2d", "lap1d_locking_off", "markov", "markov_mag", "lap2d_arnoldi", "markov_arnoldi"])
 def test_eps_matches_oracle_driver(be, case):
     """Same start vector, same kernels: the C driver and the oracle driver must take
     the same decisions (restarts, converged count) and agree to rounding."""
     from scipy.sparse import csr_matrix
     kw = dict(nev=5, tol=1e-10)
     herm = True
-    if case == "lap2d":
+    if case in ("lap2d", "lap2d_arnoldi"):
         csr = og.laplacian2d(31, 23)
+        if case.endswith("arnoldi"):
+            kw.update(solver="arnoldi", tol=1e-9)
+    elif case == "markov_arnoldi":
+        csr = og.markov(18)
+        herm = False
+        # explicit restarts from a single Schur vector amplify rounding differences once a
+        # cluster is reached (the 4th and 5th eigenvalues here): three pairs keep both
+        # drivers on the same path
+        kw.update(which="largest_real", tol=1e-10, solver="arnoldi", nev=3)
     elif case == "lap1d_locking_off":
         csr = og.laplacian1d(200)
         kw.update(lock=False, ncv=24)

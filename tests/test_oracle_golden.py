@@ -148,6 +148,27 @@ def test_eps_goldens():
     assert sorted(set(_vals(e, 4)), reverse=True)[:len(distinct)] == distinct
 
 
+def test_eps_goldens_arnoldi():
+    """The explicitly restarted Arnoldi driver against the same golden files, with the
+    arguments of the reference's runtest2_1_arnoldi, runtest4_1_arnoldi, runtest9_1_arnoldi
+    (src/eps/examples/tests/makefile:253-258,294-298,401-407)."""
+    g = golden("eps_tests.json")
+    e = _solve(og.laplacian1d(30), nev=4, solver="arnoldi")
+    assert _vals(e, 4) == g["test2"]["largest"] == g["test4"]["values"]
+    assert all(e.compute_error(i) < 5e-8 for i in range(4))
+    e = _solve(og.laplacian1d(30), nev=4, which="smallest_real", solver="arnoldi")
+    assert _vals(e, 4) == g["test2"]["smallest"]
+    rp, ci, va = og.markov(15)
+    e = _solve((rp, ci, va), hermitian=False, nev=4, ncv=7, max_it=300, solver="arnoldi")
+    key = lambda v: (-round(abs(float(v)), 4), -float(v))       # +1 / -1 tie in magnitude
+    assert sorted(_vals(e, 4), key=key) == sorted(g["test9"]["values"], key=key)
+    v0 = np.zeros(len(rp) - 1)
+    v0[:2] = 1.0
+    e = _solve((rp, ci, va), hermitian=False, v0=v0, nev=4, which="largest_real", solver="arnoldi")
+    assert _vals(e, 4) == g["ex5"]["values"]
+    assert all(e.compute_error(i) < 5e-8 for i in range(4))
+
+
 def test_eps_analytic_spectrum():
     """2-D Laplacian: lambda = 4 - 2cos(i pi/(n+1)) - 2cos(j pi/(m+1)); tol 1e-10 gives 1e-10 agreement."""
     n, m = 40, 33      # non-square grid: no exactly repeated eigenvalues
