@@ -34,7 +34,7 @@ static double opt_real(int argc, char **argv, const char *name, double dflt) {
 static void eps_set_from_options(EPS eps, int argc, char **argv) {
   PetscInt nev, ncv, mpd;
   int it = opt_find(argc, argv, "-eps_type");
-  if (it && it + 1 < argc) CHK(EPSSetType(eps, argv[it + 1]));       /* krylovschur | arnoldi */
+  if (it && it + 1 < argc) CHK(EPSSetType(eps, argv[it + 1]));       /* krylovschur | arnoldi | lanczos */
   CHK(EPSGetDimensions(eps, &nev, &ncv, &mpd));
   nev = (PetscInt)opt_int(argc, argv, "-eps_nev", nev);
   CHK(EPSSetDimensions(eps, nev, (PetscInt)opt_int(argc, argv, "-eps_ncv", 0), (PetscInt)opt_int(argc, argv, "-eps_mpd", 0)));

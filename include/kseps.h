@@ -271,8 +271,10 @@ typedef PetscErrorCode (*EPSMonitorFn)(EPS eps, PetscInt its, PetscInt nconv, Pe
 
 PetscErrorCode EPSCreate(void *ctx, EPS *eps);                                   /* epsbasic.c:60-80 */
 PetscErrorCode EPSSetOperators(EPS eps, Mat A, Mat B);                           /* B must be NULL */
-/* "krylovschur" (default; krylovschur.c, ks-symm.c) or "arnoldi" (explicit restart,
- * src/eps/impls/krylov/arnoldi/arnoldi.c) */
+/* "krylovschur" (default; krylovschur.c, ks-symm.c), "arnoldi" (explicit restart,
+ * src/eps/impls/krylov/arnoldi/arnoldi.c) or "lanczos" (explicit restart, symmetric problems,
+ * full reorthogonalisation: src/eps/impls/krylov/lanczos/lanczos.c with
+ * -eps_lanczos_reorthog full) */
 PetscErrorCode EPSSetType(EPS eps, const char *type);                            /* epsbasic.c */
 PetscErrorCode EPSGetType(EPS eps, const char **type);
 PetscErrorCode EPSSetProblemType(EPS eps, EPSProblemType type);                  /* epsopts.c:946-989 */

@@ -45,7 +45,7 @@ class EPS:
         self.n = int(n_local)
         self.N = int(N if N is not None else n_local)
         self.hermitian = hermitian
-        if solver not in ("krylovschur", "arnoldi"):
+        if solver not in ("krylovschur", "arnoldi", "lanczos"):
             raise ValueError("unknown solver " + solver)
         self.solver = solver
         self.nev, self.ncv, self.mpd = nev, ncv, mpd
@@ -94,7 +94,7 @@ class EPS:
         self.errest = np.zeros(ncv + 1)
         self.perm = np.arange(ncv + 1)
         cmpf = dsmod.COMPARE[self.which]
-        if self.hermitian and self.solver == "krylovschur":
+        if self.hermitian and self.solver in ("krylovschur", "lanczos"):
             self.ds = dsmod.DSHEP(ncv + 1, cmpf)
         else:
             self.ds = dsmod.DSNHEP(ncv + 1, cmpf)
@@ -331,6 +331,95 @@ class EPS:
         ds.set_dimensions(self.nconv, 0, 0)
         ds.set_state(dsmod.STATE_RAW)
 
+    def _solve_lanczos(self):
+        """``EPSSolve_Lanczos`` (src/eps/impls/krylov/lanczos/lanczos.c:543-726) with full
+        reorthogonalisation (``EPSBasicLanczos`` -> ``EPSFullLanczos``, :499-541): explicit
+        restart with the wanted unconverged Ritz vector, converged vectors locked in front."""
+        ds, V = self.ds, self.V
+        ds.extrarow = False
+        ncv = self.ncv
+        ritz = np.zeros(ncv + 1)
+        bnd = np.zeros(ncv + 1)
+        conv = ["N"] * (ncv + 1)
+        perm = np.zeros(ncv + 1, dtype=int)
+        cmpf = dsmod.COMPARE[self.which]
+        macheps = np.finfo(float).eps
+        self._get_start_vector(0)
+        anorm = -1.0
+        nconv = 0
+        while self.reason == ITERATING:
+            self.its += 1
+            n = min(nconv + self.mpd, ncv)
+            d, e = ds.d, ds.e
+            n, breakdown = self._full_lanczos(d, e, nconv, n)
+            beta = e[n - 1]
+            ds.set_dimensions(n, nconv, 0)
+            ds.set_state(dsmod.STATE_INTERMEDIATE)
+            V.set_active_columns(nconv, n)
+            ds.solve(ritz)
+            ds.sort(ritz)
+            for i in range(nconv, n):
+                anorm = max(anorm, abs(ritz[i]))
+            Y = ds.Q
+            for i in range(nconv, n):
+                resnorm = beta * abs(Y[n - 1, i]) + macheps * anorm
+                bnd[i] = resnorm / abs(ritz[i])                    # EPSConvergedRelative
+                conv[i] = "C" if bnd[i] < self.tol else "N"
+            if not breakdown:
+                restart = nconv
+                while restart < n and conv[restart] != "N":
+                    restart += 1
+                if restart >= n:
+                    breakdown = True
+                else:
+                    for i in range(restart + 1, n):
+                        if conv[i] == "N" and cmpf(ritz[restart], 0.0, ritz[i], 0.0) > 0:
+                            restart = i
+                    V.set_active_columns(nconv, n)
+                    V.mult_column(1.0, 0.0, n, np.ascontiguousarray(Y[nconv:n, restart]))
+                    V.set_active_columns(nconv, n)
+            # converged Ritz pairs first
+            for i in range(nconv, n):
+                perm[i] = i
+            k = nconv
+            while k < n:
+                if conv[perm[k]] != "C":
+                    j = k + 1
+                    while j < n and conv[perm[j]] != "C":
+                        j += 1
+                    if j >= n:
+                        break
+                    perm[k], perm[j] = perm[j], perm[k]
+                k += 1
+            for i in range(nconv, k):
+                x = perm[i]
+                if x != i:
+                    j = i + 1
+                    while perm[j] != i:
+                        j += 1
+                    ritz[x], ritz[i] = ritz[i], ritz[x]
+                    bnd[x], bnd[i] = bnd[i], bnd[x]
+                    conv[x], conv[i] = conv[i], conv[x]
+                    perm[j] = x
+                    perm[i] = i
+                    tmp = Y[:n, x].copy()
+                    Y[:n, x] = Y[:n, i]
+                    Y[:n, i] = tmp
+            V.mult_in_place(ds.get_mat_Q(), nconv, k)
+            for i in range(nconv, n):
+                self.eigr[i] = ritz[i]
+                self.errest[i] = bnd[i]
+            nconv = k
+            if self.monitor:
+                self.monitor(self.its, nconv, self.eigr, self.eigi, self.errest, n)
+            self.reason = self._stopping(nconv)
+            if self.reason == ITERATING:
+                V.copy_column(n, nconv)
+                if breakdown:
+                    if self._get_start_vector(nconv):
+                        self.reason = DIVERGED_BREAKDOWN
+        self.nconv = nconv
+
     def solve(self):
         """``EPSSolve`` (epssolve.c:63-146)."""
         self.setup()
@@ -339,6 +428,10 @@ class EPS:
         self.reason = ITERATING
         if self.solver == "arnoldi":
             self._solve_arnoldi()
+        elif self.solver == "lanczos":
+            if not self.hermitian:
+                raise ValueError("Requested method is only available for Hermitian problems")
+            self._solve_lanczos()
         elif self.hermitian:
             self._solve_symm()
         else:
@@ -368,7 +461,7 @@ class EPS:
         if self._vectors_done:
             return
         self._vectors_done = True
-        if self.hermitian and self.solver == "krylovschur":
+        if self.hermitian and self.solver in ("krylovschur", "lanczos"):
             return
         n = self.ds.n
         if n == 0:

@@ -44,12 +44,13 @@ PetscErrorCode EPSSetProblemType(EPS eps, EPSProblemType type) {
   return 0;
 }
 
-/* epsbasic.c (EPSSetType): "krylovschur" (default) or "arnoldi" */
+/* epsbasic.c (EPSSetType): "krylovschur" (default), "arnoldi" or "lanczos" */
 PetscErrorCode EPSSetType(EPS eps, const char *type) {
   if (!eps || !type) SETERRQ(PETSC_ERR_ARG_NULL, "Null argument");
   int t;
   if (!strcmp(type, "krylovschur")) t = 0;
   else if (!strcmp(type, "arnoldi")) t = 1;
+  else if (!strcmp(type, "lanczos")) t = 2;
   else SETERRQ(PETSC_ERR_ARG_UNKNOWN_TYPE, "Unknown EPS type given: %s", type);
   if (t != eps->type) { eps->type = t; eps->state = 0; }
   return 0;
@@ -57,7 +58,7 @@ PetscErrorCode EPSSetType(EPS eps, const char *type) {
 
 PetscErrorCode EPSGetType(EPS eps, const char **type) {
   if (!eps || !type) SETERRQ(PETSC_ERR_ARG_NULL, "Null argument");
-  *type = eps->type == 1 ? "arnoldi" : "krylovschur";
+  *type = eps->type == 1 ? "arnoldi" : eps->type == 2 ? "lanczos" : "krylovschur";
   return 0;
 }
 
@@ -188,6 +189,11 @@ PetscErrorCode EPSSetUp(EPS eps) {
     ierr = DSSetType(eps->ds, "nhep");CHKERRQ(ierr);
     ierr = DSSetCompact(eps->ds, PETSC_FALSE);CHKERRQ(ierr);
     ierr = DSSetExtraRow(eps->ds, PETSC_TRUE);CHKERRQ(ierr);
+  } else if (eps->type == 2) {                     /* EPSSetUp_Lanczos lanczos.c:47-108 */
+    if (!eps->ishermitian) SETERRQ(PETSC_ERR_SUP, "Requested method is only available for Hermitian problems");
+    ierr = DSSetType(eps->ds, "hep");CHKERRQ(ierr);
+    ierr = DSSetCompact(eps->ds, PETSC_TRUE);CHKERRQ(ierr);
+    ierr = DSSetExtraRow(eps->ds, PETSC_FALSE);CHKERRQ(ierr);
   } else if (eps->ishermitian) {
     ierr = DSSetType(eps->ds, "hep");CHKERRQ(ierr);
     ierr = DSSetCompact(eps->ds, PETSC_TRUE);CHKERRQ(ierr);
@@ -482,13 +488,113 @@ static PetscErrorCode EPSSolve_Arnoldi(EPS eps) {
   return 0;
 }
 
+/* lanczos.c:543-726 with full reorthogonalisation (EPSBasicLanczos -> EPSFullLanczos,
+ * lanczos.c:499-541): explicit restart with the wanted unconverged Ritz vector, converged
+ * Ritz vectors locked in front */
+static PetscErrorCode EPSSolve_Lanczos(EPS eps) {
+  PetscErrorCode ierr;
+  PetscInt nconv = 0, i, j, k, l, x, n, restart, ncv = eps->ncv, r, ld;
+  PetscScalar *Y, *ritz, stmp;
+  PetscReal *d, *e, *bnd, anorm = -1.0, beta, rtmp, resnorm;
+  PetscInt *perm;
+  PetscBool breakdown;
+  char *conv, ctmp;
+  ierr = DSGetLeadingDimension(eps->ds, &ld);CHKERRQ(ierr);
+  ritz = (PetscScalar *)calloc((size_t)ncv + 1, sizeof(*ritz));
+  bnd = (PetscReal *)calloc((size_t)ncv + 1, sizeof(*bnd));
+  perm = (PetscInt *)calloc((size_t)ncv + 1, sizeof(*perm));
+  conv = (char *)calloc((size_t)ncv + 1, 1);
+  if (!ritz || !bnd || !perm || !conv) { free(ritz); free(bnd); free(perm); free(conv); SETERRQ(PETSC_ERR_MEM, "Out of memory"); }
+#define LCHK(call) do { ierr = (call); if (ierr) { free(ritz); free(bnd); free(perm); free(conv); return ierr; } } while (0)
+  LCHK(EPSGetStartVector(eps, 0, NULL));
+  while (eps->reason == EPS_CONVERGED_ITERATING) {
+    eps->its++;
+    /* compute an ncv-step Lanczos factorization */
+    n = PetscMin(nconv + eps->mpd, ncv);
+    LCHK(DSGetArrayReal(eps->ds, DS_MAT_T, &d));
+    e = d + ld;
+    LCHK(EPSFullLanczos(eps, d, e, nconv, &n, &breakdown));
+    beta = e[n - 1];
+    LCHK(DSSetDimensions(eps->ds, n, 0, nconv, 0));
+    LCHK(DSSetState(eps->ds, DS_STATE_INTERMEDIATE));
+    LCHK(BVSetActiveColumns(eps->V, nconv, n));
+    /* solve projected problem */
+    LCHK(DSSolve(eps->ds, ritz, NULL));
+    LCHK(DSSort(eps->ds, ritz, NULL, NULL, NULL, NULL));
+    /* estimate ||A||, then residual estimates beta*abs(Y(m,:)) + eps*||A|| */
+    for (i = nconv; i < n; i++) anorm = PetscMax(anorm, fabs(ritz[i]));
+    LCHK(DSGetArray(eps->ds, DS_MAT_Q, &Y));
+    for (i = nconv; i < n; i++) {
+      resnorm = beta * fabs(Y[n - 1 + (size_t)i * ld]) + PETSC_MACHINE_EPSILON * anorm;
+      bnd[i] = resnorm / fabs(ritz[i]);                                     /* EPSConvergedRelative */
+      conv[i] = bnd[i] < eps->tol ? 'C' : 'N';
+    }
+    /* restart vector: the wanted one among the unconverged Ritz vectors */
+    if (!breakdown) {
+      restart = nconv;
+      while (restart < n && conv[restart] != 'N') restart++;
+      if (restart >= n) breakdown = PETSC_TRUE;
+      else {
+        for (i = restart + 1; i < n; i++) {
+          if (conv[i] == 'N') {
+            LCHK(eps->cmp(ritz[restart], 0.0, ritz[i], 0.0, &r, NULL));
+            if (r > 0) restart = i;
+          }
+        }
+        LCHK(BVMultColumn(eps->V, 1.0, 0.0, n, Y + (size_t)restart * ld + nconv));
+      }
+    }
+    /* count and put converged eigenvalues first */
+    for (i = nconv; i < n; i++) perm[i] = i;
+    for (k = nconv; k < n; k++) {
+      if (conv[perm[k]] != 'C') {
+        j = k + 1;
+        while (j < n && conv[perm[j]] != 'C') j++;
+        if (j >= n) break;
+        l = perm[k]; perm[k] = perm[j]; perm[j] = l;
+      }
+    }
+    /* sort eigenvectors according to the permutation */
+    for (i = nconv; i < k; i++) {
+      x = perm[i];
+      if (x != i) {
+        j = i + 1;
+        while (perm[j] != i) j++;
+        stmp = ritz[x]; ritz[x] = ritz[i]; ritz[i] = stmp;
+        rtmp = bnd[x]; bnd[x] = bnd[i]; bnd[i] = rtmp;
+        ctmp = conv[x]; conv[x] = conv[i]; conv[i] = ctmp;
+        perm[j] = x; perm[i] = i;
+        for (l = 0; l < n; l++) { stmp = Y[l + (size_t)x * ld]; Y[l + (size_t)x * ld] = Y[l + (size_t)i * ld]; Y[l + (size_t)i * ld] = stmp; }
+      }
+    }
+    /* compute converged eigenvectors */
+    LCHK(UpdateBasis(eps, DS_MAT_Q, nconv, k));
+    /* store ritz values and estimated errors */
+    for (i = nconv; i < n; i++) { eps->eigr[i] = ritz[i]; eps->errest[i] = bnd[i]; }
+    nconv = k;
+    if (eps->monitor) LCHK(eps->monitor(eps, eps->its, nconv, eps->eigr, eps->eigi, eps->errest, n, eps->monitorctx));
+    EPSStoppingBasic(eps, eps->its, eps->max_it, nconv, eps->nev, &eps->reason);
+    if (eps->reason == EPS_CONVERGED_ITERATING) {       /* copy restart vector */
+      LCHK(BVCopyColumn(eps->V, n, nconv));
+      if (breakdown) {                                  /* use a random vector for restarting */
+        LCHK(EPSGetStartVector(eps, nconv, &breakdown));
+        if (breakdown) eps->reason = EPS_DIVERGED_BREAKDOWN;
+      }
+    }
+  }
+  eps->nconv = nconv;
+#undef LCHK
+  free(ritz); free(bnd); free(perm); free(conv);
+  return 0;
+}
+
 static PetscErrorCode EPSComputeVectors(EPS eps) {
   PetscErrorCode ierr;
   PetscInt n;
   EPSCheckSolved(eps);
   if (eps->state == 3) return 0;
   eps->state = 3;
-  if (eps->ishermitian && eps->type == 0) return 0;   /* Lanczos vectors are the eigenvectors of a standard HEP */
+  if (eps->ishermitian && eps->type != 1) return 0;   /* Lanczos vectors are the eigenvectors of a standard HEP */
   ierr = DSGetDimensions(eps->ds, &n, NULL, NULL, NULL, NULL);CHKERRQ(ierr);
   if (!n) return 0;
   ierr = DSVectors(eps->ds, DS_MAT_X, NULL, NULL);CHKERRQ(ierr);        /* right eigenvectors of T */
@@ -509,6 +615,7 @@ PetscErrorCode EPSSolve(EPS eps) {
   eps->reason = EPS_CONVERGED_ITERATING;
   for (i = 0; i < eps->ncv; i++) { eps->eigr[i] = 0.0; eps->eigi[i] = 0.0; eps->errest[i] = 0.0; eps->perm[i] = i; }
   if (eps->type == 1) { ierr = EPSSolve_Arnoldi(eps);CHKERRQ(ierr); }
+  else if (eps->type == 2) { ierr = EPSSolve_Lanczos(eps);CHKERRQ(ierr); }
   else if (eps->ishermitian) { ierr = EPSSolve_KrylovSchur_Symm(eps);CHKERRQ(ierr); }
   else { ierr = EPSSolve_KrylovSchur_Default(eps);CHKERRQ(ierr); }
   eps->state = 2;

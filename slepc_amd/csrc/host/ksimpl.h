@@ -41,7 +41,7 @@ struct _p_EPS {
   BV V;
   DS ds;
   EPSProblemType problem_type;
-  int type;                 /* 0 krylovschur (default), 1 arnoldi */
+  int type;                 /* 0 krylovschur (default), 1 arnoldi, 2 lanczos (full reorthogonalisation) */
   PetscBool ishermitian;
   PetscInt nev, ncv, mpd, max_it;
   PetscInt64 n, nloc;

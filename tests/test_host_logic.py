@@ -268,17 +268,19 @@ def test_eps_goldens(be):
     assert _fmt(r["values"], 4) == g["test2"]["smallest"]
 
 
-@pytest.mark.parametrize("case", ["lap2d", "lap1d_locking_off", "markov", "markov_mag", "lap2d_arnoldi", "markov_arnoldi"])
+@pytest.mark.parametrize("case", ["lap2d", "lap1d_locking_off", "markov", "markov_mag", "lap2d_arnoldi", "markov_arnoldi", "lap2d_lanczos"])
 def test_eps_matches_oracle_driver(be, case):
     """Same start vector, same kernels: the C driver and the oracle driver must take
     the same decisions (restarts, converged count) and agree to rounding."""
     from scipy.sparse import csr_matrix
     kw = dict(nev=5, tol=1e-10)
     herm = True
-    if case in ("lap2d", "lap2d_arnoldi"):
+    if case in ("lap2d", "lap2d_arnoldi", "lap2d_lanczos"):
         csr = og.laplacian2d(31, 23)
         if case.endswith("arnoldi"):
             kw.update(solver="arnoldi", tol=1e-9)
+        elif case.endswith("lanczos"):
+            kw.update(solver="lanczos", tol=1e-9)
     elif case == "markov_arnoldi":
         csr = og.markov(18)
         herm = False

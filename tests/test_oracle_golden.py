@@ -169,6 +169,28 @@ def test_eps_goldens_arnoldi():
     assert all(e.compute_error(i) < 5e-8 for i in range(4))
 
 
+def test_eps_goldens_lanczos():
+    """Explicitly restarted Lanczos with full reorthogonalisation against the golden files of
+    the reference's runtest2_2_full, runtest4_1_lanczos, runtest8_1_lanczos
+    (src/eps/examples/tests/makefile:260-265,294-298,374-383)."""
+    g = golden("eps_tests.json")
+    e = _solve(og.laplacian1d(30), nev=4, solver="lanczos")
+    assert _vals(e, 4) == g["test2"]["largest"] == g["test4"]["values"]
+    assert all(e.compute_error(i) < 5e-8 for i in range(4))
+    e = _solve(og.laplacian1d(30), nev=4, which="smallest_real", solver="lanczos")
+    assert _vals(e, 4) == g["test2"]["smallest"]
+    # the 72 x 72 grid has double eigenvalues (7.99074 twice); restarted Lanczos with full
+    # reorthogonalisation finds both copies, the golden Krylov-Schur run lists one: compare
+    # the distinct values
+    e = _solve(og.laplacian2d(72), nev=4, ncv=20, solver="lanczos")
+    assert sorted(set(_vals(e, 4)), reverse=True) == g["ex2"]["values"][:3]
+    # test8: full reorthogonalisation with explicit restarts does find both copies of 7.88881
+    e = _solve(og.laplacian2d(20), nev=4, ncv=11, solver="lanczos")
+    assert _vals(e, 4) == g["test8"]["values"]
+    with pytest.raises(ValueError):
+        _solve(og.markov(6), hermitian=False, solver="lanczos")
+
+
 def test_eps_analytic_spectrum():
     """2-D Laplacian: lambda = 4 - 2cos(i pi/(n+1)) - 2cos(j pi/(m+1)); tol 1e-10 gives 1e-10 agreement."""
     n, m = 40, 33      # non-square grid: no exactly repeated eigenvalues
