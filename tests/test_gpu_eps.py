@@ -72,7 +72,7 @@ CASES = {
     "markov_120": (lambda: mg.markov(120), False, dict(nev=6, which="largest_real", tol=1e-12)),
     # explicitly restarted Arnoldi (arnoldi.c) on the same kernels
     "lap2d_60x45_arnoldi": (lambda: mg.laplacian2d(60, 45), True, dict(nev=4, tol=1e-9, solver="arnoldi")),
-    "lap2d_60x45_lanczos": (lambda: mg.laplacian2d(60, 45), True, dict(nev=4, tol=1e-9, solver="lanczos")),
+    "lap2d_60x45_lanczos": (lambda: mg.laplacian2d(60, 45), True, dict(nev=4, ncv=40, tol=1e-9, solver="lanczos")),
     "markov_60_arnoldi": (lambda: mg.markov(60), False, dict(nev=4, which="largest_real", tol=1e-10, solver="arnoldi")),
 }
 
