@@ -45,8 +45,9 @@ static void eps_set_from_options(EPS eps, int argc, char **argv) {
   if (opt_find(argc, argv, "-eps_smallest_real")) CHK(EPSSetWhichEigenpairs(eps, EPS_SMALLEST_REAL));
 }
 
-/* the report of EPSErrorView(eps,EPS_ERROR_RELATIVE,NULL) */
-static void eps_report(EPS eps) {
+/* the report of EPSErrorView(eps,EPS_ERROR_RELATIVE,NULL), after the solver lines the
+ * tutorials print; `stopping` adds the line with the tolerance and the restart cap */
+static void eps_report_ex(EPS eps, int stopping) {
   PetscInt nev, ncv, mpd, nconv, its, maxit;
   PetscReal tol, err;
   CHK(EPSGetDimensions(eps, &nev, &ncv, &mpd));
@@ -57,6 +58,7 @@ static void eps_report(EPS eps) {
   CHK(EPSGetType(eps, &type));
   printf(" Solution method: %s\n\n", type);
   printf(" Number of requested eigenvalues: %d\n", (int)nev);
+  if (stopping) printf(" Stopping condition: tol=%.4g, maxit=%d\n", tol, (int)maxit);
   if (nconv < nev) {
     printf(" Problem: less than %d eigenvalues converged\n\n", (int)nev);
     return;
@@ -80,4 +82,5 @@ static void eps_report(EPS eps) {
   printf("\n\n");
   if (getenv("KS_EXAMPLE_VERBOSE")) fprintf(stderr, "restarts %d\n", (int)its);
 }
+static void eps_report(EPS eps) { eps_report_ex(eps, 0); }
 #endif

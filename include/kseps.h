@@ -46,6 +46,10 @@ typedef int PetscBool;
 #define PETSC_ERR_PLIB           77
 #define PETSC_ERR_USER           83
 #define PETSC_ERR_ARG_UNKNOWN_TYPE 86
+#define PETSC_ERR_FILE_OPEN      65
+#define PETSC_ERR_FILE_READ      66
+#define PETSC_ERR_FILE_WRITE     67
+#define PETSC_ERR_FILE_UNEXPECTED 79
 
 const char *KSGetLastError(void);
 
@@ -110,6 +114,10 @@ struct _MatOps {
   PetscErrorCode (*mult)(Mat A, Vec x, Vec y);
   PetscErrorCode (*createvecs)(Mat A, Vec *right, Vec *left);
   PetscErrorCode (*destroy)(Mat A);
+  /* optional (may be NULL): *norm = ||A*xr - kr*xr + ki*xi||_2 in one pass, xi may be NULL;
+   * `work` is a scratch vector the operator may use.  EPSComputeError falls back to
+   * MatMult + VecAXPY + VecNorm (epssolve.c:506-556) without it. */
+  PetscErrorCode (*residualnorm)(Mat A, PetscScalar kr, PetscScalar ki, Vec xr, Vec xi, Vec work, PetscReal *norm);
 };
 struct _p_Mat {
   struct _MatOps ops;
@@ -128,6 +136,19 @@ PetscErrorCode MatCreateShell(void *ctx, PetscInt64 n, PetscInt64 N, PetscInt64 
                               PetscErrorCode (*mult)(Mat, Vec, Vec),
                               PetscErrorCode (*createvecs)(Mat, Vec *, Vec *), Mat *A);
 PetscErrorCode MatShellGetContext(Mat A, void **user);
+/* PETSc binary matrix files (the format MatLoad reads and MatView writes on a
+ * PetscViewerBinary; src/eps/examples/tutorials/ex4.c:56-60 loads the files of
+ * share/slepc/datafiles/matrices this way).  KSMatReadPetscBinary returns the whole
+ * matrix in CSR on the host, every row in ascending column order; the three arrays are
+ * released with KSFree.  MatLoadAIJHIP gives rank `rank` of `nranks` its contiguous row
+ * block (the first M mod nranks ranks hold one row more, as MatLoad distributes them)
+ * as a device operator. */
+PetscErrorCode KSMatReadPetscBinary(const char *filename, PetscInt64 *M, PetscInt64 *N, int64_t **rowptr,
+                                    int32_t **colidx, double **val);
+PetscErrorCode KSMatWritePetscBinary(const char *filename, PetscInt64 M, PetscInt64 N, const int64_t *rowptr,
+                                     const int32_t *colidx, const double *val);
+void KSFree(void *p);
+PetscErrorCode MatLoadAIJHIP(ksg_ctx ctx, const char *filename, int rank, int nranks, Mat *A);
 PetscErrorCode MatMult(Mat A, Vec x, Vec y);
 PetscErrorCode MatCreateVecs(Mat A, Vec *right, Vec *left);
 PetscErrorCode MatGetSize(Mat A, PetscInt64 *M, PetscInt64 *N);

@@ -173,6 +173,13 @@ int ksg_mat_destroy(ksg_mat A);
 /* y = A*x on device vectors of n_local entries; collective when nranks > 1
  * (MatMult as called by STApply_Shift, shift.c:38). */
 int ksg_mat_mult(ksg_mat A, const double *x_dev, double *y_dev);
+/* *norm = ||A*x - kr*x + ki*xi||_2 over all ranks; xi may be NULL (then ki is ignored).
+ * The residual of an eigenpair as EPSComputeResidualNorm_Private forms it
+ * (src/eps/interface/epssolve.c:506-556: MatMult, VecAXPY, VecNorm) in one pass over the
+ * matrix that stores nothing.  With nranks > 1 `work` (n_local entries, distinct from x and
+ * xi) receives A*x first; with one rank it is not touched and may be NULL.  Collective. */
+int ksg_mat_residual_norm(ksg_mat A, double kr, double ki, const double *x_dev, const double *xi_dev,
+                          double *work_dev, double *norm);
 int ksg_mat_sizes(ksg_mat A, int64_t *n_local, int64_t *N, int64_t *row0, int64_t *nnz_local);
 /* Kernel-selection report: number of row tiles handled by the row-per-thread
  * stream path, the grouped (several lanes per row) path and the long-row path,

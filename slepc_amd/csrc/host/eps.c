@@ -711,6 +711,18 @@ static PetscErrorCode EPSComputeResidualNorm_Private(EPS eps, PetscScalar kr, Pe
   PetscErrorCode ierr;
   Vec u = z[0], v = z[1], w = z[2];
   PetscReal ni, nr;
+  if (eps->A->ops.residualnorm) {
+    /* the operator forms the same residuals in one pass each, storing nothing */
+    if (ki == 0 || fabs(ki) < fabs(kr * PETSC_MACHINE_EPSILON)) {
+      ierr = eps->A->ops.residualnorm(eps->A, fabs(kr) > PETSC_MACHINE_EPSILON ? kr : 0.0, 0.0, xr, NULL, u, norm);CHKERRQ(ierr);
+    } else {
+      const PetscBool sh = SlepcAbsEigenvalue(kr, ki) > PETSC_MACHINE_EPSILON;
+      ierr = eps->A->ops.residualnorm(eps->A, sh ? kr : 0.0, sh ? ki : 0.0, xr, xi, u, &nr);CHKERRQ(ierr);
+      ierr = eps->A->ops.residualnorm(eps->A, sh ? kr : 0.0, sh ? -ki : 0.0, xi, xr, u, &ni);CHKERRQ(ierr);
+      *norm = SlepcAbsEigenvalue(nr, ni);
+    }
+    return 0;
+  }
   if (ki == 0 || fabs(ki) < fabs(kr * PETSC_MACHINE_EPSILON)) {
     ierr = MatMult(eps->A, xr, u);CHKERRQ(ierr);                       /* u=A*x */
     if (fabs(kr) > PETSC_MACHINE_EPSILON) {

@@ -42,6 +42,12 @@ __global__ __launch_bounds__(KSG_BLOCK) void k_reduce_partials(const double *__r
   }
 }
 
+int ksg_launch_reduce_sum(ksg_ctx c, const double *partial, int nb, int ncols, double *d_out) {
+  hipLaunchKernelGGL((k_reduce_partials<0>), dim3(ncols), dim3(KSG_BLOCK), 0, c->stream, partial, nb, d_out);
+  KSG_HIP(hipGetLastError());
+  return KSG_OK;
+}
+
 /* ------------------------------------------------------------------------ */
 /* streaming loads                                                            */
 /* ------------------------------------------------------------------------ */

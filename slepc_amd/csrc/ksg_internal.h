@@ -148,6 +148,8 @@ int ksg_ensure_work(ksg_ctx ctx, size_t doubles);
 /* reductions used by several files: sum over `nb` partials per column */
 int ksg_launch_dotvec(ksg_ctx ctx, const double *X, int64_t ld, int k, const double *y,
                       int64_t n, double *d_out);
+/* out[col] = sum of partial[col*nb .. col*nb+nb) in a fixed order */
+int ksg_launch_reduce_sum(ksg_ctx ctx, const double *partial, int nb, int ncols, double *d_out);
 int ksg_launch_sumsq(ksg_ctx ctx, const double *X, int64_t ld, int ncols, int64_t n, double *d_out);
 
 static inline int ksg_grid_for(int64_t work_items) {

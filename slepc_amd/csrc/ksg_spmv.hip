@@ -39,15 +39,37 @@ __device__ __forceinline__ void fence_i(int32_t &v) { asm volatile("" : "+v"(v))
 
 #define KSG_TILE_PER_THREAD (KSG_TILE_NNZ / KSG_BLOCK)    /* entries of a tile per thread: 8 */
 
+/* RES = 0: y = A x.  RES = 1: nothing is stored; every row's sum goes into the residual
+ * r = (A x)_row - kr x_row + ki xi_row (xi may be NULL) and the workgroup leaves the sum
+ * of r^2 over its rows in partial[blockIdx.x] -- the norm EPSComputeResidualNorm_Private
+ * (src/eps/interface/epssolve.c:506-556) needs, without materialising A x. */
+template <int RES>
+__device__ __forceinline__ void spmv_emit(double s, int row, const double *__restrict__ x, double *__restrict__ y,
+                                          double kr, double ki, const double *__restrict__ xi, double &acc, bool nt) {
+  if (RES) {
+    double r = fma(-kr, x[row], s);
+    if (xi) r = fma(ki, xi[row], r);
+    acc = fma(r, r, acc);
+  } else if (nt) {
+    __builtin_nontemporal_store(s, &y[row]);
+  } else {
+    y[row] = s;
+  }
+}
+
+template <int RES>
 __global__ __launch_bounds__(KSG_BLOCK) void k_spmv_tiles(const int32_t *__restrict__ tiles,
                                                            const int64_t *__restrict__ tile_p,
                                                            const int64_t *__restrict__ rowptr,
                                                            const int32_t *__restrict__ colidx,
                                                            const double *__restrict__ val,
                                                            const double *__restrict__ x,
-                                                           double *__restrict__ y) {
+                                                           double *__restrict__ y, double kr, double ki,
+                                                           const double *__restrict__ xi,
+                                                           double *__restrict__ partial) {
   __shared__ double prod[KSG_TILE_NNZ];
   __shared__ double red[KSG_BLOCK / 64];
+  double acc = 0.0;
   /* row and entry ranges of the tile come from two independent tables (no dependent
    * load of rowptr[tiles[b]] before the streaming can start) */
   const int r0 = tiles[blockIdx.x], r1 = tiles[blockIdx.x + 1];
@@ -86,7 +108,8 @@ __global__ __launch_bounds__(KSG_BLOCK) void k_spmv_tiles(const int32_t *__restr
       double s = red[0];
 #pragma unroll
       for (int w = 1; w < KSG_BLOCK / 64; w++) s += red[w];
-      y[r0] = s;
+      spmv_emit<RES>(s, r0, x, y, kr, ki, xi, acc, false);
+      if (RES) partial[blockIdx.x] = acc;
     }
     return;
   }
@@ -141,7 +164,7 @@ __global__ __launch_bounds__(KSG_BLOCK) void k_spmv_tiles(const int32_t *__restr
         const int b = (int)(rb[j] - p0), e = (int)(re[j] - p0);
         double s = 0.0;
         for (int t = b; t < e; t++) s += prod[t];
-        __builtin_nontemporal_store(s, &y[r0 + lr]);
+        spmv_emit<RES>(s, r0 + lr, x, y, kr, ki, xi, acc, true);
       }
     }
   } else {
@@ -156,7 +179,44 @@ __global__ __launch_bounds__(KSG_BLOCK) void k_spmv_tiles(const int32_t *__restr
       for (int t = b + g; t < e; t += G) s += prod[t];
     }
     s = wave_sum_width(s, G);
-    if (lr < nrows && g == 0) y[r0 + lr] = s;
+    if (lr < nrows && g == 0) spmv_emit<RES>(s, r0 + lr, x, y, kr, ki, xi, acc, false);
+  }
+  if (RES) {
+    /* sum of the squared residuals of the tile, in a fixed order */
+    __syncthreads();                                   /* prod is dead: red is free again */
+    acc = wave_sum_width(acc, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      double t = red[0];
+#pragma unroll
+      for (int w = 1; w < KSG_BLOCK / 64; w++) t += red[w];
+      partial[blockIdx.x] = t;
+    }
+  }
+}
+
+/* sum over the rows of (u - kr x + ki xi)^2, one partial per workgroup (the residual norm
+ * when A x had to be completed by a halo exchange first) */
+__global__ __launch_bounds__(KSG_BLOCK) void k_resnorm(const double *__restrict__ u, const double *__restrict__ x,
+                                                        const double *__restrict__ xi, double kr, double ki,
+                                                        int64_t n, double *__restrict__ partial) {
+  __shared__ double red[KSG_BLOCK / 64];
+  const int64_t stride = (int64_t)gridDim.x * KSG_BLOCK;
+  double acc = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * KSG_BLOCK + threadIdx.x; i < n; i += stride) {
+    double r = fma(-kr, x[i], u[i]);
+    if (xi) r = fma(ki, xi[i], r);
+    acc = fma(r, r, acc);
+  }
+  acc = wave_sum_width(acc, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = red[0];
+#pragma unroll
+    for (int w = 1; w < KSG_BLOCK / 64; w++) t += red[w];
+    partial[blockIdx.x] = t;
   }
 }
 
@@ -433,8 +493,9 @@ static int mat_mult_raw(ksg_mat A, const double *x, double *y) {
       hipLaunchKernelGGL(k_gather, dim3(ksg_grid_for(A->nsend)), dim3(KSG_BLOCK), 0, c->comm_stream, x, A->d_send_idx, A->d_send, A->nsend);
   }
   if (A->diag.ntiles)
-    hipLaunchKernelGGL(k_spmv_tiles, dim3((unsigned)A->diag.ntiles), dim3(KSG_BLOCK), 0, c->stream,
-                       A->diag.tiles, A->diag.tile_p, A->diag.rowptr, A->diag.colidx, A->diag.val, x, y);
+    hipLaunchKernelGGL(k_spmv_tiles<0>, dim3((unsigned)A->diag.ntiles), dim3(KSG_BLOCK), 0, c->stream,
+                       A->diag.tiles, A->diag.tile_p, A->diag.rowptr, A->diag.colidx, A->diag.val, x, y, 0.0, 0.0,
+                       (const double *)NULL, (double *)NULL);
   KSG_HIP(hipGetLastError());
   if (halo) {
     KSG_CHK(ksg_comm_exchange(c, A));
@@ -460,6 +521,45 @@ extern "C" int ksg_mat_mult(ksg_mat A, const double *x, double *y) {
   KSG_CHK(ksg_op_begin(c, KSG_EV_MATMULT));
   KSG_CHK(mat_mult_raw(A, x, y));
   return ksg_op_end(c, KSG_EV_MATMULT, spmv_bytes(A), 2.0 * (double)A->nnz);
+}
+
+/* ||A x - kr x + ki xi||_2 over all ranks (xi may be NULL).  One rank: a single pass over
+ * the matrix, nothing stored.  Several ranks: A x into `work` (halo exchange included), then
+ * one pass over work, x, xi. */
+extern "C" int ksg_mat_residual_norm(ksg_mat A, double kr, double ki, const double *x, const double *xi,
+                                     double *work, double *norm) {
+  if (!A || !norm) KSG_FAIL(KSG_ERR_ARG, "ksg_mat_residual_norm: NULL argument");
+  if (A->n && !x) KSG_FAIL(KSG_ERR_ARG, "ksg_mat_residual_norm: NULL vector");
+  ksg_ctx c = A->ctx;
+  const bool halo = c->nranks > 1;
+  if (halo && A->n && (!work || work == x || work == xi)) KSG_FAIL(KSG_ERR_ARG, "ksg_mat_residual_norm: a separate work vector is needed with several ranks");
+  KSG_CHK(ksg_op_begin(c, KSG_EV_MATMULT));
+  int nb = 0;
+  if (!halo) {
+    nb = (int)A->diag.ntiles;
+    if (nb) {
+      KSG_CHK(ksg_ensure_partial(c, (size_t)nb));
+      hipLaunchKernelGGL(k_spmv_tiles<1>, dim3((unsigned)nb), dim3(KSG_BLOCK), 0, c->stream, A->diag.tiles, A->diag.tile_p,
+                         A->diag.rowptr, A->diag.colidx, A->diag.val, x, (double *)NULL, kr, ki, xi, c->d_partial);
+    }
+  } else {
+    KSG_CHK(mat_mult_raw(A, x, work));
+    nb = A->n ? ksg_grid_for(A->n) : 0;
+    if (nb) {
+      KSG_CHK(ksg_ensure_partial(c, (size_t)nb));
+      hipLaunchKernelGGL(k_resnorm, dim3(nb), dim3(KSG_BLOCK), 0, c->stream, work, x, xi, kr, ki, A->n, c->d_partial);
+    }
+  }
+  KSG_HIP(hipGetLastError());
+  if (nb) { KSG_CHK(ksg_launch_reduce_sum(c, c->d_partial, nb, 1, c->d_red)); }
+  else KSG_HIP(hipMemsetAsync(c->d_red, 0, sizeof(double), c->stream));
+  const double bytes = 12.0 * (double)A->nnz + 8.0 * (double)(A->n + 1) + 8.0 * (double)(A->n + A->nghost) +
+                       (xi ? 8.0 * (double)A->n : 0.0) + (halo ? 16.0 * (double)A->n : 0.0);
+  KSG_CHK(ksg_op_end(c, KSG_EV_MATMULT, bytes, 2.0 * (double)A->nnz + 5.0 * (double)A->n));
+  double s = 0.0;
+  KSG_CHK(ksg_comm_allreduce(c, c->d_red, &s, 1, 0));
+  *norm = sqrt(s);
+  return KSG_OK;
 }
 
 extern "C" int ksg_bv_matmult(ksg_bv V, ksg_mat A, ksg_bv W) {

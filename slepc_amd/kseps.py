@@ -76,10 +76,12 @@ MatP = C.POINTER(MatStruct)
 MATMULT_FN = C.CFUNCTYPE(Err, MatP, VecP, VecP)
 MATVECS_FN = C.CFUNCTYPE(Err, MatP, C.POINTER(VecP), C.POINTER(VecP))
 MATDESTROY_FN = C.CFUNCTYPE(Err, MatP)
+MATRESNORM_FN = C.CFUNCTYPE(Err, MatP, C.c_double, C.c_double, VecP, VecP, VecP, c_dp)
 
 
 class MatOps(C.Structure):
-    _fields_ = [("mult", MATMULT_FN), ("createvecs", MATVECS_FN), ("destroy", MATDESTROY_FN)]
+    _fields_ = [("mult", MATMULT_FN), ("createvecs", MATVECS_FN), ("destroy", MATDESTROY_FN),
+                ("residualnorm", MATRESNORM_FN)]
 
 
 MatStruct._fields_ = [("ops", MatOps), ("n", c_i64), ("N", c_i64), ("row0", c_i64),
@@ -147,6 +149,10 @@ SIGNATURES = {
     "MatCreateAIJHIP": (Err, [vp, c_i64, c_i64, c_i64, vp, vp, vp, C.POINTER(MatP)]),
     "MatCreateShell": (Err, [vp, c_i64, c_i64, c_i64, vp, MATMULT_FN, MATVECS_FN, C.POINTER(MatP)]),
     "MatShellGetContext": (Err, [MatP, C.POINTER(vp)]),
+    "KSMatReadPetscBinary": (Err, [C.c_char_p, C.POINTER(c_i64), C.POINTER(c_i64), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]),
+    "KSMatWritePetscBinary": (Err, [C.c_char_p, c_i64, c_i64, vp, vp, vp]),
+    "KSFree": (None, [vp]),
+    "MatLoadAIJHIP": (Err, [vp, C.c_char_p, C.c_int, C.c_int, C.POINTER(MatP)]),
     "MatMult": (Err, [MatP, VecP, VecP]),
     "MatCreateVecs": (Err, [MatP, C.POINTER(VecP), C.POINTER(VecP)]),
     "MatGetSize": (Err, [MatP, C.POINTER(c_i64), C.POINTER(c_i64)]),
@@ -335,6 +341,14 @@ class Mat:
                                   ci.ctypes.data, va.ctypes.data, C.byref(p)))
         return cls(p, lib)
 
+    @classmethod
+    def load_aij_hip(cls, ctx, filename, rank=0, nranks=1):
+        """MatLoad of a PETSc binary file onto the device (row block of `rank`)."""
+        lib = load()
+        p = MatP()
+        check(lib.MatLoadAIJHIP(ctx.h, os.fsencode(filename), rank, nranks, C.byref(p)))
+        return cls(p, lib)
+
     def create_vecs(self):
         r = VecP()
         check(self.lib.MatCreateVecs(self.p, C.byref(r), None))
@@ -351,6 +365,32 @@ class Mat:
         if self.p:
             check(self.lib.MatDestroy(C.byref(self.p)))
             self.p = None
+
+
+def read_petsc_binary(filename):
+    """(M, N, rowptr, colidx, val) of a PETSc binary matrix file, read by the C library."""
+    lib = load()
+    M, N = c_i64(), c_i64()
+    rp, ci, va = vp(), vp(), vp()
+    check(lib.KSMatReadPetscBinary(os.fsencode(filename), C.byref(M), C.byref(N), C.byref(rp), C.byref(ci), C.byref(va)))
+    try:
+        m = M.value
+        rowptr = np.ctypeslib.as_array(C.cast(rp, C.POINTER(c_i64)), shape=(m + 1,)).copy()
+        nz = int(rowptr[m])
+        colidx = np.ctypeslib.as_array(C.cast(ci, C.POINTER(C.c_int32)), shape=(max(nz, 1),))[:nz].copy()
+        val = np.ctypeslib.as_array(C.cast(va, C.POINTER(C.c_double)), shape=(max(nz, 1),))[:nz].copy()
+    finally:
+        for q in (rp, ci, va):
+            lib.KSFree(q)
+    return m, N.value, rowptr, colidx, val
+
+
+def write_petsc_binary(filename, M, N, rowptr, colidx, val):
+    lib = load()
+    rp = np.ascontiguousarray(rowptr, dtype=np.int64)
+    ci = np.ascontiguousarray(colidx, dtype=np.int32)
+    va = np.ascontiguousarray(val, dtype=np.float64)
+    check(lib.KSMatWritePetscBinary(os.fsencode(filename), M, N, rp.ctypes.data, ci.ctypes.data, va.ctypes.data))
 
 
 class EPS:

@@ -88,6 +88,8 @@ SIGNATURES = {
                                      C.c_void_p, C.POINTER(C.c_void_p)]),
     "ksg_mat_destroy": (C.c_int, [C.c_void_p]),
     "ksg_mat_mult": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ksg_mat_residual_norm": (C.c_int, [C.c_void_p, C.c_double, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p,
+                                        C.POINTER(C.c_double)]),
     "ksg_mat_sizes": (C.c_int, [C.c_void_p, C.POINTER(c_i64), C.POINTER(c_i64), C.POINTER(c_i64),
                                 C.POINTER(c_i64)]),
     "ksg_mat_info": (C.c_int, [C.c_void_p, C.POINTER(c_i64)]),
@@ -369,6 +371,12 @@ class DeviceCSR:
 
     def mult(self, x_dev, y_dev):
         check(self.lib.ksg_mat_mult(self.h, x_dev, y_dev))
+
+    def residual_norm(self, kr, ki, x_dev, xi_dev=None, work_dev=None):
+        """||A x - kr x + ki xi||_2 (device pointers; xi and work may be None)."""
+        r = C.c_double()
+        check(self.lib.ksg_mat_residual_norm(self.h, kr, ki, x_dev, xi_dev, work_dev, C.byref(r)))
+        return r.value
 
     def info(self):
         a = (c_i64 * 4)()

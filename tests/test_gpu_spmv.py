@@ -104,3 +104,39 @@ def test_edge_cases(gpu_ctx):
     assert np.array_equal(y, [10.0])
     with pytest.raises(ksgpu.KsgError):
         ksgpu.DeviceCSR(gpu_ctx, np.array([0, 1], dtype=np.int64), np.array([5], dtype=np.int32), np.array([1.0]))
+
+
+@pytest.mark.parametrize("gen", ["lap2d", "markov", "rmat"])
+def test_fused_residual_norm(gpu_ctx, gen):
+    """ksg_mat_residual_norm (one pass, nothing stored) against MatMult + AXPY + norm on the
+    host in extended precision: real shift, complex pair, zero shift."""
+    from scipy.sparse import csr_matrix
+    from slepc_amd import ksgpu, matgen as mg
+    if gen == "lap2d":
+        rp, ci, va = mg.laplacian2d(211, 97)
+    elif gen == "markov":
+        rp, ci, va = mg.markov(70)
+    else:
+        rp, ci, va = mg.rmat_laplacian(14, 8, seed=3)      # hub rows: grouped and long-row tiles
+    n = len(rp) - 1
+    ctx = gpu_ctx
+    A = ksgpu.DeviceCSR(ctx, rp, ci, va)
+    rng = np.random.default_rng(11)
+    xr, xi = rng.standard_normal(n), rng.standard_normal(n)
+    dx, dxi = ctx.vec_alloc(n), ctx.vec_alloc(n)
+    ctx.upload(dx, xr)
+    ctx.upload(dxi, xi)
+    S = csr_matrix((va, ci, rp), shape=(n, n))
+    axr = (S @ xr).astype(np.longdouble)
+    for kr, ki, use_xi in ((3.25, 0.0, False), (-1.5, 0.75, True), (0.0, 0.0, False)):
+        ref = axr - np.longdouble(kr) * xr
+        if use_xi:
+            ref = ref + np.longdouble(ki) * xi
+        want = float(np.sqrt(np.sum(ref * ref)))
+        got = A.residual_norm(kr, ki, dx, dxi if use_xi else None)
+        assert abs(got - want) <= 1e-12 * want
+        # the same call twice gives the same bits (fixed reduction order)
+        assert got == A.residual_norm(kr, ki, dx, dxi if use_xi else None)
+    ctx.vec_free(dx)
+    ctx.vec_free(dxi)
+    A.destroy()
