@@ -305,6 +305,10 @@ PetscErrorCode EPSSetWhichEigenpairs(EPS eps, EPSWhich which);
 PetscErrorCode EPSSetInitialSpace(EPS eps, PetscInt n, Vec *is);                 /* epssetup.c:449-460 */
 PetscErrorCode EPSKrylovSchurSetRestart(EPS eps, PetscReal keep);                /* krylovschur.c:290 */
 PetscErrorCode EPSKrylovSchurSetLocking(EPS eps, PetscBool lock);
+/* Arnoldi with delayed reorthogonalisation (-eps_arnoldi_delayed, arnoldi.c:168-175;
+ * EPSDelayedArnoldi / EPSDelayedArnoldi1 of epskrylov.c:82-233, the latter when the BV
+ * refinement is BV_ORTHOG_REFINE_NEVER).  As the reference warns, it may be unstable. */
+PetscErrorCode EPSArnoldiSetDelayed(EPS eps, PetscBool delayed);
 PetscErrorCode EPSMonitorSet(EPS eps, EPSMonitorFn monitor, void *ctx);
 PetscErrorCode EPSGetBV(EPS eps, BV *bv);
 PetscErrorCode EPSGetDS(EPS eps, DS *ds);

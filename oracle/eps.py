@@ -11,7 +11,7 @@ Follows ``src/eps/impls/krylov/krylovschur/ks-symm.c:30-111``,
 import numpy as np
 
 from . import ds as dsmod
-from .bv import BV, SelfComm, EPSILON
+from .bv import BV, SelfComm, EPSILON, REFINE_IFNEEDED, REFINE_NEVER, REFINE_ALWAYS
 
 ITERATING = 0
 CONVERGED_TOL = 2
@@ -40,7 +40,8 @@ class EPS:
 
     def __init__(self, matvec, n_local, N=None, hermitian=True, nev=1, ncv=0, mpd=0,
                  tol=1e-8, max_it=0, which=None, keep=0.5, lock=True, comm=None,
-                 row0=0, v0=None, monitor=None, solver="krylovschur"):
+                 row0=0, v0=None, monitor=None, solver="krylovschur", delayed=False,
+                 orthog_refine=REFINE_IFNEEDED):
         self.matvec = matvec
         self.n = int(n_local)
         self.N = int(N if N is not None else n_local)
@@ -48,6 +49,8 @@ class EPS:
         if solver not in ("krylovschur", "arnoldi", "lanczos"):
             raise ValueError("unknown solver " + solver)
         self.solver = solver
+        self.delayed = delayed                       # EPSArnoldiSetDelayed (arnoldi.c:168-175)
+        self.orthog_refine = orthog_refine           # -bv_orthog_refine
         self.nev, self.ncv, self.mpd = nev, ncv, mpd
         self.tol = tol                               # default 1e-8: epssetup.c:184
         self.max_it = max_it
@@ -89,6 +92,7 @@ class EPS:
             self.keep = 0.5                                  # krylovschur.c:103
         ncv = self.ncv
         self.V = BV(self.n, ncv + 1, N=self.N, comm=self.comm)   # EPSAllocateSolution(eps,1)
+        self.V.orthog_ref = self.orthog_refine
         self.eigr = np.zeros(ncv + 1)
         self.eigi = np.zeros(ncv + 1)
         self.errest = np.zeros(ncv + 1)
@@ -166,6 +170,77 @@ class EPS:
         for j in range(k, M):
             H[:j + 2, j] = a[nc + (j + 1) * ld: nc + (j + 1) * ld + j + 2]
         return M, beta, breakdown
+
+    def _vdot(self, x, y):
+        return float(self.V.comm.allreduce_sum(np.array([x @ y]))[0])
+
+    def _delayed_arnoldi(self, H, k, m):
+        """``EPSDelayedArnoldi`` (epskrylov.c:82-186): the reorthogonalisation of column j
+        and the normalisation of column j-1 are postponed to step j+1, so that every step
+        needs one round of reductions only.  Returns (M, beta, breakdown)."""
+        V = self.V
+        u = np.zeros(self.n)
+        t = np.zeros(self.n)
+        lhh = np.zeros(m + 1)
+        V.set_active_columns(0, m)
+        for j in range(k, m):
+            self._apply(V.col(j), V.col(j + 1))
+            H[:j + 1, j] = V.dot_column(j + 1)
+            if j > k:
+                lhh[:j] = V.dot_column(j)
+                dot = self._vdot(V.col(j), V.col(j))
+            if j > k + 1:
+                norm2 = np.sqrt(self._vdot(u, u))
+            if j > k:
+                norm1 = np.sqrt(dot)
+                H[:j, j] = H[:j, j] / norm1
+                H[j, j] = H[j, j] / dot
+                t[:] = V.col(j)
+                V.scale_column(j, 1.0 / norm1)
+                V.scale_column(j + 1, 1.0 / norm1)
+            V.mult_column(-1.0, 1.0, j + 1, H[:j + 1, j].copy())
+            if j > k:
+                V.set_active_columns(0, j)
+                V.multvec(-1.0, 1.0, t, lhh[:j].copy())
+                V.set_active_columns(0, m)
+                H[:j, j - 1] += lhh[:j]
+            if j > k + 1:
+                V.col(j - 1)[:] = u
+                V.scale_column(j - 1, 1.0 / norm2)
+                H[j - 1, j - 2] = norm2
+            if j < m - 1:
+                u[:] = t
+        norm2 = np.sqrt(self._vdot(t, t))
+        t *= 1.0 / norm2
+        V.col(m - 1)[:] = t
+        H[m - 1, m - 2] = norm2
+        lhh[:m] = V.dot_column(m)
+        V.mult_column(-1.0, 1.0, m, lhh[:m].copy())
+        H[:m, m - 1] += lhh[:m]
+        beta = V.norm_column(m)
+        V.scale_column(m, 1.0 / beta)
+        return m, beta, False
+
+    def _delayed_arnoldi1(self, H, k, m):
+        """``EPSDelayedArnoldi1`` (epskrylov.c:192-233): delayed normalisation only, no
+        reorthogonalisation (chosen when the BV refinement is "never")."""
+        V = self.V
+        beta = 0.0
+        V.set_active_columns(0, m)
+        for j in range(k, m):
+            self._apply(V.col(j), V.col(j + 1))
+            H[:j + 1, j] = V.dot_column(j + 1)
+            if j > k:
+                dot = self._vdot(V.col(j), V.col(j))
+                norm = np.sqrt(dot)
+                V.scale_column(j, 1.0 / norm)
+                H[j, j - 1] = norm
+                H[:j, j] = H[:j, j] / norm
+                H[j, j] = H[j, j] / dot
+                V.scale_column(j + 1, 1.0 / norm)
+                beta = norm
+            V.mult_column(-1.0, 1.0, j + 1, H[:j + 1, j].copy())
+        return m, beta, False
 
     def _krylov_convergence(self, kini, nits, beta):
         """``EPSKrylovConvergence`` (epskrylov.c:252-327) with the relative test
@@ -309,7 +384,12 @@ class EPS:
             nv = min(self.nconv + self.mpd, self.ncv)
             ds.set_dimensions(nv, self.nconv, 0)
             H = ds.A
-            nv, beta, breakdown = self._basic_arnoldi(H, self.nconv, nv)
+            if not self.delayed:
+                nv, beta, breakdown = self._basic_arnoldi(H, self.nconv, nv)
+            elif self.V.orthog_ref == REFINE_NEVER:
+                nv, beta, breakdown = self._delayed_arnoldi1(H, self.nconv, nv)
+            else:
+                nv, beta, breakdown = self._delayed_arnoldi(H, self.nconv, nv)
             ds.set_dimensions(nv, self.nconv, 0)
             ds.set_state(dsmod.STATE_INTERMEDIATE)
             V.set_active_columns(self.nconv, nv)

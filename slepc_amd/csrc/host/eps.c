@@ -120,6 +120,8 @@ PetscErrorCode EPSKrylovSchurSetRestart(EPS eps, PetscReal keep) {
   }
   return 0;
 }
+/* arnoldi.c:168-175 */
+PetscErrorCode EPSArnoldiSetDelayed(EPS eps, PetscBool delayed) { if (!eps) SETERRQ(PETSC_ERR_ARG_NULL, "Null EPS"); eps->delayed = delayed ? PETSC_TRUE : PETSC_FALSE; return 0; }
 PetscErrorCode EPSKrylovSchurSetLocking(EPS eps, PetscBool lock) { if (!eps) SETERRQ(PETSC_ERR_ARG_NULL, "Null EPS"); eps->lock = lock; return 0; }
 PetscErrorCode EPSMonitorSet(EPS eps, EPSMonitorFn monitor, void *ctx) { if (!eps) SETERRQ(PETSC_ERR_ARG_NULL, "Null EPS"); eps->monitor = monitor; eps->monitorctx = ctx; return 0; }
 PetscErrorCode EPSGetBV(EPS eps, BV *bv) { if (!eps || !bv) SETERRQ(PETSC_ERR_ARG_NULL, "Null argument"); *bv = eps->V; return 0; }
@@ -285,6 +287,109 @@ static PetscErrorCode EPSBasicArnoldi(EPS eps, PetscScalar *H, PetscInt ldh, Pet
   /* extract the Hessenberg matrix from the BV buffer */
   ierr = BVGetBuffer(eps->V, &a, &ld);CHKERRQ(ierr);
   for (j = k; j < *M; j++) memcpy(H + (size_t)j * ldh, a + nc + (size_t)(j + 1) * ld, (size_t)(j + 2) * sizeof(PetscScalar));
+  return 0;
+}
+
+/* epskrylov.c:82-186: Arnoldi with the reorthogonalisation of column j and the
+ * normalisation of column j-1 postponed to step j+1, so that all reductions of a step can
+ * travel together */
+static PetscErrorCode EPSDelayedArnoldi(EPS eps, PetscScalar *H, PetscInt ldh, PetscInt k, PetscInt *M, PetscReal *beta, PetscBool *breakdown) {
+  PetscErrorCode ierr;
+  PetscInt i, j, m = *M;
+  Vec u = NULL, t = NULL, vj, vj1;
+  PetscScalar *lhh, dot = 0.0;
+  PetscReal norm1 = 0.0, norm2 = 1.0;
+  lhh = (PetscScalar *)malloc((size_t)(m + 1) * sizeof(*lhh));
+  if (!lhh) SETERRQ(PETSC_ERR_MEM, "Out of memory");
+#define DCHK(e) do { ierr = (e); if (ierr) { free(lhh); VecDestroy(&u); VecDestroy(&t); CHKERRQ(ierr); } } while (0)
+  DCHK(VecDuplicate(eps->V->t, &u));
+  DCHK(VecDuplicate(eps->V->t, &t));
+  DCHK(BVSetActiveColumns(eps->V, 0, m));
+  for (j = k; j < m; j++) {
+    DCHK(BVGetColumn(eps->V, j, &vj));
+    DCHK(BVGetColumn(eps->V, j + 1, &vj1));
+    DCHK(STApply(eps, vj, vj1));
+    DCHK(BVRestoreColumn(eps->V, j, &vj));
+    DCHK(BVRestoreColumn(eps->V, j + 1, &vj1));
+
+    DCHK(BVDotColumn(eps->V, j + 1, H + (size_t)ldh * j));
+    if (j > k) {
+      DCHK(BVDotColumn(eps->V, j, lhh));
+      DCHK(BVGetColumn(eps->V, j, &vj));
+      DCHK(VecDot(vj, vj, &dot));
+      DCHK(BVRestoreColumn(eps->V, j, &vj));
+    }
+    if (j > k + 1) DCHK(BVNormVec(eps->V, u, NORM_2, &norm2));
+
+    if (j > k) {
+      norm1 = sqrt(dot);
+      for (i = 0; i < j; i++) H[(size_t)ldh * j + i] = H[(size_t)ldh * j + i] / norm1;
+      H[(size_t)ldh * j + j] = H[(size_t)ldh * j + j] / dot;
+      DCHK(BVCopyVec(eps->V, j, t));
+      DCHK(BVScaleColumn(eps->V, j, 1.0 / norm1));
+      DCHK(BVScaleColumn(eps->V, j + 1, 1.0 / norm1));
+    }
+    DCHK(BVMultColumn(eps->V, -1.0, 1.0, j + 1, H + (size_t)ldh * j));
+    if (j > k) {
+      DCHK(BVSetActiveColumns(eps->V, 0, j));
+      DCHK(BVMultVec(eps->V, -1.0, 1.0, t, lhh));
+      DCHK(BVSetActiveColumns(eps->V, 0, m));
+      for (i = 0; i < j; i++) H[(size_t)ldh * (j - 1) + i] += lhh[i];
+    }
+    if (j > k + 1) {
+      DCHK(BVInsertVec(eps->V, j - 1, u));
+      DCHK(BVScaleColumn(eps->V, j - 1, 1.0 / norm2));
+      H[(size_t)ldh * (j - 2) + j - 1] = norm2;
+    }
+    if (j < m - 1) DCHK(VecCopy(t, u));
+  }
+  DCHK(BVNormVec(eps->V, t, NORM_2, &norm2));
+  DCHK(VecScale(t, 1.0 / norm2));
+  DCHK(BVInsertVec(eps->V, m - 1, t));
+  H[(size_t)ldh * (m - 2) + m - 1] = norm2;
+  DCHK(BVDotColumn(eps->V, m, lhh));
+  DCHK(BVMultColumn(eps->V, -1.0, 1.0, m, lhh));
+  for (i = 0; i < m; i++) H[(size_t)ldh * (m - 1) + i] += lhh[i];
+  DCHK(BVNormColumn(eps->V, m, NORM_2, beta));
+  DCHK(BVScaleColumn(eps->V, m, 1.0 / *beta));
+#undef DCHK
+  *breakdown = PETSC_FALSE;
+  free(lhh);
+  ierr = VecDestroy(&u);CHKERRQ(ierr);
+  ierr = VecDestroy(&t);CHKERRQ(ierr);
+  return 0;
+}
+
+/* epskrylov.c:192-233: delayed normalisation only, no reorthogonalisation */
+static PetscErrorCode EPSDelayedArnoldi1(EPS eps, PetscScalar *H, PetscInt ldh, PetscInt k, PetscInt *M, PetscReal *beta, PetscBool *breakdown) {
+  PetscErrorCode ierr;
+  PetscInt i, j, m = *M;
+  PetscScalar dot;
+  PetscReal norm;
+  Vec vj, vj1;
+  ierr = BVSetActiveColumns(eps->V, 0, m);CHKERRQ(ierr);
+  for (j = k; j < m; j++) {
+    ierr = BVGetColumn(eps->V, j, &vj);CHKERRQ(ierr);
+    ierr = BVGetColumn(eps->V, j + 1, &vj1);CHKERRQ(ierr);
+    ierr = STApply(eps, vj, vj1);CHKERRQ(ierr);
+    ierr = BVRestoreColumn(eps->V, j + 1, &vj1);CHKERRQ(ierr);
+    ierr = BVRestoreColumn(eps->V, j, &vj);CHKERRQ(ierr);
+    ierr = BVDotColumn(eps->V, j + 1, H + (size_t)ldh * j);CHKERRQ(ierr);
+    if (j > k) {
+      ierr = BVGetColumn(eps->V, j, &vj);CHKERRQ(ierr);
+      ierr = VecDot(vj, vj, &dot);CHKERRQ(ierr);
+      ierr = BVRestoreColumn(eps->V, j, &vj);CHKERRQ(ierr);
+      norm = sqrt(dot);
+      ierr = BVScaleColumn(eps->V, j, 1.0 / norm);CHKERRQ(ierr);
+      H[(size_t)ldh * (j - 1) + j] = norm;
+      for (i = 0; i < j; i++) H[(size_t)ldh * j + i] = H[(size_t)ldh * j + i] / norm;
+      H[(size_t)ldh * j + j] = H[(size_t)ldh * j + j] / dot;
+      ierr = BVScaleColumn(eps->V, j + 1, 1.0 / norm);CHKERRQ(ierr);
+      *beta = norm;
+    }
+    ierr = BVMultColumn(eps->V, -1.0, 1.0, j + 1, H + (size_t)ldh * j);CHKERRQ(ierr);
+  }
+  *breakdown = PETSC_FALSE;
   return 0;
 }
 
@@ -464,7 +569,9 @@ static PetscErrorCode EPSSolve_Arnoldi(EPS eps) {
     /* compute an nv-step Arnoldi factorization; the locked Schur vectors stay in front */
     nv = PetscMin(eps->nconv + eps->mpd, eps->ncv);
     ierr = DSGetArray(eps->ds, DS_MAT_A, &H);CHKERRQ(ierr);
-    ierr = EPSBasicArnoldi(eps, H, ld, eps->nconv, &nv, &beta, &breakdown);CHKERRQ(ierr);
+    if (!eps->delayed) { ierr = EPSBasicArnoldi(eps, H, ld, eps->nconv, &nv, &beta, &breakdown);CHKERRQ(ierr); }
+    else if (eps->V->orthog_ref == BV_ORTHOG_REFINE_NEVER) { ierr = EPSDelayedArnoldi1(eps, H, ld, eps->nconv, &nv, &beta, &breakdown);CHKERRQ(ierr); }
+    else { ierr = EPSDelayedArnoldi(eps, H, ld, eps->nconv, &nv, &beta, &breakdown);CHKERRQ(ierr); }
     ierr = DSSetDimensions(eps->ds, nv, 0, eps->nconv, 0);CHKERRQ(ierr);
     ierr = DSSetState(eps->ds, DS_STATE_INTERMEDIATE);CHKERRQ(ierr);
     ierr = BVSetActiveColumns(eps->V, eps->nconv, nv);CHKERRQ(ierr);

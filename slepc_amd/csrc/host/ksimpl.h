@@ -50,6 +50,7 @@ struct _p_EPS {
   SlepcCompareFn cmp;
   PetscReal keep;
   PetscBool lock, keep_set;
+  PetscBool delayed;        /* Arnoldi: delayed reorthogonalisation (arnoldi.c:168-175) */
   Vec *IS; PetscInt nini;
   PetscScalar *eigr, *eigi;
   PetscReal *errest;

@@ -233,6 +233,7 @@ SIGNATURES = {
     "EPSSetInitialSpace": (Err, [vp, C.c_int, C.POINTER(VecP)]),
     "EPSKrylovSchurSetRestart": (Err, [vp, C.c_double]),
     "EPSKrylovSchurSetLocking": (Err, [vp, C.c_int]),
+    "EPSArnoldiSetDelayed": (Err, [vp, C.c_int]),
     "EPSMonitorSet": (Err, [vp, MONITOR_FN, vp]),
     "EPSGetBV": (Err, [vp, C.POINTER(BVP)]),
     "EPSGetDS": (Err, [vp, C.POINTER(vp)]),
@@ -436,6 +437,9 @@ class EPS:
 
     def set_locking(self, lock):
         check(self.lib.EPSKrylovSchurSetLocking(self.h, 1 if lock else 0))
+
+    def set_arnoldi_delayed(self, delayed=True):
+        check(self.lib.EPSArnoldiSetDelayed(self.h, 1 if delayed else 0))
 
     def set_bv_type(self, name):
         bv = BVP()

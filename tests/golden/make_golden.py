@@ -119,6 +119,10 @@ def eps_tests():
     g["test8"] = {"n": 20, "nev": 4, "ncv": 11, "values": eigs("src/eps/examples/tests/output/test8_1.out")[0]}
     g["test9"] = {"m": 15, "nev": 4, "which": "largest_magnitude",
                   "values": eigs("src/eps/examples/tests/output/test9_1.out")[0]}
+    g["test9_3"] = {"m": 15, "nev": 3, "which": "largest_real", "tol": 1e-7, "solver": "arnoldi", "delayed": True,
+                    "values": eigs("src/eps/examples/tests/output/test9_3.out")[0]}
+    g["ex4"] = {"file": "rdb200.petsc", "nev": 4, "its": 5,
+                "values": eigs("src/eps/examples/tutorials/output/ex4_1.out")[0]}
     g["test10_ks"] = {"n": 10, "m": 11, "nev": 4, "which": "largest_magnitude",
                       "values": eigs("src/eps/examples/tests/output/test10_1_ks.out")[0]}
     t2 = eigs("src/eps/examples/tests/output/test2_1.out")

@@ -73,6 +73,9 @@ CASES = {
     # explicitly restarted Arnoldi (arnoldi.c) on the same kernels
     "lap2d_60x45_arnoldi": (lambda: mg.laplacian2d(60, 45), True, dict(nev=4, tol=1e-9, solver="arnoldi")),
     "lap2d_60x45_lanczos": (lambda: mg.laplacian2d(60, 45), True, dict(nev=4, ncv=40, tol=1e-9, solver="lanczos")),
+    "markov_15_arnoldi_delayed": (lambda: mg.markov(15), False, dict(nev=3, which="largest_real", tol=1e-7, solver="arnoldi", delayed=True)),
+    "markov_15_arnoldi_delayed_never": (lambda: mg.markov(15), False, dict(nev=3, which="largest_real", tol=1e-7, solver="arnoldi", delayed=True,
+                                                                          orthog_refine=K.BV_ORTHOG_REFINE_NEVER)),
     "markov_60_arnoldi": (lambda: mg.markov(60), False, dict(nev=4, which="largest_real", tol=1e-10, solver="arnoldi")),
 }
 

@@ -268,7 +268,8 @@ def test_eps_goldens(be):
     assert _fmt(r["values"], 4) == g["test2"]["smallest"]
 
 
-@pytest.mark.parametrize("case", ["lap2d", "lap1d_locking_off", "markov", "markov_mag", "lap2d_arnoldi", "markov_arnoldi", "lap2d_lanczos"])
+@pytest.mark.parametrize("case", ["lap2d", "lap1d_locking_off", "markov", "markov_mag", "lap2d_arnoldi", "markov_arnoldi", "lap2d_lanczos",
+                                  "markov_arnoldi_delayed", "markov_arnoldi_delayed_never"])
 def test_eps_matches_oracle_driver(be, case):
     """Same start vector, same kernels: the C driver and the oracle driver must take
     the same decisions (restarts, converged count) and agree to rounding."""
@@ -288,6 +289,13 @@ def test_eps_matches_oracle_driver(be, case):
         # cluster is reached (the 4th and 5th eigenvalues here): three pairs keep both
         # drivers on the same path
         kw.update(which="largest_real", tol=1e-10, solver="arnoldi", nev=3)
+    elif case.startswith("markov_arnoldi_delayed"):
+        # runtest9_3 of the reference: -eps_type arnoldi -eps_arnoldi_delayed -eps_largest_real
+        # -eps_nev 3 -eps_tol 1e-7 -bv_orthog_refine {ifneeded,never}
+        csr = og.markov(15)
+        herm = False
+        kw.update(which="largest_real", tol=1e-7, solver="arnoldi", nev=3, delayed=True,
+                  orthog_refine=K.BV_ORTHOG_REFINE_NEVER if case.endswith("never") else K.BV_ORTHOG_REFINE_IFNEEDED)
     elif case == "lap1d_locking_off":
         csr = og.laplacian1d(200)
         kw.update(lock=False, ncv=24)

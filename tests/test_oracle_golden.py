@@ -169,6 +169,17 @@ def test_eps_goldens_arnoldi():
     assert all(e.compute_error(i) < 5e-8 for i in range(4))
 
 
+def test_eps_goldens_arnoldi_delayed():
+    """Arnoldi with delayed reorthogonalisation: runtest9_3_never and runtest9_3_ifneeded of the
+    reference (src/eps/examples/tests/makefile:415-419) share one golden file."""
+    g = golden("eps_tests.json")["test9_3"]
+    for refine in (1, 0):                                 # never -> EPSDelayedArnoldi1, ifneeded -> EPSDelayedArnoldi
+        e = _solve(og.markov(g["m"]), hermitian=False, nev=g["nev"], which=g["which"], tol=g["tol"],
+                   solver="arnoldi", delayed=True, orthog_refine=refine)
+        assert _vals(e, 3) == g["values"]
+        assert all(e.compute_error(i) < 5e-7 for i in range(3))
+
+
 def test_eps_goldens_lanczos():
     """Explicitly restarted Lanczos with full reorthogonalisation against the golden files of
     the reference's runtest2_2_full, runtest4_1_lanczos, runtest8_1_lanczos
