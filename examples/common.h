@@ -45,6 +45,21 @@ static void eps_set_from_options(EPS eps, int argc, char **argv) {
   if (opt_find(argc, argv, "-eps_smallest_real")) CHK(EPSSetWhichEigenpairs(eps, EPS_SMALLEST_REAL));
 }
 
+/* -svd_type -svd_nsv -svd_ncv -svd_mpd -svd_tol -svd_max_it -svd_largest -svd_smallest
+ * -svd_trlanczos_oneside (SVDSetFromOptions) */
+static void svd_set_from_options(SVD svd, int argc, char **argv) {
+  PetscInt nsv, ncv, mpd;
+  int it = opt_find(argc, argv, "-svd_type");
+  if (it && it + 1 < argc) CHK(SVDSetType(svd, argv[it + 1]));       /* cross | trlanczos */
+  CHK(SVDGetDimensions(svd, &nsv, &ncv, &mpd));
+  nsv = (PetscInt)opt_int(argc, argv, "-svd_nsv", nsv);
+  CHK(SVDSetDimensions(svd, nsv, (PetscInt)opt_int(argc, argv, "-svd_ncv", 0), (PetscInt)opt_int(argc, argv, "-svd_mpd", 0)));
+  CHK(SVDSetTolerances(svd, opt_real(argc, argv, "-svd_tol", 0.0), (PetscInt)opt_int(argc, argv, "-svd_max_it", 0)));
+  if (opt_find(argc, argv, "-svd_largest")) CHK(SVDSetWhichSingularTriplets(svd, SVD_LARGEST));
+  if (opt_find(argc, argv, "-svd_smallest")) CHK(SVDSetWhichSingularTriplets(svd, SVD_SMALLEST));
+  if (opt_find(argc, argv, "-svd_trlanczos_oneside")) CHK(SVDTRLanczosSetOneSide(svd, PETSC_TRUE));
+}
+
 /* the report of EPSErrorView(eps,EPS_ERROR_RELATIVE,NULL), after the solver lines the
  * tutorials print; `stopping` adds the line with the tolerance and the restart cap */
 static void eps_report_ex(EPS eps, int stopping) {

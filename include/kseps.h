@@ -60,6 +60,7 @@ typedef struct _p_Mat *Mat;
 typedef struct _p_BV *BV;
 typedef struct _p_DS *DS;
 typedef struct _p_EPS *EPS;
+typedef struct _p_SVD *SVD;
 
 /* ------------------------------------------------------------------ Vec */
 /* Op table of a vector type: the PETSc Vec operations the hot-path host code
@@ -118,24 +119,37 @@ struct _MatOps {
    * `work` is a scratch vector the operator may use.  EPSComputeError falls back to
    * MatMult + VecAXPY + VecNorm (epssolve.c:506-556) without it. */
   PetscErrorCode (*residualnorm)(Mat A, PetscScalar kr, PetscScalar ki, Vec xr, Vec xi, Vec work, PetscReal *norm);
+  /* optional (may be NULL): *AT = A^T as a new matrix (MatTranspose with MAT_INITIAL_MATRIX,
+   * what SVDSetUp needs, svdsetup.c:139-148) */
+  PetscErrorCode (*transpose)(Mat A, Mat *AT);
 };
 struct _p_Mat {
   struct _MatOps ops;
-  PetscInt64 n, N, row0;
+  PetscInt64 n, N, row0;    /* rows: local, global, first local */
   void *data;               /* ksg_mat for "aijhip", user context for shells */
   void *ctx;
+  PetscInt64 cn, cN, col0;  /* columns (layout of the vector a MatMult takes); equal to the rows for a square operator */
 };
 /* GPU AIJ operator: the rows [row0,row0+n) in CSR with global column indices
  * (the role of MatCreateAIJ + MatSetValues + MatAssembly with -mat_type set to
  * the device type, ex2.c:50-66). */
 PetscErrorCode MatCreateAIJHIP(ksg_ctx ctx, PetscInt64 n, PetscInt64 N, PetscInt64 row0,
                                const int64_t *rowptr, const int32_t *colidx, const double *val, Mat *A);
+/* The same for a rectangular operator, M x N with rows [row0,row0+m) and the columns
+ * [col0,col0+n) local (MatSetSizes(A,m,n,M,N), src/svd/examples/tutorials/ex15.c). */
+PetscErrorCode MatCreateAIJHIPRect(ksg_ctx ctx, PetscInt64 m, PetscInt64 M, PetscInt64 row0, PetscInt64 n, PetscInt64 N,
+                                   PetscInt64 col0, const int64_t *rowptr, const int32_t *colidx, const double *val, Mat *A);
+PetscErrorCode MatTranspose(Mat A, Mat *AT);
 /* User operator (MatCreateShell + MatShellSetOperation(MATOP_MULT), tests/test8.c:57-61).
  * createvecs may be NULL when template vectors are supplied by another route. */
 PetscErrorCode MatCreateShell(void *ctx, PetscInt64 n, PetscInt64 N, PetscInt64 row0, void *user,
                               PetscErrorCode (*mult)(Mat, Vec, Vec),
                               PetscErrorCode (*createvecs)(Mat, Vec *, Vec *), Mat *A);
 PetscErrorCode MatShellGetContext(Mat A, void **user);
+/* for a rectangular shell: the layout of the vectors MatMult takes, and the routine that
+ * builds the transpose (the role of MatShellSetOperation(A,MATOP_TRANSPOSE,...)) */
+PetscErrorCode MatShellSetColumnLayout(Mat A, PetscInt64 n, PetscInt64 N, PetscInt64 col0);
+PetscErrorCode MatShellSetTranspose(Mat A, PetscErrorCode (*transpose)(Mat, Mat *));
 /* PETSc binary matrix files (the format MatLoad reads and MatView writes on a
  * PetscViewerBinary; src/eps/examples/tutorials/ex4.c:56-60 loads the files of
  * share/slepc/datafiles/matrices this way).  KSMatReadPetscBinary returns the whole
@@ -246,11 +260,11 @@ PetscErrorCode BVCreate_HIP(BV bv);
 
 /* ------------------------------------------------------------------ DS */
 typedef enum { DS_STATE_RAW = 0, DS_STATE_INTERMEDIATE, DS_STATE_CONDENSED, DS_STATE_TRUNCATED } DSStateType;
-typedef enum { DS_MAT_A = 0, DS_MAT_Q, DS_MAT_X, DS_MAT_T, DS_NUM_MAT } DSMatType;
+typedef enum { DS_MAT_A = 0, DS_MAT_Q, DS_MAT_X, DS_MAT_T, DS_MAT_U, DS_MAT_VT, DS_NUM_MAT } DSMatType;
 typedef PetscErrorCode (*SlepcCompareFn)(PetscScalar ar, PetscScalar ai, PetscScalar br, PetscScalar bi, PetscInt *res, void *ctx);
 
 PetscErrorCode DSCreate(DS *ds);
-PetscErrorCode DSSetType(DS ds, const char *type);          /* "hep" or "nhep" */
+PetscErrorCode DSSetType(DS ds, const char *type);          /* "hep", "nhep" or "svd" */
 PetscErrorCode DSSetCompact(DS ds, PetscBool comp);
 PetscErrorCode DSSetExtraRow(DS ds, PetscBool ext);
 PetscErrorCode DSAllocate(DS ds, PetscInt ld);
@@ -287,6 +301,7 @@ typedef enum { EPS_LARGEST_MAGNITUDE = 1, EPS_SMALLEST_MAGNITUDE, EPS_LARGEST_RE
 typedef enum { EPS_ERROR_ABSOLUTE = 0, EPS_ERROR_RELATIVE = 1 } EPSErrorType;
 typedef enum { EPS_CONVERGED_TOL = 1, EPS_CONVERGED_USER = 2, EPS_DIVERGED_ITS = -1, EPS_DIVERGED_BREAKDOWN = -2,
                EPS_DIVERGED_SYMMETRY_LOST = -3, EPS_CONVERGED_ITERATING = 0 } EPSConvergedReason;
+typedef enum { EPS_CONV_ABS = 0, EPS_CONV_REL = 1 } EPSConv;
 typedef PetscErrorCode (*EPSMonitorFn)(EPS eps, PetscInt its, PetscInt nconv, PetscScalar *eigr, PetscScalar *eigi,
                                        PetscReal *errest, PetscInt nest, void *ctx);
 
@@ -302,6 +317,7 @@ PetscErrorCode EPSSetProblemType(EPS eps, EPSProblemType type);                 
 PetscErrorCode EPSSetDimensions(EPS eps, PetscInt nev, PetscInt ncv, PetscInt mpd);
 PetscErrorCode EPSSetTolerances(EPS eps, PetscReal tol, PetscInt maxits);
 PetscErrorCode EPSSetWhichEigenpairs(EPS eps, EPSWhich which);
+PetscErrorCode EPSSetConvergenceTest(EPS eps, EPSConv conv);                     /* epsopts.c; default relative */
 PetscErrorCode EPSSetInitialSpace(EPS eps, PetscInt n, Vec *is);                 /* epssetup.c:449-460 */
 PetscErrorCode EPSKrylovSchurSetRestart(EPS eps, PetscReal keep);                /* krylovschur.c:290 */
 PetscErrorCode EPSKrylovSchurSetLocking(EPS eps, PetscBool lock);
@@ -327,6 +343,42 @@ PetscErrorCode EPSComputeError(EPS eps, PetscInt i, EPSErrorType type, PetscReal
 /* number of Gram-Schmidt passes and operator applications so far (for the byte model) */
 PetscErrorCode EPSGetCounters(EPS eps, PetscInt64 *matvecs, PetscInt64 *gs_passes);
 PetscErrorCode EPSDestroy(EPS *eps);
+
+/* ------------------------------------------------------------------ SVD */
+/* Singular value solvers on the same kernels (include/slepcsvd.h of the reference):
+ * "cross" (default, svdsetup.c:112-114; the eigenproblem of A^T A, src/svd/impls/cross/cross.c)
+ * and "trlanczos" (thick-restart Lanczos bidiagonalisation,
+ * src/svd/impls/trlanczos/trlanczos.c).  The operator may be rectangular; its transpose is
+ * built explicitly with MatTranspose. */
+typedef enum { SVD_LARGEST = 0, SVD_SMALLEST = 1 } SVDWhich;
+typedef enum { SVD_ERROR_ABSOLUTE = 0, SVD_ERROR_RELATIVE = 1 } SVDErrorType;
+typedef enum { SVD_CONV_ABS = 0, SVD_CONV_REL = 1 } SVDConv;
+typedef enum { SVD_CONVERGED_TOL = 1, SVD_CONVERGED_USER = 2, SVD_DIVERGED_ITS = -1, SVD_DIVERGED_BREAKDOWN = -2,
+               SVD_CONVERGED_ITERATING = 0 } SVDConvergedReason;
+
+PetscErrorCode SVDCreate(void *ctx, SVD *svd);                                   /* svdbasic.c */
+PetscErrorCode SVDSetOperator(SVD svd, Mat A);                                   /* svdsetup.c:47-60 */
+PetscErrorCode SVDSetType(SVD svd, const char *type);
+PetscErrorCode SVDGetType(SVD svd, const char **type);
+PetscErrorCode SVDSetDimensions(SVD svd, PetscInt nsv, PetscInt ncv, PetscInt mpd);
+PetscErrorCode SVDGetDimensions(SVD svd, PetscInt *nsv, PetscInt *ncv, PetscInt *mpd);
+PetscErrorCode SVDSetTolerances(SVD svd, PetscReal tol, PetscInt maxits);
+PetscErrorCode SVDGetTolerances(SVD svd, PetscReal *tol, PetscInt *maxits);
+PetscErrorCode SVDSetWhichSingularTriplets(SVD svd, SVDWhich which);
+PetscErrorCode SVDSetConvergenceTest(SVD svd, SVDConv conv);
+PetscErrorCode SVDSetInitialSpace(SVD svd, PetscInt n, Vec *is);                 /* svdsetup.c:222-232 */
+PetscErrorCode SVDTRLanczosSetOneSide(SVD svd, PetscBool oneside);               /* trlanczos.c:400-426 */
+PetscErrorCode SVDCrossGetEPS(SVD svd, EPS *eps);
+PetscErrorCode SVDGetBV(SVD svd, BV *V, BV *U);
+PetscErrorCode SVDSetUp(SVD svd);                                                /* svdsetup.c:98-205 */
+PetscErrorCode SVDSolve(SVD svd);                                                /* svdsolve.c:80-128 */
+PetscErrorCode SVDGetIterationNumber(SVD svd, PetscInt *its);
+PetscErrorCode SVDGetConverged(SVD svd, PetscInt *nconv);
+PetscErrorCode SVDGetConvergedReason(SVD svd, SVDConvergedReason *reason);
+/* u has the local rows of the operator as given, v its local columns; either may be NULL */
+PetscErrorCode SVDGetSingularTriplet(SVD svd, PetscInt i, PetscReal *sigma, Vec u, Vec v);
+PetscErrorCode SVDComputeError(SVD svd, PetscInt i, SVDErrorType type, PetscReal *error);
+PetscErrorCode SVDDestroy(SVD *svd);
 
 #ifdef __cplusplus
 }

@@ -169,6 +169,22 @@ int ksg_bv_matmult(ksg_bv V, ksg_mat A, ksg_bv W);
 int ksg_mat_create_csr(ksg_ctx ctx, int64_t n_local, int64_t N, int64_t row0,
                        const int64_t *rowptr, const int32_t *colidx, const double *val,
                        ksg_mat *A);
+/* The same for an operator whose columns are distributed differently from its rows (a
+ * rectangular matrix, as the singular value solvers take: MatSetSizes(A,m,n,M,N) of
+ * src/svd/examples/tutorials/ex15.c): the vector x of ksg_mat_mult has nc_local entries, the
+ * columns [col0, col0+nc_local) of the NC global ones. */
+int ksg_mat_create_csr_rect(ksg_ctx ctx, int64_t n_local, int64_t N, int64_t row0,
+                            int64_t nc_local, int64_t NC, int64_t col0,
+                            const int64_t *rowptr, const int32_t *colidx, const double *val,
+                            ksg_mat *A);
+int ksg_mat_col_sizes(ksg_mat A, int64_t *nc_local, int64_t *NC, int64_t *col0);
+/* The local rows back on the host with global column indices; rowptr has n_local+1
+ * entries, colidx and val nnz_local (ksg_mat_sizes). */
+int ksg_mat_get_csr(ksg_mat A, int64_t *rowptr, int32_t *colidx, double *val);
+/* AT = A^T as a new operator with rows and columns exchanged, rank p holding the rows that
+ * were its columns (MatTranspose as SVDSetUp builds svd->AT, svdsetup.c:139-148).
+ * Collective. */
+int ksg_mat_transpose(ksg_mat A, ksg_mat *AT);
 int ksg_mat_destroy(ksg_mat A);
 /* y = A*x on device vectors of n_local entries; collective when nranks > 1
  * (MatMult as called by STApply_Shift, shift.c:38). */

@@ -49,6 +49,7 @@ class EPS:
         if solver not in ("krylovschur", "arnoldi", "lanczos"):
             raise ValueError("unknown solver " + solver)
         self.solver = solver
+        self.conv = "rel"                            # EPSSetConvergenceTest
         self.delayed = delayed                       # EPSArnoldiSetDelayed (arnoldi.c:168-175)
         self.orthog_refine = orthog_refine           # -bv_orthog_refine
         self.nev, self.ncv, self.mpd = nev, ncv, mpd
@@ -252,7 +253,8 @@ class EPS:
             re, im = self.eigr[k], self.eigi[k]
             newk, resnorm = self.ds.vectors_rnorm(k)
             resnorm *= beta
-            self.errest[k] = resnorm / dsmod.abs_eig(re, im)
+            # EPSConvergedRelative / EPSConvergedAbsolute (epsdefault.c:258-280)
+            self.errest[k] = resnorm if self.conv == "abs" else resnorm / dsmod.abs_eig(re, im)
             if marker == -1 and self.errest[k] >= self.tol:
                 marker = k
             if newk == k + 1:

@@ -666,3 +666,88 @@ int ksd_trevc_right(int n, const double *T, int ldt, int k, double *xr, double *
   if (emax > 0.0) for (int i = 0; i <= k + 1; i++) { xr[i] /= emax; xi[i] /= emax; }
   return 1;
 }
+
+/* ---- singular value decomposition -------------------------------------------------------
+ * One-sided Jacobi (Hestenes): plane rotations from the right make the columns of G = A V
+ * mutually orthogonal; then s_j = ||g_j||, u_j = g_j / s_j.  Takes the place of LAPACK's
+ * gesdd/bdsdc in the projected problem of the singular value solvers
+ * (src/sys/classes/ds/impls/svd/dssvd.c:197-290); the matrices are of order <= ncv. */
+int ksd_gesvd(int n, const double *A, int lda, double *s, double *U, int ldu, double *VT, int ldvt) {
+  if (n <= 0) return 0;
+  double *G = (double *)malloc((size_t)n * n * sizeof(double));
+  double *V = (double *)calloc((size_t)n * n, sizeof(double));
+  int *ord = (int *)malloc((size_t)n * sizeof(int));
+  if (!G || !V || !ord) { free(G); free(V); free(ord); return -1; }
+  int i, j, p, q, sweep, rotated = 1;
+  for (j = 0; j < n; j++) { memcpy(G + (size_t)j * n, A + (size_t)j * lda, (size_t)n * sizeof(double)); V[j + (size_t)j * n] = 1.0; }
+  const double eps = 2.2204460492503131e-16;
+  for (sweep = 0; sweep < 60 && rotated; sweep++) {
+    rotated = 0;
+    for (p = 0; p < n - 1; p++) {
+      for (q = p + 1; q < n; q++) {
+        double *gp = G + (size_t)p * n, *gq = G + (size_t)q * n;
+        double alpha = 0.0, beta = 0.0, gamma = 0.0;
+        for (i = 0; i < n; i++) { alpha += gp[i] * gp[i]; beta += gq[i] * gq[i]; gamma += gp[i] * gq[i]; }
+        if (gamma == 0.0 || fabs(gamma) <= eps * sqrt(alpha * beta)) continue;
+        rotated = 1;
+        const double zeta = (beta - alpha) / (2.0 * gamma);
+        const double t = (zeta >= 0.0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+        const double c = 1.0 / sqrt(1.0 + t * t), sn = c * t;
+        double *vp = V + (size_t)p * n, *vq = V + (size_t)q * n;
+        for (i = 0; i < n; i++) {
+          const double a = gp[i], b = gq[i];
+          gp[i] = c * a - sn * b; gq[i] = sn * a + c * b;
+          const double va = vp[i], vb = vq[i];
+          vp[i] = c * va - sn * vb; vq[i] = sn * va + c * vb;
+        }
+      }
+    }
+  }
+  if (rotated) { free(G); free(V); free(ord); return 1; }       /* no convergence */
+  /* singular values, descending */
+  for (j = 0; j < n; j++) {
+    double nrm = 0.0;
+    for (i = 0; i < n; i++) nrm = hypot(nrm, G[i + (size_t)j * n]);
+    s[j] = nrm; ord[j] = j;
+  }
+  for (i = 1; i < n; i++) {                                     /* insertion sort of ord by s, stable */
+    const int o = ord[i];
+    for (j = i - 1; j >= 0 && s[ord[j]] < s[o]; j--) ord[j + 1] = ord[j];
+    ord[j + 1] = o;
+  }
+  double smax = s[ord[0]];
+  int rank = 0;
+  for (j = 0; j < n; j++) {
+    const int o = ord[j];
+    for (i = 0; i < n; i++) VT[j + (size_t)i * ldvt] = V[i + (size_t)o * n];
+    if (s[o] > (double)n * eps * smax && s[o] > 0.0) {
+      for (i = 0; i < n; i++) U[i + (size_t)j * ldu] = G[i + (size_t)o * n] / s[o];
+      rank = j + 1;
+    }
+  }
+  /* columns of U for (numerically) zero singular values: complete to an orthonormal basis */
+  for (j = rank; j < n; j++) {
+    int e;
+    for (e = 0; e < n; e++) {
+      double nrm = 0.0;
+      for (i = 0; i < n; i++) U[i + (size_t)j * ldu] = (i == e) ? 1.0 : 0.0;
+      for (int pass = 0; pass < 2; pass++)
+        for (q = 0; q < j; q++) {
+          double d = 0.0;
+          for (i = 0; i < n; i++) d += U[i + (size_t)q * ldu] * U[i + (size_t)j * ldu];
+          for (i = 0; i < n; i++) U[i + (size_t)j * ldu] -= d * U[i + (size_t)q * ldu];
+        }
+      for (i = 0; i < n; i++) nrm = hypot(nrm, U[i + (size_t)j * ldu]);
+      if (nrm > 0.5 / sqrt((double)n)) { for (i = 0; i < n; i++) U[i + (size_t)j * ldu] /= nrm; break; }
+    }
+  }
+  {
+    double *tmp = (double *)malloc((size_t)n * sizeof(double));
+    if (!tmp) { free(G); free(V); free(ord); return -1; }
+    for (j = 0; j < n; j++) tmp[j] = s[ord[j]];
+    memcpy(s, tmp, (size_t)n * sizeof(double));
+    free(tmp);
+  }
+  free(G); free(V); free(ord);
+  return 0;
+}

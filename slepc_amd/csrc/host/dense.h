@@ -12,4 +12,8 @@ int ksd_hseqr(int n, int ilo, double *T, int ldt, double *wr, double *wi, double
 int ksd_trexc(int n, double *T, int ldt, double *Q, int ldq, int nq, int ifst, int ilst);
 int ksd_trevc_right(int n, const double *T, int ldt, int k, double *xr, double *xi);
 
+/* A = U diag(s) VT for a square n x n matrix (column-major), singular values descending;
+ * U and VT are n x n orthogonal.  A is not modified. */
+int ksd_gesvd(int n, const double *A, int lda, double *s, double *U, int ldu, double *VT, int ldvt);
+
 #endif

@@ -4,6 +4,9 @@
  *   "hep"  - symmetric, compact storage (arrow + tridiagonal in T), extra row
  *            (src/sys/classes/ds/impls/hep/dshep.c)
  *   "nhep" - non-symmetric, real Schur form (src/sys/classes/ds/impls/nhep/dsnhep.c)
+ *   "svd"  - singular values of an arrow + upper bidiagonal matrix, compact storage, as the
+ *            thick-restart Lanczos bidiagonalisation sets it up (trlanczos.c:71-73;
+ *            src/sys/classes/ds/impls/svd/dssvd.c)
  * Interface functions follow src/sys/classes/ds/interface/dsops.c, dsbasic.c,
  * dspriv.c.  The LAPACK calls of the reference are replaced by dense.c. */
 #include "dense.h"
@@ -26,6 +29,7 @@ PetscErrorCode DSSetType(DS ds, const char *type) {
   if (!ds || !type) SETERRQ(PETSC_ERR_ARG_NULL, "Null argument");
   if (!strcmp(type, "hep")) ds->type = 0;
   else if (!strcmp(type, "nhep")) ds->type = 1;
+  else if (!strcmp(type, "svd")) ds->type = 2;
   else SETERRQ(PETSC_ERR_ARG_WRONG, "Unable to find requested DS type %s", type);
   return 0;
 }
@@ -47,6 +51,11 @@ PetscErrorCode DSAllocate(DS ds, PetscInt ld) {
   ds->mat[DS_MAT_A] = (PetscScalar *)calloc((size_t)ld * ld, sizeof(PetscScalar));
   ds->mat[DS_MAT_Q] = (PetscScalar *)calloc((size_t)ld * ld, sizeof(PetscScalar));
   ds->mat[DS_MAT_X] = (PetscScalar *)calloc((size_t)ld * ld, sizeof(PetscScalar));
+  if (ds->type == 2) {          /* DSAllocate_SVD dssvd.c:24-37 */
+    ds->mat[DS_MAT_U] = (PetscScalar *)calloc((size_t)ld * ld, sizeof(PetscScalar));
+    ds->mat[DS_MAT_VT] = (PetscScalar *)calloc((size_t)ld * ld, sizeof(PetscScalar));
+    if (!ds->mat[DS_MAT_U] || !ds->mat[DS_MAT_VT]) SETERRQ(PETSC_ERR_MEM, "Out of memory");
+  }
   ds->rmat = (PetscReal *)calloc((size_t)3 * ld, sizeof(PetscReal));
   ds->perm = (PetscInt *)calloc((size_t)ld, sizeof(PetscInt));
   if (!ds->mat[DS_MAT_A] || !ds->mat[DS_MAT_Q] || !ds->mat[DS_MAT_X] || !ds->rmat || !ds->perm) SETERRQ(PETSC_ERR_MEM, "Out of memory");
@@ -62,6 +71,10 @@ PetscErrorCode DSSetDimensions(DS ds, PetscInt n, PetscInt m, PetscInt l, PetscI
   if (ds->extrarow && n + 1 > ds->ld) SETERRQ(PETSC_ERR_ARG_OUTOFRANGE, "A value of n equal to ld leaves no room for extra row");
   ds->n = n;
   ds->t = ds->n;
+  if (m) {
+    if (m < 0 || m > ds->ld) SETERRQ(PETSC_ERR_ARG_OUTOFRANGE, "Illegal value of m. Must be between 0 and ld");
+    ds->m = m;
+  }
   if (l < 0 || l > ds->n) SETERRQ(PETSC_ERR_ARG_OUTOFRANGE, "Illegal value of l. Must be between 0 and n");
   ds->l = l;
   if (k < 0 || k > ds->n) SETERRQ(PETSC_ERR_ARG_OUTOFRANGE, "Illegal value of k. Must be between 0 and n");
@@ -71,7 +84,7 @@ PetscErrorCode DSSetDimensions(DS ds, PetscInt n, PetscInt m, PetscInt l, PetscI
 PetscErrorCode DSGetDimensions(DS ds, PetscInt *n, PetscInt *m, PetscInt *l, PetscInt *k, PetscInt *t) {
   DSCheckAlloc(ds);
   if (n) *n = ds->n;
-  if (m) *m = 0;
+  if (m) *m = ds->m;
   if (l) *l = ds->l;
   if (k) *k = ds->k;
   if (t) *t = ds->t;
@@ -409,6 +422,79 @@ static PetscErrorCode DSUpdateExtraRow_NHEP(DS ds) {
   return 0;
 }
 
+/* ---- SVD (dssvd.c) ---------------------------------------------------------------------------------- */
+/* dssvd.c:64-98, compact (arrow + upper bidiagonal in T) to dense */
+static PetscErrorCode DSSwitchToDense_SVD(DS ds) {
+  PetscReal *T = ds->rmat;
+  PetscScalar *A = ds->mat[DS_MAT_A];
+  PetscInt i, m = ds->m, k = ds->k, ld = ds->ld;
+  if (!m) SETERRQ(PETSC_ERR_ARG_WRONG, "m was not set");
+  memset(A, 0, (size_t)ld * ld * sizeof(PetscScalar));
+  for (i = 0; i < k; i++) { A[i + i * ld] = T[i]; A[i + k * ld] = T[i + ld]; }
+  A[k + k * ld] = T[k];
+  for (i = k + 1; i < m; i++) { A[i + i * ld] = T[i]; A[i - 1 + i * ld] = T[i - 1 + ld]; }
+  return 0;
+}
+
+/* dssvd.c:197-290 (DSSolve_SVD_DC); the bidiagonal and the arrow case both go through the
+ * dense Jacobi routine */
+static PetscErrorCode DSSolve_SVD(DS ds, PetscScalar *wr) {
+  PetscErrorCode ierr;
+  PetscInt i, l = ds->l, n = ds->n, m = ds->m, ld = ds->ld;
+  PetscScalar *A = ds->mat[DS_MAT_A], *U = ds->mat[DS_MAT_U], *VT = ds->mat[DS_MAT_VT];
+  PetscReal *d = ds->rmat, *e = ds->rmat + ld;
+  if (!ds->compact) SETERRQ(PETSC_ERR_SUP, "Only compact storage is available for DSSVD");
+  if (n != m) SETERRQ(PETSC_ERR_SUP, "Only square projected problems are available for DSSVD");
+  memset(U, 0, (size_t)ld * ld * sizeof(PetscScalar));
+  memset(VT, 0, (size_t)ld * ld * sizeof(PetscScalar));
+  for (i = 0; i < l; i++) { U[i + i * ld] = 1.0; VT[i + i * ld] = 1.0; wr[i] = d[i]; }
+  if (ds->state > DS_STATE_RAW) {
+    /* upper bidiagonal: d on the diagonal, e above it */
+    memset(A, 0, (size_t)ld * ld * sizeof(PetscScalar));
+    for (i = l; i < n; i++) { A[i + i * ld] = d[i]; if (i + 1 < n) A[i + (i + 1) * ld] = e[i]; }
+  } else {
+    ierr = DSSwitchToDense_SVD(ds);CHKERRQ(ierr);
+  }
+  if (n > l) {
+    const int info = ksd_gesvd(n - l, A + l + (size_t)l * ld, ld, d + l, U + l + (size_t)l * ld, ld, VT + l + (size_t)l * ld, ld);
+    if (info) SETERRQ(PETSC_ERR_LIB, "Error in the dense SVD: %d", info);
+  }
+  for (i = l; i < n; i++) wr[i] = d[i];
+  if (n > 1) memset(e, 0, (size_t)(n - 1) * sizeof(PetscReal));
+  return 0;
+}
+
+/* dssvd.c:167-195 with DSSortEigenvaluesReal_Private (dspriv.c:242-264) and
+ * DSPermuteBoth_Private (dspriv.c:335-362) */
+static PetscErrorCode DSSort_SVD(DS ds, PetscScalar *wr) {
+  PetscErrorCode ierr;
+  PetscInt n = PetscMin(ds->n, ds->m), m = ds->m, l = ds->l, i, j, k, p, result, tmp, *perm = ds->perm, ld = ds->ld;
+  PetscReal *d = ds->rmat;
+  PetscScalar *U = ds->mat[DS_MAT_U], *VT = ds->mat[DS_MAT_VT];
+  for (i = l + 1; i < n; i++) {
+    const PetscScalar re = d[perm[i]];
+    j = i - 1;
+    ierr = ds->cmp(re, 0.0, d[perm[j]], 0.0, &result, ds->cmpctx);CHKERRQ(ierr);
+    while (result < 0 && j >= l) {
+      tmp = perm[j]; perm[j] = perm[j + 1]; perm[j + 1] = tmp; j--;
+      if (j >= l) { ierr = ds->cmp(re, 0.0, d[perm[j]], 0.0, &result, ds->cmpctx);CHKERRQ(ierr); }
+    }
+  }
+  for (i = l; i < n; i++) wr[i] = d[perm[i]];
+  for (i = l; i < n; i++) {
+    p = perm[i];
+    if (p != i) {
+      j = i + 1;
+      while (perm[j] != i) j++;
+      perm[j] = p; perm[i] = i;
+      for (k = 0; k < n; k++) { PetscScalar t = U[k + p * ld]; U[k + p * ld] = U[k + i * ld]; U[k + i * ld] = t; }
+      for (k = 0; k < m; k++) { PetscScalar t = VT[p + k * ld]; VT[p + k * ld] = VT[i + k * ld]; VT[i + k * ld] = t; }
+    }
+  }
+  for (i = l; i < n; i++) d[i] = wr[i];
+  return 0;
+}
+
 /* ---- interface (dsops.c) ------------------------------------------------------------------------- */
 PetscErrorCode DSSolve(DS ds, PetscScalar *eigr, PetscScalar *eigi) {
   PetscErrorCode ierr;
@@ -416,6 +502,7 @@ PetscErrorCode DSSolve(DS ds, PetscScalar *eigr, PetscScalar *eigi) {
   if (!eigr) SETERRQ(PETSC_ERR_ARG_NULL, "Null pointer: eigr");
   if (ds->state >= DS_STATE_CONDENSED) return 0;
   if (ds->type == 0) { ierr = DSSolve_HEP_QR(ds, eigr, eigi);CHKERRQ(ierr); }
+  else if (ds->type == 2) { ierr = DSSolve_SVD(ds, eigr);CHKERRQ(ierr); }
   else { ierr = DSSolve_NHEP(ds, eigr, eigi);CHKERRQ(ierr); }
   ds->state = DS_STATE_CONDENSED;
   return 0;
@@ -433,6 +520,7 @@ PetscErrorCode DSSort(DS ds, PetscScalar *eigr, PetscScalar *eigi, PetscScalar *
   if (rr && rr != eigr) SETERRQ(PETSC_ERR_SUP, "Sorting by auxiliary values is not available");
   for (i = 0; i < ds->n; i++) ds->perm[i] = i;
   if (ds->type == 0) { ierr = DSSort_HEP(ds, eigr, eigi);CHKERRQ(ierr); }
+  else if (ds->type == 2) { ierr = DSSort_SVD(ds, eigr);CHKERRQ(ierr); }
   else { ierr = DSSort_NHEP_Total(ds, eigr, eigi);CHKERRQ(ierr); }
   return 0;
 }
@@ -441,6 +529,7 @@ PetscErrorCode DSUpdateExtraRow(DS ds) {
   PetscErrorCode ierr;
   DSCheckAlloc(ds);
   if (!ds->extrarow) SETERRQ(PETSC_ERR_ARG_WRONGSTATE, "Should have called DSSetExtraRow");
+  if (ds->type == 2) SETERRQ(PETSC_ERR_SUP, "DSSVD has no extra row");
   if (ds->type == 0) { ierr = DSUpdateExtraRow_HEP(ds);CHKERRQ(ierr); }
   else { ierr = DSUpdateExtraRow_NHEP(ds);CHKERRQ(ierr); }
   return 0;
@@ -452,7 +541,10 @@ PetscErrorCode DSVectors(DS ds, DSMatType mat, PetscInt *j, PetscReal *rnorm) {
   if (mat >= DS_NUM_MAT) SETERRQ(PETSC_ERR_ARG_WRONG, "Invalid matrix");
   if (rnorm && !j) SETERRQ(PETSC_ERR_ORDER, "Must give a value of j");
   if (ds->type == 0) { ierr = DSVectors_HEP(ds, mat, j, rnorm);CHKERRQ(ierr); }
-  else {
+  else if (ds->type == 2) {          /* DSVectors_SVD dssvd.c:152-165 */
+    if (mat != DS_MAT_U && mat != DS_MAT_VT) SETERRQ(PETSC_ERR_ARG_OUTOFRANGE, "Invalid mat parameter");
+    if (rnorm) *rnorm = 0.0;
+  } else {
     if (mat != DS_MAT_X) SETERRQ(PETSC_ERR_SUP, "Only right eigenvectors are available");
     if (j) { ierr = DSVectors_NHEP_Eigen_Some(ds, j, rnorm);CHKERRQ(ierr); }
     else { ierr = DSVectors_NHEP_Eigen_All(ds);CHKERRQ(ierr); }
@@ -466,6 +558,7 @@ PetscErrorCode DSTruncate(DS ds, PetscInt n) {
   DSCheckAlloc(ds);
   DSCheckSolved(ds);
   if (n < ds->l || n > ds->n) SETERRQ(PETSC_ERR_ARG_OUTOFRANGE, "Illegal value of n. Must be between l and n");
+  if (ds->type == 2) SETERRQ(PETSC_ERR_SUP, "DSSVD cannot be truncated");
   if (ds->type == 0) { ierr = DSTruncate_HEP(ds, n);CHKERRQ(ierr); }
   else { ierr = DSTruncate_NHEP(ds, n);CHKERRQ(ierr); }
   ds->state = DS_STATE_TRUNCATED;

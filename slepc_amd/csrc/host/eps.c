@@ -17,6 +17,7 @@ PetscErrorCode EPSCreate(void *ctx, EPS *outeps) {
   eps->nev = 1;
   eps->tol = 0.0;                 /* PETSC_DEFAULT -> 1e-8 at setup (epssetup.c:184) */
   eps->lock = PETSC_TRUE;
+  eps->conv = EPS_CONV_REL;
   eps->problem_type = (EPSProblemType)0;
   ierr = BVCreate(ctx, &eps->V);CHKERRQ(ierr);
   ierr = DSCreate(&eps->ds);CHKERRQ(ierr);
@@ -120,6 +121,12 @@ PetscErrorCode EPSKrylovSchurSetRestart(EPS eps, PetscReal keep) {
   }
   return 0;
 }
+PetscErrorCode EPSSetConvergenceTest(EPS eps, EPSConv conv) {
+  if (!eps) SETERRQ(PETSC_ERR_ARG_NULL, "Null EPS");
+  if (conv != EPS_CONV_ABS && conv != EPS_CONV_REL) SETERRQ(PETSC_ERR_ARG_OUTOFRANGE, "Invalid 'conv' value");
+  eps->conv = conv;
+  return 0;
+}
 /* arnoldi.c:168-175 */
 PetscErrorCode EPSArnoldiSetDelayed(EPS eps, PetscBool delayed) { if (!eps) SETERRQ(PETSC_ERR_ARG_NULL, "Null EPS"); eps->delayed = delayed ? PETSC_TRUE : PETSC_FALSE; return 0; }
 PetscErrorCode EPSKrylovSchurSetLocking(EPS eps, PetscBool lock) { if (!eps) SETERRQ(PETSC_ERR_ARG_NULL, "Null EPS"); eps->lock = lock; return 0; }
@@ -151,7 +158,11 @@ PetscErrorCode EPSSetUp(EPS eps) {
   if (eps->state) return 0;
   if (!eps->A) SETERRQ(PETSC_ERR_ARG_WRONGSTATE, "EPSSetOperators must be called first");
   if (!eps->problem_type) { ierr = EPSSetProblemType(eps, EPS_NHEP);CHKERRQ(ierr); }     /* epssetup.c:138-141 */
-  ierr = MatGetSize(eps->A, &eps->n, NULL);CHKERRQ(ierr);
+  {
+    PetscInt64 ncols;
+    ierr = MatGetSize(eps->A, &eps->n, &ncols);CHKERRQ(ierr);
+    if (ncols != eps->n) SETERRQ(PETSC_ERR_ARG_WRONG, "A is a non-square matrix");        /* epssetup.c:324-326 */
+  }
   ierr = MatGetLocalSize(eps->A, &eps->nloc, NULL);CHKERRQ(ierr);
   if (eps->nev > eps->n) eps->nev = (PetscInt)eps->n;
   if (eps->ncv > eps->n) eps->ncv = (PetscInt)eps->n;
@@ -404,7 +415,8 @@ static PetscErrorCode EPSKrylovConvergence(EPS eps, PetscInt kini, PetscInt nits
     newk = k;
     ierr = DSVectors(eps->ds, DS_MAT_X, &newk, &resnorm);CHKERRQ(ierr);
     resnorm *= beta * corrf;
-    eps->errest[k] = resnorm / SlepcAbsEigenvalue(re, im);
+    /* EPSConvergedRelative / EPSConvergedAbsolute (epsdefault.c:258-280) */
+    eps->errest[k] = eps->conv == EPS_CONV_ABS ? resnorm : resnorm / SlepcAbsEigenvalue(re, im);
     if (marker == -1 && eps->errest[k] >= eps->tol) marker = k;
     if (newk == k + 1) { eps->errest[k + 1] = eps->errest[k]; k++; }
     if (marker != -1) break;

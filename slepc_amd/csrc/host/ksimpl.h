@@ -24,9 +24,9 @@ void KSErrorTrace(const char *func, int line);
 static inline PetscReal SlepcAbsEigenvalue(PetscScalar re, PetscScalar im) { return hypot(re, im); }
 
 struct _p_DS {
-  int type;                 /* 0 hep, 1 nhep */
+  int type;                 /* 0 hep, 1 nhep, 2 svd */
   PetscBool compact, extrarow;
-  PetscInt ld, n, l, k, t;
+  PetscInt ld, n, m, l, k, t;
   DSStateType state;
   PetscScalar *mat[DS_NUM_MAT];
   PetscReal *rmat;          /* DS_MAT_T: 3*ld reals */
@@ -50,6 +50,7 @@ struct _p_EPS {
   SlepcCompareFn cmp;
   PetscReal keep;
   PetscBool lock, keep_set;
+  EPSConv conv;             /* convergence test: relative (default) or absolute */
   PetscBool delayed;        /* Arnoldi: delayed reorthogonalisation (arnoldi.c:168-175) */
   Vec *IS; PetscInt nini;
   PetscScalar *eigr, *eigi;

@@ -11,7 +11,7 @@ static PetscErrorCode MatMult_AIJHIP(Mat A, Vec x, Vec y) {
 }
 static PetscErrorCode MatCreateVecs_AIJHIP(Mat A, Vec *right, Vec *left) {
   PetscErrorCode ierr;
-  if (right) { ierr = VecCreateHIP((ksg_ctx)A->ctx, A->n, A->N, A->row0, right);CHKERRQ(ierr); }
+  if (right) { ierr = VecCreateHIP((ksg_ctx)A->ctx, A->cn, A->cN, A->col0, right);CHKERRQ(ierr); }
   if (left) { ierr = VecCreateHIP((ksg_ctx)A->ctx, A->n, A->N, A->row0, left);CHKERRQ(ierr); }
   return 0;
 }
@@ -21,17 +21,52 @@ static PetscErrorCode MatResidualNorm_AIJHIP(Mat A, PetscScalar kr, PetscScalar 
 }
 static PetscErrorCode MatDestroy_AIJHIP(Mat A) { CHKKSG(ksg_mat_destroy((ksg_mat)A->data)); A->data = NULL; return 0; }
 
+static PetscErrorCode MatTranspose_AIJHIP(Mat A, Mat *AT);
+
+/* wraps a libksgpu matrix */
+static PetscErrorCode MatWrap_AIJHIP(ksg_ctx ctx, ksg_mat m, Mat *A) {
+  Mat a = (Mat)calloc(1, sizeof(*a));
+  if (!a) { ksg_mat_destroy(m); SETERRQ(PETSC_ERR_MEM, "Out of memory"); }
+  a->ops.mult = MatMult_AIJHIP; a->ops.createvecs = MatCreateVecs_AIJHIP; a->ops.destroy = MatDestroy_AIJHIP;
+  a->ops.transpose = MatTranspose_AIJHIP;
+  a->data = m; a->ctx = ctx;
+  if (ksg_mat_sizes(m, &a->n, &a->N, &a->row0, NULL) || ksg_mat_col_sizes(m, &a->cn, &a->cN, &a->col0)) {
+    ksg_mat_destroy(m); free(a);
+    SETERRQ(PETSC_ERR_LIB, "libksgpu: %s", ksg_last_error());
+  }
+  /* the residual of an eigenpair only makes sense for a square operator */
+  a->ops.residualnorm = (a->N == a->cN && a->n == a->cn) ? MatResidualNorm_AIJHIP : NULL;
+  *A = a;
+  return 0;
+}
+
+static PetscErrorCode MatTranspose_AIJHIP(Mat A, Mat *AT) {
+  ksg_mat t = NULL;
+  CHKKSG(ksg_mat_transpose((ksg_mat)A->data, &t));
+  return MatWrap_AIJHIP((ksg_ctx)A->ctx, t, AT);
+}
+
 PetscErrorCode MatCreateAIJHIP(ksg_ctx ctx, PetscInt64 n, PetscInt64 N, PetscInt64 row0, const int64_t *rowptr,
                                const int32_t *colidx, const double *val, Mat *A) {
   if (!ctx || !A) SETERRQ(PETSC_ERR_ARG_NULL, "Null argument");
   ksg_mat m = NULL;
   CHKKSG(ksg_mat_create_csr(ctx, n, N, row0, rowptr, colidx, val, &m));
-  Mat a = (Mat)calloc(1, sizeof(*a));
-  if (!a) { ksg_mat_destroy(m); SETERRQ(PETSC_ERR_MEM, "Out of memory"); }
-  a->ops.mult = MatMult_AIJHIP; a->ops.createvecs = MatCreateVecs_AIJHIP; a->ops.destroy = MatDestroy_AIJHIP;
-  a->ops.residualnorm = MatResidualNorm_AIJHIP;
-  a->n = n; a->N = N; a->row0 = row0; a->data = m; a->ctx = ctx;
-  *A = a;
+  return MatWrap_AIJHIP(ctx, m, A);
+}
+
+PetscErrorCode MatCreateAIJHIPRect(ksg_ctx ctx, PetscInt64 m, PetscInt64 M, PetscInt64 row0, PetscInt64 n, PetscInt64 N,
+                                   PetscInt64 col0, const int64_t *rowptr, const int32_t *colidx, const double *val, Mat *A) {
+  if (!ctx || !A) SETERRQ(PETSC_ERR_ARG_NULL, "Null argument");
+  ksg_mat mm = NULL;
+  CHKKSG(ksg_mat_create_csr_rect(ctx, m, M, row0, n, N, col0, rowptr, colidx, val, &mm));
+  return MatWrap_AIJHIP(ctx, mm, A);
+}
+
+PetscErrorCode MatTranspose(Mat A, Mat *AT) {
+  PetscErrorCode ierr;
+  if (!A || !AT) SETERRQ(PETSC_ERR_ARG_NULL, "Null argument");
+  if (!A->ops.transpose) SETERRQ(PETSC_ERR_SUP, "This matrix type cannot be transposed");
+  ierr = A->ops.transpose(A, AT);CHKERRQ(ierr);
   return 0;
 }
 
@@ -41,9 +76,24 @@ PetscErrorCode MatCreateShell(void *ctx, PetscInt64 n, PetscInt64 N, PetscInt64 
   if (n < 0 || N < n) SETERRQ(PETSC_ERR_ARG_OUTOFRANGE, "Invalid sizes");
   Mat a = (Mat)calloc(1, sizeof(*a));
   if (!a) SETERRQ(PETSC_ERR_MEM, "Out of memory");
-  a->ops.mult = mult; a->ops.createvecs = createvecs; a->ops.destroy = NULL; a->ops.residualnorm = NULL;
+  a->ops.mult = mult; a->ops.createvecs = createvecs; a->ops.destroy = NULL; a->ops.residualnorm = NULL; a->ops.transpose = NULL;
   a->n = n; a->N = N; a->row0 = row0; a->data = user; a->ctx = ctx;
+  a->cn = n; a->cN = N; a->col0 = row0;
   *A = a;
+  return 0;
+}
+
+/* a shell whose MatMult takes vectors of another layout than its rows (rectangular), and
+ * the routine that builds its transpose (MatShellSetOperation(A,MATOP_TRANSPOSE,...)) */
+PetscErrorCode MatShellSetColumnLayout(Mat A, PetscInt64 n, PetscInt64 N, PetscInt64 col0) {
+  if (!A) SETERRQ(PETSC_ERR_ARG_NULL, "Null matrix");
+  if (n < 0 || N < n || col0 < 0) SETERRQ(PETSC_ERR_ARG_OUTOFRANGE, "Invalid sizes");
+  A->cn = n; A->cN = N; A->col0 = col0;
+  return 0;
+}
+PetscErrorCode MatShellSetTranspose(Mat A, PetscErrorCode (*transpose)(Mat, Mat *)) {
+  if (!A) SETERRQ(PETSC_ERR_ARG_NULL, "Null matrix");
+  A->ops.transpose = transpose;
   return 0;
 }
 
@@ -53,7 +103,7 @@ PetscErrorCode MatMult(Mat A, Vec x, Vec y) {
   PetscErrorCode ierr;
   if (!A || !x || !y) SETERRQ(PETSC_ERR_ARG_NULL, "Null argument");
   if (x == y || x->array == y->array) SETERRQ(PETSC_ERR_ARG_WRONG, "x and y must be different vectors");
-  if (x->n != A->n || y->n != A->n) SETERRQ(PETSC_ERR_ARG_SIZ, "Mat local size %lld, vectors %lld and %lld", (long long)A->n, (long long)x->n, (long long)y->n);
+  if (x->n != A->cn || y->n != A->n) SETERRQ(PETSC_ERR_ARG_SIZ, "Mat local size %lld x %lld, vectors %lld and %lld", (long long)A->n, (long long)A->cn, (long long)x->n, (long long)y->n);
   ierr = A->ops.mult(A, x, y);CHKERRQ(ierr);
   y->state++;
   return 0;
@@ -66,8 +116,8 @@ PetscErrorCode MatCreateVecs(Mat A, Vec *right, Vec *left) {
   ierr = A->ops.createvecs(A, right, left);CHKERRQ(ierr);
   return 0;
 }
-PetscErrorCode MatGetSize(Mat A, PetscInt64 *M, PetscInt64 *N) { if (!A) SETERRQ(PETSC_ERR_ARG_NULL, "Null matrix"); if (M) *M = A->N; if (N) *N = A->N; return 0; }
-PetscErrorCode MatGetLocalSize(Mat A, PetscInt64 *m, PetscInt64 *n) { if (!A) SETERRQ(PETSC_ERR_ARG_NULL, "Null matrix"); if (m) *m = A->n; if (n) *n = A->n; return 0; }
+PetscErrorCode MatGetSize(Mat A, PetscInt64 *M, PetscInt64 *N) { if (!A) SETERRQ(PETSC_ERR_ARG_NULL, "Null matrix"); if (M) *M = A->N; if (N) *N = A->cN; return 0; }
+PetscErrorCode MatGetLocalSize(Mat A, PetscInt64 *m, PetscInt64 *n) { if (!A) SETERRQ(PETSC_ERR_ARG_NULL, "Null matrix"); if (m) *m = A->n; if (n) *n = A->cn; return 0; }
 PetscErrorCode MatDestroy(Mat *A) {
   PetscErrorCode ierr;
   if (!A || !*A) return 0;
@@ -210,14 +260,16 @@ PetscErrorCode MatLoadAIJHIP(ksg_ctx ctx, const char *filename, int rank, int nr
   if (!ctx || !A) SETERRQ(PETSC_ERR_ARG_NULL, "Null argument");
   if (nranks < 1 || rank < 0 || rank >= nranks) SETERRQ(PETSC_ERR_ARG_OUTOFRANGE, "Rank %d of %d", rank, nranks);
   ierr = KSMatReadPetscBinary(filename, &M, &N, &rp, &ci, &va);CHKERRQ(ierr);
-  if (M != N) { free(rp); free(ci); free(va); SETERRQ(PETSC_ERR_ARG_SIZ, "%s: matrix is %lld x %lld, the operator must be square", filename, (long long)M, (long long)N); }
   /* contiguous row blocks, the first M mod nranks ranks one row longer (PetscSplitOwnership) */
   const PetscInt64 base = M / nranks, extra = M % nranks;
   const PetscInt64 row0 = rank * base + (rank < extra ? rank : extra), n = base + (rank < extra ? 1 : 0);
   int64_t *lrp = (int64_t *)malloc(((size_t)n + 1) * sizeof(*lrp));
   if (!lrp) { free(rp); free(ci); free(va); SETERRQ(PETSC_ERR_MEM, "Out of memory"); }
   for (PetscInt64 r = 0; r <= n; r++) lrp[r] = rp[row0 + r] - rp[row0];
-  ierr = MatCreateAIJHIP(ctx, n, M, row0, lrp, ci + rp[row0], va + rp[row0], A);
+  /* columns (the layout of x) are split the same way */
+  const PetscInt64 cbase = N / nranks, cextra = N % nranks;
+  const PetscInt64 col0 = rank * cbase + (rank < cextra ? rank : cextra), cn = cbase + (rank < cextra ? 1 : 0);
+  ierr = MatCreateAIJHIPRect(ctx, n, M, row0, cn, N, col0, lrp, ci + rp[row0], va + rp[row0], A);
   free(lrp); free(rp); free(ci); free(va);
   CHKERRQ(ierr);
   return 0;

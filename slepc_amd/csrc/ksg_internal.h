@@ -109,7 +109,10 @@ struct ksg_csr_dev {
 struct ksg_mat_s {
   ksg_ctx ctx;
   int64_t n, N, row0, nnz;
-  ksg_csr_dev diag;          /* columns local (col - row0)                     */
+  int64_t nc, NC, col0;      /* column layout: x has nc local entries, columns [col0,col0+nc) are local */
+  std::vector<int64_t> cstarts;  /* first column of every rank, nranks+1 (empty with one rank) */
+  std::vector<int32_t> ghosts;   /* global column of every ghost-buffer slot */
+  ksg_csr_dev diag;          /* columns local (col - col0)                     */
   /* ghost block: only rows that have ghost entries */
   int64_t no_rows;           /* number of such rows                            */
   int32_t *o_rows;           /* their local row indices                        */

@@ -322,6 +322,7 @@ static void csr_free(ksg_csr_dev *D) {
 }
 
 static int validate_csr(int64_t n, int64_t N, const int64_t *rowptr, const int32_t *colidx) {
+  /* N: number of columns */
   if (rowptr[0] != 0) KSG_FAIL(KSG_ERR_ARG, "ksg_mat_create_csr: rowptr[0] must be 0");
   for (int64_t i = 0; i < n; i++)
     if (rowptr[i + 1] < rowptr[i]) KSG_FAIL(KSG_ERR_ARG, "ksg_mat_create_csr: rowptr decreases at row %lld", (long long)i);
@@ -332,17 +333,31 @@ static int validate_csr(int64_t n, int64_t N, const int64_t *rowptr, const int32
   return KSG_OK;
 }
 
-extern "C" int ksg_mat_create_csr(ksg_ctx c, int64_t n, int64_t N, int64_t row0, const int64_t *rowptr,
-                                  const int32_t *colidx, const double *val, ksg_mat *out) {
-  if (!c || !out || !rowptr || n < 0 || N < n || row0 < 0 || row0 + n > N)
+/* all-gather of one int64 per rank plus the end of the last block, through a zero-padded sum */
+static int gather_starts(ksg_ctx c, int64_t first, int64_t count, std::vector<int64_t> &out) {
+  const int P = c->nranks;
+  std::vector<double> starts((size_t)P + 1, 0.0);
+  starts[c->rank] = (double)first;
+  if (c->rank == P - 1) starts[P] = (double)(first + count);
+  KSG_CHK(ksg_comm_allreduce_host(c, starts.data(), P + 1, 0));
+  out.resize((size_t)P + 1);
+  for (int p = 0; p <= P; p++) out[p] = (int64_t)starts[p];
+  return KSG_OK;
+}
+
+static int mat_create(ksg_ctx c, int64_t n, int64_t N, int64_t row0, int64_t nc, int64_t NC, int64_t col0,
+                      const int64_t *rowptr, const int32_t *colidx, const double *val, ksg_mat *out) {
+  if (!c || !out || !rowptr || n < 0 || N < n || row0 < 0 || row0 + n > N || nc < 0 || NC < nc || col0 < 0 || col0 + nc > NC)
     KSG_FAIL(KSG_ERR_ARG, "ksg_mat_create_csr: bad arguments");
-  if (N > (int64_t)INT32_MAX) KSG_FAIL(KSG_ERR_UNSUPPORTED, "ksg_mat_create_csr: N exceeds 32-bit column indices");
+  if (NC > (int64_t)INT32_MAX) KSG_FAIL(KSG_ERR_UNSUPPORTED, "ksg_mat_create_csr: N exceeds 32-bit column indices");
+  if (n > (int64_t)INT32_MAX) KSG_FAIL(KSG_ERR_UNSUPPORTED, "ksg_mat_create_csr: more than 2^31-1 local rows");
   if (rowptr[n] > 0 && (!colidx || !val)) KSG_FAIL(KSG_ERR_ARG, "ksg_mat_create_csr: NULL arrays");
-  KSG_CHK(validate_csr(n, N, rowptr, colidx));
+  KSG_CHK(validate_csr(n, NC, rowptr, colidx));
   KSG_HIP(hipSetDevice(c->device));
   ksg_mat A = new (std::nothrow) ksg_mat_s();
   if (!A) KSG_FAIL(KSG_ERR_MEM, "ksg_mat_create_csr: out of host memory");
   A->ctx = c; A->n = n; A->N = N; A->row0 = row0; A->nnz = rowptr[n];
+  A->nc = nc; A->NC = NC; A->col0 = col0;
   memset(&A->diag, 0, sizeof(A->diag));
   A->no_rows = 0; A->o_rows = NULL; A->o_rowptr = NULL; A->o_colidx = NULL; A->o_val = NULL; A->o_nnz = 0;
   A->nghost = A->nsend = 0;
@@ -351,7 +366,7 @@ extern "C" int ksg_mat_create_csr(ksg_ctx c, int64_t n, int64_t N, int64_t row0,
   int rc = KSG_OK;
 
   if (P == 1) {
-    if (row0 != 0 || n != N) { delete A; KSG_FAIL(KSG_ERR_ARG, "ksg_mat_create_csr: one rank must own all rows"); }
+    if (row0 != 0 || n != N || col0 != 0 || nc != NC) { delete A; KSG_FAIL(KSG_ERR_ARG, "ksg_mat_create_csr: one rank must own all rows and columns"); }
     rc = csr_to_device(&A->diag, n, rowptr, colidx, val);
     if (rc) { csr_free(&A->diag); delete A; return rc; }
     *out = A;
@@ -359,19 +374,21 @@ extern "C" int ksg_mat_create_csr(ksg_ctx c, int64_t n, int64_t N, int64_t row0,
   }
 
   /* ---- several ranks: ownership ranges (allgather through a zero-padded sum) ---- */
-  std::vector<double> starts((size_t)P + 1, 0.0);
-  starts[c->rank] = (double)row0;
-  if (c->rank == P - 1) starts[P] = (double)(row0 + n);
-  rc = ksg_comm_allreduce_host(c, starts.data(), P + 1, 0);
+  std::vector<int64_t> rs;
+  rc = gather_starts(c, row0, n, rs);
   if (rc) { delete A; return rc; }
-  std::vector<int64_t> rs((size_t)P + 1);
-  for (int p = 0; p <= P; p++) rs[p] = (int64_t)starts[p];
   if (rs[0] != 0 || rs[P] != N) { delete A; KSG_FAIL(KSG_ERR_ARG, "ksg_mat_create_csr: row blocks do not tile [0,N)"); }
   for (int p = 0; p < P; p++) if (rs[p + 1] < rs[p]) { delete A; KSG_FAIL(KSG_ERR_ARG, "ksg_mat_create_csr: row blocks are not ordered by rank"); }
+  /* the vector x is distributed by column blocks (the same as the rows for a square operator) */
+  rc = gather_starts(c, col0, nc, A->cstarts);
+  if (rc) { delete A; return rc; }
+  const std::vector<int64_t> &cs = A->cstarts;
+  if (cs[0] != 0 || cs[P] != NC) { delete A; KSG_FAIL(KSG_ERR_ARG, "ksg_mat_create_csr: column blocks do not tile [0,NC)"); }
+  for (int p = 0; p < P; p++) if (cs[p + 1] < cs[p]) { delete A; KSG_FAIL(KSG_ERR_ARG, "ksg_mat_create_csr: column blocks are not ordered by rank"); }
 
   /* ---- split into diagonal and ghost block ---- */
   const int64_t nnz = rowptr[n];
-  const int64_t lo = row0, hi = row0 + n;
+  const int64_t lo = col0, hi = col0 + nc;
   std::vector<int64_t> d_rp((size_t)n + 1, 0), o_rp;
   std::vector<int32_t> d_ci, o_ci, o_rows;
   std::vector<double> d_v, o_v;
@@ -393,6 +410,7 @@ extern "C" int ksg_mat_create_csr(ksg_ctx c, int64_t n, int64_t N, int64_t row0,
   for (size_t p = 0; p < o_ci.size(); p++)
     o_ci[p] = (int32_t)(std::lower_bound(ghosts.begin(), ghosts.end(), o_ci[p]) - ghosts.begin());
   A->nghost = (int64_t)ghosts.size();
+  A->ghosts = ghosts;
 
   /* ---- who owns my ghosts: receive offsets (ghosts are sorted, so grouped by owner) ---- */
   A->recvoff.assign((size_t)P + 1, 0);
@@ -400,7 +418,7 @@ extern "C" int ksg_mat_create_csr(ksg_ctx c, int64_t n, int64_t N, int64_t row0,
     size_t g = 0;
     for (int p = 0; p < P; p++) {
       A->recvoff[p] = (int64_t)g;
-      while (g < ghosts.size() && (int64_t)ghosts[g] < rs[p + 1]) g++;
+      while (g < ghosts.size() && (int64_t)ghosts[g] < cs[p + 1]) g++;
     }
     A->recvoff[P] = (int64_t)ghosts.size();
   }
@@ -422,7 +440,7 @@ extern "C" int ksg_mat_create_csr(ksg_ctx c, int64_t n, int64_t N, int64_t row0,
   std::vector<int32_t> send_idx((size_t)std::max<int64_t>(A->nsend, 1));
   for (int64_t i = 0; i < A->nsend; i++) {
     const int64_t gidx = (int64_t)asked[i];
-    if (gidx < lo || gidx >= hi) { delete A; KSG_FAIL(KSG_ERR_COMM, "halo plan: rank asked for row %lld that is not mine", (long long)gidx); }
+    if (gidx < lo || gidx >= hi) { delete A; KSG_FAIL(KSG_ERR_COMM, "halo plan: rank asked for entry %lld that is not mine", (long long)gidx); }
     send_idx[i] = (int32_t)(gidx - lo);
   }
 
@@ -444,6 +462,152 @@ extern "C" int ksg_mat_create_csr(ksg_ctx c, int64_t n, int64_t N, int64_t row0,
   if (rc) { ksg_mat_destroy(A); if (rc == KSG_ERR_MEM) ksg_set_error("ksg_mat_create_csr: out of device memory"); return rc; }
   *out = A;
   return KSG_OK;
+}
+
+extern "C" int ksg_mat_create_csr(ksg_ctx c, int64_t n, int64_t N, int64_t row0, const int64_t *rowptr,
+                                  const int32_t *colidx, const double *val, ksg_mat *out) {
+  return mat_create(c, n, N, row0, n, N, row0, rowptr, colidx, val, out);
+}
+
+extern "C" int ksg_mat_create_csr_rect(ksg_ctx c, int64_t n, int64_t N, int64_t row0, int64_t nc, int64_t NC,
+                                       int64_t col0, const int64_t *rowptr, const int32_t *colidx,
+                                       const double *val, ksg_mat *out) {
+  return mat_create(c, n, N, row0, nc, NC, col0, rowptr, colidx, val, out);
+}
+
+extern "C" int ksg_mat_col_sizes(ksg_mat A, int64_t *nc, int64_t *NC, int64_t *col0) {
+  if (!A) KSG_FAIL(KSG_ERR_ARG, "ksg_mat_col_sizes: NULL matrix");
+  if (nc) *nc = A->nc;
+  if (NC) *NC = A->NC;
+  if (col0) *col0 = A->col0;
+  return KSG_OK;
+}
+
+template <class T>
+static int download(std::vector<T> &dst, const T *src, size_t count) {
+  dst.resize(count);
+  if (count) KSG_HIP(hipMemcpy(dst.data(), src, count * sizeof(T), hipMemcpyDeviceToHost));
+  return KSG_OK;
+}
+
+/* the local rows back on the host with global column indices (the two blocks of a
+ * distributed matrix merged again, every row in ascending column order when it was given so) */
+static int mat_to_host(ksg_mat A, std::vector<int64_t> &rp, std::vector<int32_t> &ci, std::vector<double> &va) {
+  ksg_ctx c = A->ctx;
+  KSG_HIP(hipSetDevice(c->device));
+  KSG_HIP(hipStreamSynchronize(c->stream));
+  std::vector<int64_t> drp;
+  std::vector<int32_t> dci;
+  std::vector<double> dva;
+  if (A->diag.rowptr) {
+    KSG_CHK(download(drp, A->diag.rowptr, (size_t)A->n + 1));
+    KSG_CHK(download(dci, A->diag.colidx, (size_t)A->diag.nnz));
+    KSG_CHK(download(dva, A->diag.val, (size_t)A->diag.nnz));
+  } else {
+    drp.assign((size_t)A->n + 1, 0);
+  }
+  if (c->nranks == 1) {
+    rp.swap(drp); ci.swap(dci); va.swap(dva);
+    return KSG_OK;
+  }
+  std::vector<int32_t> orows, oci;
+  std::vector<int64_t> orp;
+  std::vector<double> ova;
+  KSG_CHK(download(orows, A->o_rows, (size_t)A->no_rows));
+  KSG_CHK(download(orp, A->o_rowptr, (size_t)A->no_rows + 1));
+  KSG_CHK(download(oci, A->o_colidx, (size_t)A->o_nnz));
+  KSG_CHK(download(ova, A->o_val, (size_t)A->o_nnz));
+  rp.assign((size_t)A->n + 1, 0);
+  ci.clear(); va.clear();
+  ci.reserve((size_t)A->nnz); va.reserve((size_t)A->nnz);
+  size_t o = 0;
+  for (int64_t i = 0; i < A->n; i++) {
+    int64_t a = drp[i], ae = drp[i + 1], b = 0, be = 0;
+    if (o < orows.size() && orows[o] == i) { b = orp[o]; be = orp[o + 1]; o++; }
+    while (a < ae || b < be) {
+      const int64_t ga = a < ae ? (int64_t)dci[a] + A->col0 : INT64_MAX;
+      const int64_t gb = b < be ? (int64_t)A->ghosts[oci[b]] : INT64_MAX;
+      if (ga <= gb) { ci.push_back((int32_t)ga); va.push_back(dva[a]); a++; }
+      else { ci.push_back((int32_t)gb); va.push_back(ova[b]); b++; }
+    }
+    rp[i + 1] = (int64_t)ci.size();
+  }
+  return KSG_OK;
+}
+
+extern "C" int ksg_mat_get_csr(ksg_mat A, int64_t *rowptr, int32_t *colidx, double *val) {
+  if (!A || !rowptr) KSG_FAIL(KSG_ERR_ARG, "ksg_mat_get_csr: NULL argument");
+  if (A->nnz && (!colidx || !val)) KSG_FAIL(KSG_ERR_ARG, "ksg_mat_get_csr: NULL arrays");
+  std::vector<int64_t> rp;
+  std::vector<int32_t> ci;
+  std::vector<double> va;
+  KSG_CHK(mat_to_host(A, rp, ci, va));
+  memcpy(rowptr, rp.data(), rp.size() * sizeof(int64_t));
+  if (!ci.empty()) { memcpy(colidx, ci.data(), ci.size() * sizeof(int32_t)); memcpy(val, va.data(), va.size() * sizeof(double)); }
+  return KSG_OK;
+}
+
+/* AT = A^T as a new operator: rank p receives the entries of the columns it owns and holds
+ * them as rows (what MatTranspose does for an MPIAIJ matrix).  Collective. */
+extern "C" int ksg_mat_transpose(ksg_mat A, ksg_mat *out) {
+  if (!A || !out) KSG_FAIL(KSG_ERR_ARG, "ksg_mat_transpose: NULL argument");
+  ksg_ctx c = A->ctx;
+  const int P = c->nranks;
+  std::vector<int64_t> rp;
+  std::vector<int32_t> ci;
+  std::vector<double> va;
+  KSG_CHK(mat_to_host(A, rp, ci, va));
+  /* entries for the local rows of the transpose as (row of AT = column of A minus col0, column of AT = global row of A, value),
+   * ordered by sender rank and then by row of A */
+  std::vector<int32_t> er, ec;
+  std::vector<double> ev;
+  if (P == 1) {
+    er.reserve(ci.size()); ec.reserve(ci.size());
+    for (int64_t i = 0; i < A->n; i++)
+      for (int64_t p = rp[i]; p < rp[i + 1]; p++) { er.push_back(ci[p]); ec.push_back((int32_t)i); }
+    ev = va;
+  } else {
+    if (A->N > (int64_t)INT32_MAX) KSG_FAIL(KSG_ERR_UNSUPPORTED, "ksg_mat_transpose: more than 2^31-1 rows");
+    const std::vector<int64_t> &cs = A->cstarts;
+    std::vector<int64_t> cnt((size_t)P, 0);
+    auto owner = [&](int32_t col) { return (int)(std::upper_bound(cs.begin(), cs.end(), (int64_t)col) - cs.begin()) - 1; };
+    for (size_t p = 0; p < ci.size(); p++) cnt[owner(ci[p])]++;
+    if ((size_t)P * P > KSG_RED_MAX) KSG_FAIL(KSG_ERR_UNSUPPORTED, "ksg_mat_transpose: too many ranks");
+    std::vector<double> counts((size_t)P * P, 0.0);
+    for (int p = 0; p < P; p++) counts[(size_t)c->rank * P + p] = (double)cnt[p];
+    KSG_CHK(ksg_comm_allreduce_host(c, counts.data(), P * P, 0));
+    std::vector<int64_t> sendoff((size_t)P + 1, 0), recvoff((size_t)P + 1, 0), fill((size_t)P);
+    for (int p = 0; p < P; p++) {
+      sendoff[p + 1] = sendoff[p] + 3 * cnt[p];
+      recvoff[p + 1] = recvoff[p] + 3 * (int64_t)counts[(size_t)p * P + c->rank];
+      fill[p] = sendoff[p];
+    }
+    std::vector<double> send((size_t)std::max<int64_t>(sendoff[P], 1)), recv((size_t)std::max<int64_t>(recvoff[P], 1));
+    for (int64_t i = 0; i < A->n; i++)
+      for (int64_t p = rp[i]; p < rp[i + 1]; p++) {
+        int64_t &f = fill[owner(ci[p])];
+        send[f] = (double)(A->row0 + i); send[f + 1] = (double)ci[p]; send[f + 2] = va[p];
+        f += 3;
+      }
+    KSG_CHK(ksg_comm_exchange_host(c, send.data(), sendoff.data(), recv.data(), recvoff.data()));
+    const int64_t ne = recvoff[P] / 3;
+    er.resize((size_t)ne); ec.resize((size_t)ne); ev.resize((size_t)ne);
+    for (int64_t e = 0; e < ne; e++) {
+      const int64_t col = (int64_t)recv[3 * e + 1];
+      if (col < A->col0 || col >= A->col0 + A->nc) KSG_FAIL(KSG_ERR_COMM, "ksg_mat_transpose: received column %lld that is not mine", (long long)col);
+      er[e] = (int32_t)(col - A->col0); ec[e] = (int32_t)recv[3 * e]; ev[e] = recv[3 * e + 2];
+    }
+  }
+  /* stable counting sort by row: columns stay ascending */
+  const int64_t nrow = A->nc, ne = (int64_t)er.size();
+  std::vector<int64_t> trp((size_t)nrow + 1, 0);
+  for (int64_t e = 0; e < ne; e++) trp[er[e] + 1]++;
+  for (int64_t r = 0; r < nrow; r++) trp[r + 1] += trp[r];
+  std::vector<int64_t> pos(trp.begin(), trp.end() - 1);
+  std::vector<int32_t> tci((size_t)std::max<int64_t>(ne, 1));
+  std::vector<double> tva((size_t)std::max<int64_t>(ne, 1));
+  for (int64_t e = 0; e < ne; e++) { const int64_t q = pos[er[e]]++; tci[q] = ec[e]; tva[q] = ev[e]; }
+  return mat_create(c, A->nc, A->NC, A->col0, A->n, A->N, A->row0, trp.data(), tci.data(), tva.data(), out);
 }
 
 extern "C" int ksg_mat_destroy(ksg_mat A) {
@@ -510,7 +674,7 @@ static int mat_mult_raw(ksg_mat A, const double *x, double *y) {
 }
 
 static inline double spmv_bytes(ksg_mat A) {
-  return 12.0 * (double)A->nnz + 8.0 * (double)(A->n + 1) + 8.0 * (double)(A->n + A->nghost) + 8.0 * (double)A->n;
+  return 12.0 * (double)A->nnz + 8.0 * (double)(A->n + 1) + 8.0 * (double)(A->nc + A->nghost) + 8.0 * (double)A->n;
 }
 
 extern "C" int ksg_mat_mult(ksg_mat A, const double *x, double *y) {
@@ -530,6 +694,7 @@ extern "C" int ksg_mat_residual_norm(ksg_mat A, double kr, double ki, const doub
                                      double *work, double *norm) {
   if (!A || !norm) KSG_FAIL(KSG_ERR_ARG, "ksg_mat_residual_norm: NULL argument");
   if (A->n && !x) KSG_FAIL(KSG_ERR_ARG, "ksg_mat_residual_norm: NULL vector");
+  if (A->n != A->nc || A->N != A->NC) KSG_FAIL(KSG_ERR_ARG, "ksg_mat_residual_norm: the operator must be square");
   ksg_ctx c = A->ctx;
   const bool halo = c->nranks > 1;
   if (halo && A->n && (!work || work == x || work == xi)) KSG_FAIL(KSG_ERR_ARG, "ksg_mat_residual_norm: a separate work vector is needed with several ranks");
@@ -565,7 +730,7 @@ extern "C" int ksg_mat_residual_norm(ksg_mat A, double kr, double ki, const doub
 extern "C" int ksg_bv_matmult(ksg_bv V, ksg_mat A, ksg_bv W) {
   if (!V || !W || !A) KSG_FAIL(KSG_ERR_ARG, "ksg_bv_matmult: NULL argument");
   if (V == W) KSG_FAIL(KSG_ERR_ARG, "ksg_bv_matmult: V and W must differ");
-  if (V->n != A->n || W->n != A->n || V->k - V->l != W->k - W->l || V->l < 0 || W->l < 0)
+  if (V->n != A->nc || W->n != A->n || V->k - V->l != W->k - W->l || V->l < 0 || W->l < 0)
     KSG_FAIL(KSG_ERR_ARG, "ksg_bv_matmult: size mismatch");
   ksg_ctx c = V->ctx;
   const int nc = V->k - V->l;

@@ -76,16 +76,17 @@ MatP = C.POINTER(MatStruct)
 MATMULT_FN = C.CFUNCTYPE(Err, MatP, VecP, VecP)
 MATVECS_FN = C.CFUNCTYPE(Err, MatP, C.POINTER(VecP), C.POINTER(VecP))
 MATDESTROY_FN = C.CFUNCTYPE(Err, MatP)
+MATTRANSPOSE_FN = C.CFUNCTYPE(Err, MatP, C.POINTER(MatP))
 MATRESNORM_FN = C.CFUNCTYPE(Err, MatP, C.c_double, C.c_double, VecP, VecP, VecP, c_dp)
 
 
 class MatOps(C.Structure):
     _fields_ = [("mult", MATMULT_FN), ("createvecs", MATVECS_FN), ("destroy", MATDESTROY_FN),
-                ("residualnorm", MATRESNORM_FN)]
+                ("residualnorm", MATRESNORM_FN), ("transpose", MATTRANSPOSE_FN)]
 
 
 MatStruct._fields_ = [("ops", MatOps), ("n", c_i64), ("N", c_i64), ("row0", c_i64),
-                      ("data", C.c_void_p), ("ctx", C.c_void_p)]
+                      ("data", C.c_void_p), ("ctx", C.c_void_p), ("cn", c_i64), ("cN", c_i64), ("col0", c_i64)]
 
 
 class BVStruct(C.Structure):
@@ -147,8 +148,12 @@ SIGNATURES = {
     "VecSetValuesHost": (Err, [VecP, c_dp]),
     "VecFillHash": (Err, [VecP, C.c_uint64]),
     "MatCreateAIJHIP": (Err, [vp, c_i64, c_i64, c_i64, vp, vp, vp, C.POINTER(MatP)]),
+    "MatCreateAIJHIPRect": (Err, [vp, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, vp, vp, vp, C.POINTER(MatP)]),
+    "MatTranspose": (Err, [MatP, C.POINTER(MatP)]),
     "MatCreateShell": (Err, [vp, c_i64, c_i64, c_i64, vp, MATMULT_FN, MATVECS_FN, C.POINTER(MatP)]),
     "MatShellGetContext": (Err, [MatP, C.POINTER(vp)]),
+    "MatShellSetColumnLayout": (Err, [MatP, c_i64, c_i64, c_i64]),
+    "MatShellSetTranspose": (Err, [MatP, MATTRANSPOSE_FN]),
     "KSMatReadPetscBinary": (Err, [C.c_char_p, C.POINTER(c_i64), C.POINTER(c_i64), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]),
     "KSMatWritePetscBinary": (Err, [C.c_char_p, c_i64, c_i64, vp, vp, vp]),
     "KSFree": (None, [vp]),
@@ -230,6 +235,7 @@ SIGNATURES = {
     "EPSSetDimensions": (Err, [vp, C.c_int, C.c_int, C.c_int]),
     "EPSSetTolerances": (Err, [vp, C.c_double, C.c_int]),
     "EPSSetWhichEigenpairs": (Err, [vp, C.c_int]),
+    "EPSSetConvergenceTest": (Err, [vp, C.c_int]),
     "EPSSetInitialSpace": (Err, [vp, C.c_int, C.POINTER(VecP)]),
     "EPSKrylovSchurSetRestart": (Err, [vp, C.c_double]),
     "EPSKrylovSchurSetLocking": (Err, [vp, C.c_int]),
@@ -251,6 +257,28 @@ SIGNATURES = {
     "EPSComputeError": (Err, [vp, C.c_int, C.c_int, c_dp]),
     "EPSGetCounters": (Err, [vp, C.POINTER(c_i64), C.POINTER(c_i64)]),
     "EPSDestroy": (Err, [C.POINTER(vp)]),
+    "SVDCreate": (Err, [vp, C.POINTER(vp)]),
+    "SVDSetOperator": (Err, [vp, MatP]),
+    "SVDSetType": (Err, [vp, C.c_char_p]),
+    "SVDGetType": (Err, [vp, C.POINTER(C.c_char_p)]),
+    "SVDSetDimensions": (Err, [vp, C.c_int, C.c_int, C.c_int]),
+    "SVDGetDimensions": (Err, [vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "SVDSetTolerances": (Err, [vp, C.c_double, C.c_int]),
+    "SVDGetTolerances": (Err, [vp, c_dp, C.POINTER(C.c_int)]),
+    "SVDSetWhichSingularTriplets": (Err, [vp, C.c_int]),
+    "SVDSetConvergenceTest": (Err, [vp, C.c_int]),
+    "SVDSetInitialSpace": (Err, [vp, C.c_int, C.POINTER(VecP)]),
+    "SVDTRLanczosSetOneSide": (Err, [vp, C.c_int]),
+    "SVDCrossGetEPS": (Err, [vp, C.POINTER(vp)]),
+    "SVDGetBV": (Err, [vp, C.POINTER(BVP), C.POINTER(BVP)]),
+    "SVDSetUp": (Err, [vp]),
+    "SVDSolve": (Err, [vp]),
+    "SVDGetIterationNumber": (Err, [vp, C.POINTER(C.c_int)]),
+    "SVDGetConverged": (Err, [vp, C.POINTER(C.c_int)]),
+    "SVDGetConvergedReason": (Err, [vp, C.POINTER(C.c_int)]),
+    "SVDGetSingularTriplet": (Err, [vp, C.c_int, c_dp, VecP, VecP]),
+    "SVDComputeError": (Err, [vp, C.c_int, C.c_int, c_dp]),
+    "SVDDestroy": (Err, [C.POINTER(vp)]),
 }
 
 _lib = None
@@ -343,6 +371,25 @@ class Mat:
         return cls(p, lib)
 
     @classmethod
+    def create_aij_hip_rect(cls, ctx, rowptr, colidx, val, ncols, M=None, row0=0, ncols_local=None, col0=0):
+        """M x ncols operator from the CSR rows [row0, row0+m); one process: all of it."""
+        lib = load()
+        rp = np.ascontiguousarray(rowptr, dtype=np.int64)
+        ci = np.ascontiguousarray(colidx, dtype=np.int32)
+        va = np.ascontiguousarray(val, dtype=np.float64)
+        m = rp.size - 1
+        p = MatP()
+        check(lib.MatCreateAIJHIPRect(ctx.h, m, M if M is not None else m, row0,
+                                      ncols_local if ncols_local is not None else ncols, ncols, col0,
+                                      rp.ctypes.data, ci.ctypes.data, va.ctypes.data, C.byref(p)))
+        return cls(p, lib)
+
+    def transpose(self):
+        p = MatP()
+        check(self.lib.MatTranspose(self.p, C.byref(p)))
+        return Mat(p, self.lib)
+
+    @classmethod
     def load_aij_hip(cls, ctx, filename, rank=0, nranks=1):
         """MatLoad of a PETSc binary file onto the device (row block of `rank`)."""
         lib = load()
@@ -353,6 +400,11 @@ class Mat:
     def create_vecs(self):
         r = VecP()
         check(self.lib.MatCreateVecs(self.p, C.byref(r), None))
+        return Vec(r, self.lib)
+
+    def create_vecs_left(self):
+        r = VecP()
+        check(self.lib.MatCreateVecs(self.p, None, C.byref(r)))
         return Vec(r, self.lib)
 
     def mult(self, x, y):
@@ -366,6 +418,103 @@ class Mat:
         if self.p:
             check(self.lib.MatDestroy(C.byref(self.p)))
             self.p = None
+
+
+SVD_LARGEST, SVD_SMALLEST = 0, 1
+SVD_CONV_ABS, SVD_CONV_REL = 0, 1
+SVD_ERROR_ABSOLUTE, SVD_ERROR_RELATIVE = 0, 1
+SVD_CONVERGED_TOL, SVD_DIVERGED_ITS = 1, -1
+
+
+class SVD:
+    """``SVDCreate`` ... ``SVDDestroy`` with the argument meaning of the C interface."""
+
+    def __init__(self, ctx_handle=None):
+        self.lib = load()
+        self.h = vp()
+        check(self.lib.SVDCreate(ctx_handle, C.byref(self.h)))
+
+    def set_operator(self, A):
+        self._A = A
+        check(self.lib.SVDSetOperator(self.h, A.p))
+
+    def set_type(self, name):
+        check(self.lib.SVDSetType(self.h, name.encode()))
+
+    def get_type(self):
+        s = C.c_char_p()
+        check(self.lib.SVDGetType(self.h, C.byref(s)))
+        return s.value.decode()
+
+    def set_dimensions(self, nsv, ncv=0, mpd=0):
+        check(self.lib.SVDSetDimensions(self.h, nsv, ncv, mpd))
+
+    def set_tolerances(self, tol=0.0, max_it=0):
+        check(self.lib.SVDSetTolerances(self.h, tol, max_it))
+
+    def set_which(self, which):
+        check(self.lib.SVDSetWhichSingularTriplets(self.h, SVD_SMALLEST if which in ("smallest", SVD_SMALLEST) else SVD_LARGEST))
+
+    def set_convergence_test(self, conv):
+        check(self.lib.SVDSetConvergenceTest(self.h, SVD_CONV_ABS if conv in ("abs", SVD_CONV_ABS) else SVD_CONV_REL))
+
+    def set_initial_space(self, vecs):
+        arr = (VecP * len(vecs))(*[v.p for v in vecs])
+        check(self.lib.SVDSetInitialSpace(self.h, len(vecs), arr))
+
+    def set_oneside(self, oneside=True):
+        check(self.lib.SVDTRLanczosSetOneSide(self.h, 1 if oneside else 0))
+
+    def set_bv_type(self, name):
+        V, U = BVP(), BVP()
+        check(self.lib.SVDGetBV(self.h, C.byref(V), C.byref(U)))
+        check(self.lib.BVSetType(V, name.encode()))
+        check(self.lib.BVSetType(U, name.encode()))
+
+    def solve(self):
+        check(self.lib.SVDSolve(self.h))
+
+    def _geti(self, fn):
+        v = C.c_int()
+        check(fn(self.h, C.byref(v)))
+        return v.value
+
+    @property
+    def its(self):
+        return self._geti(self.lib.SVDGetIterationNumber)
+
+    @property
+    def nconv(self):
+        return self._geti(self.lib.SVDGetConverged)
+
+    @property
+    def reason(self):
+        return self._geti(self.lib.SVDGetConvergedReason)
+
+    def dimensions(self):
+        a, b, c = C.c_int(), C.c_int(), C.c_int()
+        check(self.lib.SVDGetDimensions(self.h, C.byref(a), C.byref(b), C.byref(c)))
+        return a.value, b.value, c.value
+
+    def tolerances(self):
+        t, m = C.c_double(), C.c_int()
+        check(self.lib.SVDGetTolerances(self.h, C.byref(t), C.byref(m)))
+        return t.value, m.value
+
+    def get_singular_triplet(self, i, u=None, v=None):
+        s = C.c_double()
+        check(self.lib.SVDGetSingularTriplet(self.h, i, C.byref(s), u.p if u else None, v.p if v else None))
+        return s.value
+
+    def compute_error(self, i, etype=SVD_ERROR_RELATIVE):
+        e = C.c_double()
+        check(self.lib.SVDComputeError(self.h, i, etype, C.byref(e)))
+        return e.value
+
+    def destroy(self):
+        if self.h:
+            check(self.lib.SVDDestroy(C.byref(self.h)))
+            self.h = None
 
 
 def read_petsc_binary(filename):

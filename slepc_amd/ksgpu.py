@@ -87,6 +87,11 @@ SIGNATURES = {
     "ksg_mat_create_csr": (C.c_int, [C.c_void_p, c_i64, c_i64, c_i64, C.c_void_p, C.c_void_p,
                                      C.c_void_p, C.POINTER(C.c_void_p)]),
     "ksg_mat_destroy": (C.c_int, [C.c_void_p]),
+    "ksg_mat_create_csr_rect": (C.c_int, [C.c_void_p, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, C.c_void_p, C.c_void_p,
+                                          C.c_void_p, C.POINTER(C.c_void_p)]),
+    "ksg_mat_col_sizes": (C.c_int, [C.c_void_p, C.POINTER(c_i64), C.POINTER(c_i64), C.POINTER(c_i64)]),
+    "ksg_mat_get_csr": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ksg_mat_transpose": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
     "ksg_mat_mult": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "ksg_mat_residual_norm": (C.c_int, [C.c_void_p, C.c_double, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p,
                                         C.POINTER(C.c_double)]),
@@ -348,7 +353,9 @@ class DeviceBV:
 class DeviceCSR:
     """Row block of a CSR matrix in device memory (``ksg_mat_*``)."""
 
-    def __init__(self, ctx, rowptr, colidx, val, N=None, row0=0):
+    def __init__(self, ctx, rowptr, colidx, val, N=None, row0=0, cols=None):
+        """``cols`` = (nc_local, NC, col0) for an operator whose columns are laid out
+        differently from its rows (rectangular); default: square, columns like rows."""
         self.ctx = ctx
         self.lib = ctx.lib
         rp = np.ascontiguousarray(rowptr, dtype=np.int64)
@@ -356,13 +363,39 @@ class DeviceCSR:
         va = np.ascontiguousarray(val, dtype=np.float64)
         n = rp.size - 1
         h = C.c_void_p()
-        check(self.lib.ksg_mat_create_csr(ctx.h, n, N if N is not None else n, row0, rp.ctypes.data,
-                                          ci.ctypes.data, va.ctypes.data, C.byref(h)))
+        if cols is None:
+            check(self.lib.ksg_mat_create_csr(ctx.h, n, N if N is not None else n, row0, rp.ctypes.data,
+                                              ci.ctypes.data, va.ctypes.data, C.byref(h)))
+        else:
+            check(self.lib.ksg_mat_create_csr_rect(ctx.h, n, N if N is not None else n, row0, cols[0], cols[1], cols[2],
+                                                   rp.ctypes.data, ci.ctypes.data, va.ctypes.data, C.byref(h)))
+        self._adopt(h)
+
+    def _adopt(self, h):
         self.h = h
-        self.n = n
-        self.N = N if N is not None else n
-        self.row0 = row0
-        self.nnz = int(rp[-1])
+        n, N, row0, nnz = c_i64(), c_i64(), c_i64(), c_i64()
+        check(self.lib.ksg_mat_sizes(h, C.byref(n), C.byref(N), C.byref(row0), C.byref(nnz)))
+        nc, NC, col0 = c_i64(), c_i64(), c_i64()
+        check(self.lib.ksg_mat_col_sizes(h, C.byref(nc), C.byref(NC), C.byref(col0)))
+        self.n, self.N, self.row0, self.nnz = n.value, N.value, row0.value, nnz.value
+        self.nc, self.NC, self.col0 = nc.value, NC.value, col0.value
+
+    def transpose(self):
+        """A^T as a new operator (collective)."""
+        h = C.c_void_p()
+        check(self.lib.ksg_mat_transpose(self.h, C.byref(h)))
+        t = DeviceCSR.__new__(DeviceCSR)
+        t.ctx, t.lib = self.ctx, self.lib
+        t._adopt(h)
+        return t
+
+    def get_csr(self):
+        """(rowptr, colidx, val) of the local rows, global column indices."""
+        rp = np.zeros(self.n + 1, dtype=np.int64)
+        ci = np.zeros(max(self.nnz, 1), dtype=np.int32)
+        va = np.zeros(max(self.nnz, 1), dtype=np.float64)
+        check(self.lib.ksg_mat_get_csr(self.h, rp.ctypes.data, ci.ctypes.data, va.ctypes.data))
+        return rp, ci[:self.nnz], va[:self.nnz]
 
     def destroy(self):
         if self.h:

@@ -54,6 +54,22 @@ class Backend:
             return self.plug.shell_mat(mv, len(rp) - 1)
         return K.Mat.create_aij_hip(self.ctx, rp, ci, va)
 
+    def mat_csr_rect(self, rp, ci, va, ncols):
+        """M x ncols operator (one process)."""
+        M = len(rp) - 1
+        if self.kind == "oracle":
+            from scipy.sparse import csr_matrix
+            A = csr_matrix((va, ci, rp), shape=(M, ncols))
+            AT = csr_matrix(A.T)
+
+            def mv(x, y):
+                y[:] = A @ x
+
+            def mvt(x, y):
+                y[:] = AT @ x
+            return self.plug.shell_mat_rect(mv, mvt, M, ncols)
+        return K.Mat.create_aij_hip_rect(self.ctx, rp, ci, va, ncols)
+
     # -- BV helpers over the C interface --
     def set_col(self, bv, j, arr):
         v = K.VecP()
@@ -265,5 +281,47 @@ def solve_eps(be, csr, hermitian=True, nev=1, ncv=0, mpd=0, tol=0.0, max_it=0, w
     if vs:
         vs.destroy()
     eps.destroy()
+    A.destroy()
+    return res
+
+
+def solve_svd(be, csr, ncols, nsv=1, ncv=0, mpd=0, tol=0.0, max_it=0, which="largest", solver=None, oneside=False,
+              conv=None, v0=None, want_vectors=False):
+    """SVDCreate / SVDSetOperator / ... / SVDSolve / SVDGetSingularTriplet / SVDComputeError."""
+    rp, ci, va = csr
+    A = be.mat_csr_rect(rp, ci, va, ncols)
+    svd = K.SVD(be.ctx.h if be.ctx else None)
+    svd.set_operator(A)
+    if solver:
+        svd.set_type(solver)
+    svd.set_dimensions(nsv, ncv, mpd)
+    svd.set_tolerances(tol, max_it)
+    svd.set_which(which)
+    if conv:
+        svd.set_convergence_test(conv)
+    if oneside:
+        svd.set_oneside(True)
+    if be.kind == "oracle":
+        svd.set_bv_type("oracle")
+    vs = None
+    if v0 is not None:
+        vs = A.create_vecs()
+        vs.set_values(v0)
+        svd.set_initial_space([vs])
+    svd.solve()
+    res = {"its": svd.its, "nconv": svd.nconv, "reason": svd.reason, "sigma": [], "errors": [], "vectors": [],
+           "type": svd.get_type(), "dims": svd.dimensions(), "tols": svd.tolerances()}
+    u, v = A.create_vecs_left(), A.create_vecs()
+    for i in range(svd.nconv):
+        res["sigma"].append(svd.get_singular_triplet(i, u, v))
+        if i < nsv + 2:
+            res["errors"].append(svd.compute_error(i))
+            if want_vectors:
+                res["vectors"].append((u.get_values(), v.get_values()))
+    for o in (u, v):
+        o.destroy()
+    if vs:
+        vs.destroy()
+    svd.destroy()
     A.destroy()
     return res

@@ -130,8 +130,32 @@ def eps_tests():
     dump("eps_tests.json", g, "src/eps/examples/{tutorials,tests}/output/*.out")
 
 
+def svd_tests():
+    def eigs(rel, marker="required tolerance:"):
+        t = read(rel)
+        return [[x.strip() for x in blk.strip().splitlines()[0].split(",")] for blk in t.split(marker)[1:]]
+
+    g = {}
+    t = read("src/svd/examples/tutorials/output/ex8_1.out")
+    m = re.search(r"sigma_1=([\d.]+), sigma_n=([\d.]+)\n.*sigma_1/sigma_n=([\d.]+)", t)
+    g["ex8"] = {"n": 30, "sigma_1": m.group(1), "sigma_n": m.group(2), "cond": m.group(3), "text": t}
+    assert read("src/svd/examples/tests/output/test1_1.out") == t
+    t = read("src/svd/examples/tutorials/output/ex14_1.out")
+    g["ex14"] = {"file": "rdb200.petsc", "nsv": 4, "its": int(re.search(r"iterations of the method: (\d+)", t).group(1)),
+                 "type": re.search(r"Solution method: (\w+)", t).group(1), "values": eigs("src/svd/examples/tutorials/output/ex14_1.out")[0],
+                 "text": t}
+    t = read("src/svd/examples/tutorials/output/ex15_1.out")
+    g["ex15"] = {"n": 100, "mu": 1.49012e-08, "its": int(re.search(r"iterations of the method: (\d+)", t).group(1)),
+                 "nconv": int(re.search(r"singular triplets: (\d+)", t).group(1)),
+                 "sigma": re.findall(r"^\s+(\d+\.\d{6})\s+\S+$", t, re.M)}
+    g["test3"] = {"rows": 35, "cols": 30, "nsv": 4, "values": eigs("src/svd/examples/tests/output/test3_1.out")[0]}
+    g["test4"] = {"rows": 20, "cols": 22, "nsv": 1, "conv": "abs", "values": eigs("src/svd/examples/tests/output/test4_1.out")[0]}
+    dump("svd_tests.json", g, "src/svd/examples/{tutorials,tests}/output/*.out")
+
+
 if __name__ == "__main__":
     bv_test1()
     bv_misc()
     ds_tests()
     eps_tests()
+    svd_tests()

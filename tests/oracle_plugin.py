@@ -307,10 +307,10 @@ def shell_mat(matvec, n, N=None, row0=0):
     @_guard
     def _vecs(A, right, left):
         a = A.contents
-        for out in (right, left):
+        for out, (n_, N_, r0_) in ((right, (a.cn, a.cN, a.col0)), (left, (a.n, a.N, a.row0))):
             if out:
                 p = K.VecP()
-                K.check(_lib.VecCreateWithOps(C.byref(VEC_OPS), None, a.n, a.N, a.row0, 1, C.byref(p)))
+                K.check(_lib.VecCreateWithOps(C.byref(VEC_OPS), None, n_, N_, r0_, 1, C.byref(p)))
                 out[0] = p
 
     cb1, cb2 = K.MATMULT_FN(_mult), K.MATVECS_FN(_vecs)
@@ -318,6 +318,25 @@ def shell_mat(matvec, n, N=None, row0=0):
     p = K.MatP()
     K.check(_lib.MatCreateShell(None, n, N if N is not None else n, row0, ident, cb1, cb2, C.byref(p)))
     return K.Mat(p, _lib)
+
+
+def shell_mat_rect(matvec, matvec_t, M, N):
+    """A rectangular M x N shell (one process) that can be transposed: MatTranspose
+    returns the N x M shell of matvec_t."""
+    A = shell_mat(matvec, M)
+    K.check(_lib.MatShellSetColumnLayout(A.p, N, N, 0))
+
+    @_guard
+    def _transpose(Ap, out):
+        T = shell_mat_rect(matvec_t, matvec, N, M)
+        _shell_keep.append(T)
+        out[0] = T.p
+        T.p = None                      # owned by the caller of MatTranspose from here on
+
+    cb = K.MATTRANSPOSE_FN(_transpose)
+    _shell_keep.append(cb)
+    K.check(_lib.MatShellSetTranspose(A.p, cb))
+    return A
 
 
 def bv_create(n, m, N=None, row0=0, bvtype=b"oracle"):
