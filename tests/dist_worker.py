@@ -22,6 +22,8 @@ def main():
     rank, _, size = kdist.env_rank()
     dist = kdist.init_process_group() if size > 1 else None
 
+    if case.startswith("svd_"):
+        return svd_main(mode, case, out, rank, size, dist)
     if case == "lap2d":
         gx, gy = 61, 47
         N = gx * gy
@@ -136,6 +138,74 @@ def main():
     Am.destroy()
     if ctx:
         ctx.close()
+
+
+def svd_main(mode, case, out, rank, size, dist):
+    """Singular values of a rectangular operator: rows and columns both split over the ranks,
+    the transpose built by the library (an exchange of entries between the ranks)."""
+    from scipy.sparse import csr_matrix
+    from slepc_amd import kseps as K, ksgpu, matgen as mg, dist as kdist
+    assert mode == "gpu"
+    M, N = (420, 300) if case.endswith("tall") else (260, 410)
+    rng = np.random.default_rng(17)                       # the same matrix on every rank
+    D = np.where(rng.random((M, N)) < 0.03, rng.standard_normal((M, N)), 0.0)
+    D[np.arange(min(M, N)), np.arange(min(M, N))] += 3.0 + np.arange(min(M, N)) / 50.0
+    A = csr_matrix(D)
+    A.sort_indices()
+    row0, row1 = mg.split_rows(M, size, rank)
+    col0, col1 = mg.split_rows(N, size, rank)
+    L = A[row0:row1]
+    ctx = ksgpu.Context(0)
+    if size > 1:
+        kdist.init_comm(ctx, transport=os.environ.get("KS_TRANSPORT", "gloo"))
+    Am = K.Mat.create_aij_hip_rect(ctx, L.indptr, L.indices, L.data, N, M=M, row0=row0, ncols_local=col1 - col0, col0=col0)
+    res = {}
+    # the transposed operator against the host, entry for entry
+    T = Am.transpose()
+    y = T.create_vecs_left()
+    x = T.create_vecs()
+    xs = np.sin(np.arange(M, dtype=float))
+    x.set_values(xs[row0:row1])
+    T.mult(x, y)
+    ref = (csr_matrix(A.T) @ xs)[col0:col1]
+    res["transpose_err"] = float(np.abs(y.get_values() - ref).max())
+    for o in (x, y):
+        o.destroy()
+    T.destroy()
+    for solver, oneside in (("trlanczos", False), ("trlanczos", True), ("cross", False)):
+        svd = K.SVD(ctx.h)
+        svd.set_operator(Am)
+        svd.set_type(solver)
+        svd.set_dimensions(4)
+        svd.set_tolerances(1e-10)
+        if oneside:
+            svd.set_oneside(True)
+        svd.solve()
+        key = solver + ("_oneside" if oneside else "")
+        res[key] = {"its": svd.its, "nconv": svd.nconv, "reason": svd.reason,
+                    "sigma": [svd.get_singular_triplet(i) for i in range(min(svd.nconv, 4))],
+                    "errors": [svd.compute_error(i) for i in range(min(svd.nconv, 4))]}
+        u, v = Am.create_vecs_left(), Am.create_vecs()
+        svd.get_singular_triplet(0, u, v)
+        lu, lv = u.get_values(), v.get_values()
+        if size > 1:
+            gu, gv = [None] * size, [None] * size
+            dist.all_gather_object(gu, lu)
+            dist.all_gather_object(gv, lv)
+            lu, lv = np.concatenate(gu), np.concatenate(gv)
+        res[key]["u0"], res[key]["v0"] = lu.tolist(), lv.tolist()
+        for o in (u, v):
+            o.destroy()
+        svd.destroy()
+    if rank == 0:
+        ref = np.linalg.svd(D, compute_uv=False)[:4]
+        res["dense_sigma"] = ref.tolist()
+        with open(out, "w") as f:
+            json.dump(res, f)
+    if dist:
+        dist.barrier()
+    Am.destroy()
+    ctx.close()
 
 
 if __name__ == "__main__":

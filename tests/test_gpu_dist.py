@@ -24,6 +24,26 @@ def test_ranks_match_single(case, nev, ranks):
     assert np.abs(s * x2 - x1).max() < 1e-6
 
 
+@pytest.mark.parametrize("case,ranks", [("svd_tall", 2), ("svd_wide", 3)])
+def test_svd_ranks_match_single(case, ranks):
+    """Rectangular operator with rows and columns split over the ranks, its transpose built
+    by the exchange of entries, and the singular value solvers on top."""
+    one = run_ranks("gpu", case, 1)
+    many = run_ranks("gpu", case, ranks)
+    assert one["transpose_err"] < 1e-12 and many["transpose_err"] < 1e-12
+    for key in ("trlanczos", "trlanczos_oneside", "cross"):
+        a, b = one[key], many[key]
+        assert a["reason"] == b["reason"] == 1 and a["nconv"] >= 4 and b["nconv"] >= 4
+        for i in range(4):
+            assert abs(a["sigma"][i] - one["dense_sigma"][i]) <= 1e-10 * one["dense_sigma"][i]
+            assert abs(b["sigma"][i] - one["dense_sigma"][i]) <= 1e-10 * one["dense_sigma"][i]
+        assert max(b["errors"]) < 1e-7
+        for w in ("u0", "v0"):
+            x1, x2 = np.array(a[w]), np.array(b[w])
+            s = np.sign(x1 @ x2)
+            assert np.abs(s * x2 - x1).max() < 1e-6
+
+
 def test_rccl_single_rank_communicator():
     """dlopen of RCCL, ncclCommInitRank and the all-reduce on the compute stream."""
     from slepc_amd import ksgpu
