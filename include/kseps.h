@@ -172,6 +172,7 @@ PetscErrorCode MatDestroy(Mat *A);
 /* ------------------------------------------------------------------ BV */
 typedef enum { BV_ORTHOG_CGS = 0, BV_ORTHOG_MGS = 1 } BVOrthogType;
 typedef enum { BV_ORTHOG_REFINE_IFNEEDED = 0, BV_ORTHOG_REFINE_NEVER = 1, BV_ORTHOG_REFINE_ALWAYS = 2 } BVOrthogRefineType;
+typedef enum { BV_ORTHOG_BLOCK_GS = 0, BV_ORTHOG_BLOCK_CHOL = 1, BV_ORTHOG_BLOCK_TSQR = 2 } BVOrthogBlockType;
 
 /* Op table of a BV type: struct _BVOps of include/slepc/private/bvimpl.h:35-64.
  * Q matrices are host column-major arrays with leading dimension ldq. */
@@ -213,6 +214,7 @@ struct _p_BV {
   uint64_t rand_seed;
   void *data;                   /* type-specific (ksg_bv for "hip") */
   void *ctx;
+  BVOrthogBlockType orthog_block;   /* method of BVOrthogonalize */
 };
 
 PetscErrorCode BVCreate(void *ctx, BV *bv);
@@ -226,7 +228,8 @@ PetscErrorCode BVGetSizes(BV bv, PetscInt64 *n, PetscInt64 *N, PetscInt *m);
 PetscErrorCode BVResize(BV bv, PetscInt m, PetscBool copy);
 PetscErrorCode BVSetActiveColumns(BV bv, PetscInt l, PetscInt k);
 PetscErrorCode BVGetActiveColumns(BV bv, PetscInt *l, PetscInt *k);
-PetscErrorCode BVSetOrthogonalization(BV bv, BVOrthogType type, BVOrthogRefineType refine, PetscReal eta);
+/* bvorthog.c: eta 0 stands for PETSC_DEFAULT (0.7071) */
+PetscErrorCode BVSetOrthogonalization(BV bv, BVOrthogType type, BVOrthogRefineType refine, PetscReal eta, BVOrthogBlockType block);
 PetscErrorCode BVGetColumn(BV bv, PetscInt j, Vec *v);
 PetscErrorCode BVRestoreColumn(BV bv, PetscInt j, Vec *v);
 PetscErrorCode BVGetBuffer(BV bv, PetscScalar **buffer, PetscInt *ld);     /* BVGetBufferVec */
@@ -253,6 +256,13 @@ PetscErrorCode BVMatMult(BV V, Mat A, BV W);
 PetscErrorCode BVOrthogonalizeVec(BV bv, Vec v, PetscScalar *H, PetscReal *norm, PetscBool *lindep);
 PetscErrorCode BVOrthogonalizeColumn(BV bv, PetscInt j, PetscScalar *H, PetscReal *norm, PetscBool *lindep);
 PetscErrorCode BVOrthonormalizeColumn(BV bv, PetscInt j, PetscBool replace, PetscReal *norm, PetscBool *lindep);
+/* QR factorisation of the active columns (bvorthog.c:768-859): V <- Q with V0 = Q R.  R is a
+ * host column-major array with leading dimension ldr >= k (only the block [l,k) x [l,k) is
+ * referenced) or NULL.  Block method as set with BVSetOrthogonalization: column by column
+ * Gram-Schmidt (BVOrthogonalize_GS, :635-680) or Cholesky QR, R = chol(V'V), Q = V inv(R)
+ * (BVOrthogonalize_Chol, :749-765: one Gram kernel and one block-update kernel).  The
+ * tall-skinny QR variant is not available. */
+PetscErrorCode BVOrthogonalize(BV V, PetscScalar *R, PetscInt ldr);
 PetscErrorCode BVDestroy(BV *bv);
 /* Constructor of the device type, registered as "hip" (the role BVCreate_Svec plays
  * for "svec", svec.c:417-520). */

@@ -372,3 +372,35 @@ class BV:
             if self.n:
                 self.op_scale(j, 1.0 / nrm)
         return nrm, lndep
+
+
+def orthogonalize_block(V, method="gs", want_R=False):
+    """``BVOrthogonalize`` (bvorthog.c:768-859) of the active columns of the oracle BV ``V``:
+    "gs" column by column (``BVOrthogonalize_GS``, :635-680) or "chol" (``BVOrthogonalize_Chol``
+    with ``MatCholeskyFactorInvert``, :683-765).  Returns R (k x k, only the block [l,k) set)
+    when asked for."""
+    l, k = V.l, V.k
+    R = np.zeros((k, k))
+    if method == "gs":
+        for j in range(l, k):
+            H = np.zeros(k)
+            norm, _ = V.orthogonalize_column(j, H)
+            if not norm:
+                raise ArithmeticError("Breakdown in BVOrthogonalize due to a linearly dependent column")
+            R[l:j, j] = H[:j - l]
+            R[j, j] = norm
+            V.scale_column(j, 1.0 / norm)
+    elif method == "chol":
+        V.op_dot(V, R)
+        G = R[l:k, l:k]
+        try:
+            U = np.linalg.cholesky(G).T
+        except np.linalg.LinAlgError:
+            U = np.linalg.cholesky(G + 50.0 * EPSILON * np.eye(k - l)).T
+        R[l:k, l:k] = U
+        S = np.zeros((k, k))
+        S[l:k, l:k] = np.triu(np.linalg.inv(U))
+        V.op_multinplace(S, l, k, False)
+    else:
+        raise ValueError(method)
+    return R if want_R else None

@@ -5,6 +5,7 @@
  * control flow, which is the same for every type. */
 #include <stdio.h>
 
+#include "dense.h"
 #include "ksimpl.h"
 
 PetscInt64 ks_gs_passes = 0;
@@ -125,11 +126,12 @@ PetscErrorCode BVGetActiveColumns(BV bv, PetscInt *l, PetscInt *k) {
   return 0;
 }
 
-PetscErrorCode BVSetOrthogonalization(BV bv, BVOrthogType type, BVOrthogRefineType refine, PetscReal eta) {
+PetscErrorCode BVSetOrthogonalization(BV bv, BVOrthogType type, BVOrthogRefineType refine, PetscReal eta, BVOrthogBlockType block) {
   if (!bv) SETERRQ(PETSC_ERR_ARG_NULL, "Null BV");
   if (type != BV_ORTHOG_CGS && type != BV_ORTHOG_MGS) SETERRQ(PETSC_ERR_ARG_WRONG, "Unknown orthogonalization type");
   if (refine < BV_ORTHOG_REFINE_IFNEEDED || refine > BV_ORTHOG_REFINE_ALWAYS) SETERRQ(PETSC_ERR_ARG_WRONG, "Unknown refinement type");
-  bv->orthog_type = type; bv->orthog_ref = refine;
+  if (block < BV_ORTHOG_BLOCK_GS || block > BV_ORTHOG_BLOCK_TSQR) SETERRQ(PETSC_ERR_ARG_WRONG, "Unknown block orthogonalization type");
+  bv->orthog_type = type; bv->orthog_ref = refine; bv->orthog_block = block;
   if (eta == 0.0) bv->orthog_eta = 0.7071;       /* PETSC_DEFAULT */
   else {
     if (eta <= 0.0 || eta > 1.0) SETERRQ(PETSC_ERR_ARG_OUTOFRANGE, "Invalid eta value");
@@ -671,5 +673,75 @@ PetscErrorCode BVDestroy(BV *bv) {
   free(b->h);
   free(b);
   *bv = NULL;
+  return 0;
+}
+
+/* ---- block orthogonalisation (bvorthog.c:635-859) ------------------------------------------- */
+/* bvorthog.c:635-680, standard inner product */
+static PetscErrorCode BVOrthogonalize_GS(BV V, PetscScalar *r, PetscInt ldr) {
+  PetscErrorCode ierr;
+  PetscReal norm;
+  for (PetscInt j = V->l; j < V->k; j++) {
+    if (r) {
+      ierr = BVOrthogonalizeColumn(V, j, r + (size_t)j * ldr + V->l, &norm, NULL);CHKERRQ(ierr);
+      r[j + (size_t)j * ldr] = norm;
+    } else { ierr = BVOrthogonalizeColumn(V, j, NULL, &norm, NULL);CHKERRQ(ierr); }
+    if (!norm) SETERRQ(1, "Breakdown in BVOrthogonalize due to a linearly dependent column");
+    ierr = BVScaleColumn(V, j, 1.0 / norm);CHKERRQ(ierr);
+  }
+  return 0;
+}
+
+/* bvorthog.c:683-765: R = chol(V'V) on the block [l,k), S = inv(R), V <- V S */
+static PetscErrorCode BVOrthogonalize_Chol(BV V, PetscScalar *Rin, PetscInt ldrin) {
+  PetscErrorCode ierr = 0;
+  const PetscInt m = V->k, l = V->l, n = m - l;
+  PetscInt i, j, ld = Rin ? ldrin : m;
+  PetscScalar *R = Rin, *S = NULL;
+  if (!Rin) { R = (PetscScalar *)calloc((size_t)m * m, sizeof(*R)); if (!R) SETERRQ(PETSC_ERR_MEM, "Out of memory"); }
+  S = (PetscScalar *)calloc((size_t)ld * m, sizeof(*S));
+  if (!S) { if (!Rin) free(R); SETERRQ(PETSC_ERR_MEM, "Out of memory"); }
+  ierr = BVDot(V, V, R, ld);
+  if (!ierr) {
+    /* keep a copy, factor, retry once on a slightly shifted matrix as the reference does */
+    for (j = l; j < m; j++) memcpy(S + (size_t)j * ld + l, R + (size_t)j * ld + l, (size_t)n * sizeof(PetscScalar));
+    int info = ksd_potrf_upper(n, R + (size_t)l * ld + l, ld);
+    if (info) {
+      for (j = l; j < m; j++) { memcpy(R + (size_t)j * ld + l, S + (size_t)j * ld + l, (size_t)n * sizeof(PetscScalar)); R[j + (size_t)j * ld] += 50.0 * PETSC_MACHINE_EPSILON; }
+      info = ksd_potrf_upper(n, R + (size_t)l * ld + l, ld);
+      if (info) ierr = KSError(__func__, __LINE__, 1, "Error in Cholesky factorization, info=%d", info);
+    }
+  }
+  if (!ierr) {
+    memset(S, 0, (size_t)ld * m * sizeof(PetscScalar));
+    for (j = l; j < m; j++) memcpy(S + (size_t)j * ld + l, R + (size_t)j * ld + l, (size_t)n * sizeof(PetscScalar));
+    const int info = ksd_trtri_upper(n, S + (size_t)l * ld + l, ld);
+    if (info) ierr = KSError(__func__, __LINE__, 1, "Error in the triangular inverse, info=%d", info);
+  }
+  if (!ierr) {
+    /* zero out entries below the diagonal */
+    for (j = l; j < m - 1; j++) for (i = j + 1; i < m; i++) { R[i + (size_t)j * ld] = 0.0; S[i + (size_t)j * ld] = 0.0; }
+    ierr = BVMultInPlace(V, S, ld, l, m);
+  }
+  free(S);
+  if (!Rin) free(R);
+  CHKERRQ(ierr);
+  return 0;
+}
+
+PetscErrorCode BVOrthogonalize(BV V, PetscScalar *R, PetscInt ldr) {
+  PetscErrorCode ierr;
+  BVCheckSizes(V);
+  if (R) {
+    if (V->l > 0 && V->orthog_block == BV_ORTHOG_BLOCK_GS) SETERRQ(PETSC_ERR_SUP, "Cannot request matrix R in Gram-Schmidt orthogonalization if l>0");
+    if (ldr < V->k) SETERRQ(PETSC_ERR_ARG_SIZ, "Mat size %d is smaller than the number of BV active columns %d", ldr, V->k);
+  }
+  if (V->nc) SETERRQ(PETSC_ERR_SUP, "Not implemented for BV with constraints, use BVOrthogonalizeColumn() instead");
+  switch (V->orthog_block) {
+    case BV_ORTHOG_BLOCK_GS: ierr = BVOrthogonalize_GS(V, R, ldr);CHKERRQ(ierr); break;
+    case BV_ORTHOG_BLOCK_CHOL: ierr = BVOrthogonalize_Chol(V, R, ldr);CHKERRQ(ierr); break;
+    default: SETERRQ(PETSC_ERR_SUP, "The tall-skinny QR block orthogonalization is not available");
+  }
+  V->state++;
   return 0;
 }

@@ -751,3 +751,36 @@ int ksd_gesvd(int n, const double *A, int lda, double *s, double *U, int ldu, do
   free(G); free(V); free(ord);
   return 0;
 }
+
+/* ---- Cholesky factor and triangular inverse (potrf "U", trtri "U","N") ---------------------- */
+int ksd_potrf_upper(int n, double *A, int lda) {
+  for (int j = 0; j < n; j++) {
+    double d = A[j + (size_t)j * lda];
+    for (int k = 0; k < j; k++) d -= A[k + (size_t)j * lda] * A[k + (size_t)j * lda];
+    if (!(d > 0.0)) return j + 1;
+    d = sqrt(d);
+    A[j + (size_t)j * lda] = d;
+    for (int i = j + 1; i < n; i++) {
+      double s = A[j + (size_t)i * lda];
+      for (int k = 0; k < j; k++) s -= A[k + (size_t)j * lda] * A[k + (size_t)i * lda];
+      A[j + (size_t)i * lda] = s / d;
+    }
+  }
+  return 0;
+}
+
+int ksd_trtri_upper(int n, double *A, int lda) {
+  for (int j = 0; j < n; j++) {
+    if (A[j + (size_t)j * lda] == 0.0) return j + 1;
+    A[j + (size_t)j * lda] = 1.0 / A[j + (size_t)j * lda];
+    const double ajj = -A[j + (size_t)j * lda];
+    /* column j above the diagonal: x = T(0:j,0:j) * a(0:j,j), T the inverse computed so far */
+    for (int i = 0; i < j; i++) {
+      double s = 0.0;
+      for (int k = i; k < j; k++) s += A[i + (size_t)k * lda] * A[k + (size_t)j * lda];
+      A[i + (size_t)j * lda] = s;          /* row i only needs entries k >= i, which are still the originals below row i */
+    }
+    for (int i = 0; i < j; i++) A[i + (size_t)j * lda] *= ajj;
+  }
+  return 0;
+}

@@ -16,4 +16,10 @@ int ksd_trevc_right(int n, const double *T, int ldt, int k, double *xr, double *
  * U and VT are n x n orthogonal.  A is not modified. */
 int ksd_gesvd(int n, const double *A, int lda, double *s, double *U, int ldu, double *VT, int ldvt);
 
+/* upper Cholesky factor of the symmetric positive definite n x n matrix in A (upper triangle
+ * referenced), in place; returns k > 0 if the leading minor of order k is not positive */
+int ksd_potrf_upper(int n, double *A, int lda);
+/* inverse of an upper triangular matrix, in place; returns k > 0 for a zero on the diagonal */
+int ksd_trtri_upper(int n, double *A, int lda);
+
 #endif

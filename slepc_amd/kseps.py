@@ -31,6 +31,7 @@ EPS_ERROR_ABSOLUTE, EPS_ERROR_RELATIVE = 0, 1
 EPS_CONVERGED_TOL, EPS_DIVERGED_ITS, EPS_DIVERGED_BREAKDOWN = 1, -1, -2
 BV_ORTHOG_CGS, BV_ORTHOG_MGS = 0, 1
 BV_ORTHOG_REFINE_IFNEEDED, BV_ORTHOG_REFINE_NEVER, BV_ORTHOG_REFINE_ALWAYS = 0, 1, 2
+BV_ORTHOG_BLOCK_GS, BV_ORTHOG_BLOCK_CHOL, BV_ORTHOG_BLOCK_TSQR = 0, 1, 2
 DS_STATE_RAW, DS_STATE_INTERMEDIATE, DS_STATE_CONDENSED, DS_STATE_TRUNCATED = 0, 1, 2, 3
 DS_MAT_A, DS_MAT_Q, DS_MAT_X, DS_MAT_T = 0, 1, 2, 3
 
@@ -120,7 +121,8 @@ BVStruct._fields_ = [("ops", BVOps), ("type_name", C.c_char * 32), ("t", VecP), 
                      ("orthog_type", C.c_int), ("orthog_ref", C.c_int), ("orthog_eta", C.c_double),
                      ("buffer", c_dp), ("h", c_dp), ("c", c_dp), ("cv", VecP * 2),
                      ("ci", C.c_int * 2), ("st", c_i64 * 2), ("state", c_i64),
-                     ("rand_seed", C.c_uint64), ("data", C.c_void_p), ("ctx", C.c_void_p)]
+                     ("rand_seed", C.c_uint64), ("data", C.c_void_p), ("ctx", C.c_void_p),
+                     ("orthog_block", C.c_int)]
 
 BVCREATE_FN = C.CFUNCTYPE(Err, BVP)
 COMPARE_FN = C.CFUNCTYPE(Err, C.c_double, C.c_double, C.c_double, C.c_double, C.POINTER(C.c_int),
@@ -171,7 +173,8 @@ SIGNATURES = {
     "BVResize": (Err, [BVP, C.c_int, C.c_int]),
     "BVSetActiveColumns": (Err, [BVP, C.c_int, C.c_int]),
     "BVGetActiveColumns": (Err, [BVP, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
-    "BVSetOrthogonalization": (Err, [BVP, C.c_int, C.c_int, C.c_double]),
+    "BVSetOrthogonalization": (Err, [BVP, C.c_int, C.c_int, C.c_double, C.c_int]),
+    "BVOrthogonalize": (Err, [BVP, c_dp, C.c_int]),
     "BVGetColumn": (Err, [BVP, C.c_int, C.POINTER(VecP)]),
     "BVRestoreColumn": (Err, [BVP, C.c_int, C.POINTER(VecP)]),
     "BVGetBuffer": (Err, [BVP, C.POINTER(c_dp), C.POINTER(C.c_int)]),

@@ -154,7 +154,7 @@ def run_bv_test2(be, otype=K.BV_ORTHOG_CGS):
     lib = be.lib
     n, k = 20, 8
     X = be.bv(n, k)
-    K.check(lib.BVSetOrthogonalization(X, otype, K.BV_ORTHOG_REFINE_IFNEEDED, 0.0))
+    K.check(lib.BVSetOrthogonalization(X, otype, K.BV_ORTHOG_REFINE_IFNEEDED, 0.0, K.BV_ORTHOG_BLOCK_GS))
     for j in range(k):
         col = np.zeros(n)
         for i in range(n // 2 + 1):
@@ -250,7 +250,7 @@ def solve_eps(be, csr, hermitian=True, nev=1, ncv=0, mpd=0, tol=0.0, max_it=0, w
     if delayed:
         eps.set_arnoldi_delayed(True)
     if orthog_refine is not None:
-        K.check(eps.lib.BVSetOrthogonalization(eps.bv(), K.BV_ORTHOG_CGS, orthog_refine, 0.0))
+        K.check(eps.lib.BVSetOrthogonalization(eps.bv(), K.BV_ORTHOG_CGS, orthog_refine, 0.0, K.BV_ORTHOG_BLOCK_GS))
     eps.set_dimensions(nev, ncv, mpd)
     eps.set_tolerances(tol, max_it)
     if which:
@@ -283,6 +283,49 @@ def solve_eps(be, csr, hermitian=True, nev=1, ncv=0, mpd=0, tol=0.0, max_it=0, w
     eps.destroy()
     A.destroy()
     return res
+
+
+def run_bv_test11(be, block, n=20, l=2, k=8):
+    """src/sys/classes/bv/examples/tests/test11.c with the standard inner product (golden
+    output test11_1.out: "Level of orthogonality < 100*eps" for -bv_orthog_block gs and chol),
+    plus the factor R against the oracle when no leading columns are kept."""
+    from oracle import bv as obv
+    lib = be.lib
+    X0 = np.zeros((n, k))
+    if n == 20:
+        for j in range(k):
+            for i in range(n // 2 + 1):
+                if i + j < n:
+                    X0[i + j, j] = (3.0 * i + j - 2) / (2 * (i + j + 1))
+        tol = 100 * np.finfo(float).eps
+    else:                                   # a well-conditioned tall block for the kernels at full width
+        X0 = np.random.default_rng(n).standard_normal((n, k))
+        tol = 1e-12
+    for (ll, want_R) in ((l, False), (0, True)):
+        Y = be.bv(n, k)
+        K.check(lib.BVSetOrthogonalization(Y, K.BV_ORTHOG_CGS, K.BV_ORTHOG_REFINE_IFNEEDED, 0.0, block))
+        for j in range(k):
+            be.set_col(Y, j, X0[:, j])
+        O = obv.BV(n, k)
+        O.array[:, :] = X0
+        if block == K.BV_ORTHOG_BLOCK_GS:          # GS requires the leading columns to be orthogonal
+            for j in range(ll):
+                K.check(lib.BVOrthonormalizeColumn(Y, j, 0, None, None))
+                O.orthonormalize_column(j, False)
+        K.check(lib.BVSetActiveColumns(Y, ll, k))
+        O.set_active_columns(ll, k)
+        R = np.zeros((k, k), order="F")
+        K.check(lib.BVOrthogonalize(Y, dp(R) if want_R else None, k))
+        Ro = obv.orthogonalize_block(O, "gs" if block == K.BV_ORTHOG_BLOCK_GS else "chol", want_R=True)
+        Q = be.to_numpy(Y)
+        M = np.eye(k)
+        M[ll:, ll:] = Q[:, ll:].T @ Q[:, ll:]
+        assert np.abs(M - np.eye(k)).sum(axis=0).max() < tol      # MatNorm(M,NORM_1)
+        assert np.abs(Q - O.array).max() < 1e-11
+        if want_R:
+            assert np.abs(np.tril(R, -1)).max() == 0.0
+            assert np.abs(Q @ R - X0).max() < 1e-12 and np.abs(R - Ro).max() < 1e-10
+        be.destroy_bv(Y)
 
 
 def solve_svd(be, csr, ncols, nsv=1, ncv=0, mpd=0, tol=0.0, max_it=0, which="largest", solver=None, oneside=False,

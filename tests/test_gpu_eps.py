@@ -37,6 +37,12 @@ def test_bv_test4(be, trans):
     common.run_bv_test4(be, trans)
 
 
+@pytest.mark.parametrize("block", [K.BV_ORTHOG_BLOCK_GS, K.BV_ORTHOG_BLOCK_CHOL])
+def test_bv_test11(be, block):
+    common.run_bv_test11(be, block)
+    common.run_bv_test11(be, block, n=30011, l=3, k=40)       # the Gram and block-update kernels at width 40
+
+
 def test_bv_test13(be):
     common.run_bv_test13(be)
 

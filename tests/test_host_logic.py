@@ -330,6 +330,16 @@ def test_eps_matches_oracle_driver(be, case):
         assert np.abs(s * gr - xr).max() < 1e-6
 
 
+@pytest.mark.parametrize("block", [K.BV_ORTHOG_BLOCK_GS, K.BV_ORTHOG_BLOCK_CHOL])
+def test_bv_test11_block_orthogonalization(be, block):
+    common.run_bv_test11(be, block)
+    Y = be.bv(10, 3)
+    K.check(be.lib.BVSetOrthogonalization(Y, K.BV_ORTHOG_CGS, K.BV_ORTHOG_REFINE_IFNEEDED, 0.0, K.BV_ORTHOG_BLOCK_TSQR))
+    with pytest.raises(K.KsError):
+        K.check(be.lib.BVOrthogonalize(Y, None, 3))
+    be.destroy_bv(Y)
+
+
 def test_eps_errors_and_defaults(be):
     A = be.mat_csr(*og.laplacian1d(50))
     eps = K.EPS(None)
