@@ -220,6 +220,113 @@ __global__ __launch_bounds__(KSG_BLOCK) void k_resnorm(const double *__restrict_
   }
 }
 
+/* Y(:,0:k) = A X(:,0:k) in one pass over the matrix (BVMatMult, bvops.c:578-600, as a sparse
+ * matrix times a block of vectors).  The entries of a tile are parked in LDS once and reused
+ * for every column, in chunks of KC columns per pass over the tile.  Every column gets exactly
+ * the arithmetic of k_spmv_tiles (the same products, added in the same order), so the result
+ * equals k separate products bit for bit. */
+template <int KC>
+__global__ __launch_bounds__(KSG_BLOCK) void k_spmm_tiles(const int32_t *__restrict__ tiles,
+                                                           const int64_t *__restrict__ tile_p,
+                                                           const int64_t *__restrict__ rowptr,
+                                                           const int32_t *__restrict__ colidx,
+                                                           const double *__restrict__ val,
+                                                           const double *__restrict__ X, int64_t ldx,
+                                                           double *__restrict__ Y, int64_t ldy, int k) {
+  /* products and sums are rounded separately, as they are where k_spmv_tiles parks the
+   * products in LDS: no contraction into fused multiply-adds here */
+#pragma clang fp contract(off)
+  __shared__ double sv[KSG_TILE_NNZ];
+  __shared__ int32_t sc[KSG_TILE_NNZ];
+  __shared__ double red[KSG_BLOCK / 64];
+  const int r0 = tiles[blockIdx.x], r1 = tiles[blockIdx.x + 1];
+  const int64_t p0 = tile_p[blockIdx.x], p1 = tile_p[blockIdx.x + 1];
+  const int nrows = r1 - r0;
+  const int64_t nnz = p1 - p0;
+
+  if (nnz > KSG_TILE_NNZ) {
+    /* long row: the workgroup strides over it once per column */
+    for (int j = 0; j < k; j++) {
+      const double *x = X + (int64_t)j * ldx;
+      double a = 0.0;
+      for (int64_t p = p0 + threadIdx.x; p < p1; p += KSG_BLOCK)
+        a = fma(__builtin_nontemporal_load(val + p), x[__builtin_nontemporal_load(colidx + p)], a);
+      a = wave_sum_width(a, 64);
+      __syncthreads();
+      if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = a;
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        double t = red[0];
+#pragma unroll
+        for (int w = 1; w < KSG_BLOCK / 64; w++) t += red[w];
+        Y[r0 + (int64_t)j * ldy] = t;
+      }
+    }
+    return;
+  }
+
+  for (int t = threadIdx.x; t < (int)nnz; t += KSG_BLOCK) {
+    sv[t] = __builtin_nontemporal_load(val + p0 + t);
+    sc[t] = __builtin_nontemporal_load(colidx + p0 + t);
+  }
+  __syncthreads();
+
+  if (nrows > KSG_BLOCK / 2) {
+    /* one lane per row, KC columns at a time */
+    constexpr int RPT = KSG_TILE_ROWS / KSG_BLOCK;
+    int b[RPT], e[RPT];
+#pragma unroll
+    for (int i = 0; i < RPT; i++) {
+      const int lr = threadIdx.x + i * KSG_BLOCK;
+      b[i] = e[i] = 0;
+      if (lr < nrows) { b[i] = (int)(rowptr[r0 + lr] - p0); e[i] = (int)(rowptr[r0 + lr + 1] - p0); }
+    }
+    for (int j0 = 0; j0 < k; j0 += KC) {
+      const int kc = min(KC, k - j0);
+      const double *x = X + (int64_t)j0 * ldx;
+#pragma unroll
+      for (int i = 0; i < RPT; i++) {
+        const int lr = threadIdx.x + i * KSG_BLOCK;
+        if (lr >= nrows) continue;
+        double acc[KC];
+#pragma unroll
+        for (int q = 0; q < KC; q++) acc[q] = 0.0;
+        if (kc == KC) {
+          for (int t = b[i]; t < e[i]; t++) {
+            const double a = sv[t];
+            const double *xc = x + sc[t];
+#pragma unroll
+            for (int q = 0; q < KC; q++) acc[q] = acc[q] + a * xc[(int64_t)q * ldx];
+          }
+        } else {
+          for (int t = b[i]; t < e[i]; t++) {
+            const double a = sv[t];
+            const double *xc = x + sc[t];
+#pragma unroll
+            for (int q = 0; q < KC; q++) if (q < kc) acc[q] = acc[q] + a * xc[(int64_t)q * ldx];
+          }
+        }
+#pragma unroll
+        for (int q = 0; q < KC; q++) if (q < kc) __builtin_nontemporal_store(acc[q], &Y[r0 + lr + (int64_t)(j0 + q) * ldy]);
+      }
+    }
+  } else {
+    /* G lanes per row, one column at a time */
+    int G = 2;
+    while (G < 64 && nrows * (G << 1) <= KSG_BLOCK) G <<= 1;
+    const int lr = threadIdx.x / G, g = threadIdx.x % G;
+    int b = 0, e = 0;
+    if (lr < nrows) { b = (int)(rowptr[r0 + lr] - p0); e = (int)(rowptr[r0 + lr + 1] - p0); }
+    for (int j = 0; j < k; j++) {
+      const double *x = X + (int64_t)j * ldx;
+      double s = 0.0;
+      for (int t = b + g; t < e; t += G) s = s + sv[t] * x[sc[t]];
+      s = wave_sum_width(s, G);
+      if (lr < nrows && g == 0) Y[r0 + lr + (int64_t)j * ldy] = s;
+    }
+  }
+}
+
 /* ghost block: y[rows[i]] += sum of its ghost entries (few rows, thread per row) */
 __global__ __launch_bounds__(KSG_BLOCK) void k_spmv_ghost_add(int64_t nrows, const int32_t *__restrict__ rows,
                                                                const int64_t *__restrict__ rowptr,
@@ -735,7 +842,17 @@ extern "C" int ksg_bv_matmult(ksg_bv V, ksg_mat A, ksg_bv W) {
   ksg_ctx c = V->ctx;
   const int nc = V->k - V->l;
   KSG_CHK(ksg_op_begin(c, KSG_EV_MATMULT));
-  for (int j = 0; j < nc; j++)
-    KSG_CHK(mat_mult_raw(A, V->d + (int64_t)(V->nc + V->l + j) * V->ld, W->d + (int64_t)(W->nc + W->l + j) * W->ld));
+  const double *X = V->d + (int64_t)(V->nc + V->l) * V->ld;
+  double *Y = W->d + (int64_t)(W->nc + W->l) * W->ld;
+  if (c->nranks == 1 && nc > 1 && A->diag.ntiles) {
+    /* one pass over the matrix for all the columns */
+    hipLaunchKernelGGL(k_spmm_tiles<8>, dim3((unsigned)A->diag.ntiles), dim3(KSG_BLOCK), 0, c->stream, A->diag.tiles,
+                       A->diag.tile_p, A->diag.rowptr, A->diag.colidx, A->diag.val, X, V->ld, Y, W->ld, nc);
+    KSG_HIP(hipGetLastError());
+    const double bytes = 12.0 * (double)A->nnz + 8.0 * (double)(A->n + 1) + 8.0 * nc * (double)(A->nc + A->n);
+    return ksg_op_end(c, KSG_EV_MATMULT, bytes, 2.0 * nc * (double)A->nnz);
+  }
+  /* several ranks: column by column, each product with its halo exchange */
+  for (int j = 0; j < nc; j++) KSG_CHK(mat_mult_raw(A, X + (int64_t)j * V->ld, Y + (int64_t)j * W->ld));
   return ksg_op_end(c, KSG_EV_MATMULT, nc * spmv_bytes(A), 2.0 * nc * (double)A->nnz);
 }

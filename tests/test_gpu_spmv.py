@@ -140,3 +140,33 @@ def test_fused_residual_norm(gpu_ctx, gen):
     ctx.vec_free(dx)
     ctx.vec_free(dxi)
     A.destroy()
+
+
+@pytest.mark.parametrize("gen", ["lap2d", "lap3d", "markov", "rmat"])
+def test_block_product_equals_column_products(gpu_ctx, gen):
+    """BVMatMult as one pass over the matrix for all the columns: bit for bit the result of
+    one MatMult per column (stream, grouped and long-row tiles), active ranges honoured."""
+    from slepc_amd import ksgpu, matgen as mg
+    rp, ci, va = {"lap2d": lambda: mg.laplacian2d(301, 217), "lap3d": lambda: mg.laplacian3d(41, 37, 29),
+                  "markov": lambda: mg.markov(200), "rmat": lambda: mg.rmat_laplacian(16)}[gen]()
+    n = len(rp) - 1
+    A = ksgpu.DeviceCSR(gpu_ctx, rp, ci, va)
+    rng = np.random.default_rng(4)
+    m = 21
+    V, W = ksgpu.DeviceBV(gpu_ctx, n, m), ksgpu.DeviceBV(gpu_ctx, n, m)
+    Vh = rng.standard_normal((n, m))
+    V.from_numpy(Vh)
+    yd = gpu_ctx.vec_alloc(n)
+    for (l, k) in ((0, m), (2, 10), (5, 6), (3, 20)):
+        W.from_numpy(np.full((n, m), np.nan))
+        V.set_active(l, k)
+        W.set_active(l, k)
+        V.matmult(A, W)
+        Wh = W.to_numpy()
+        assert np.isnan(Wh[:, :l]).all() and np.isnan(Wh[:, k:]).all()
+        for j in range(l, k):
+            A.mult(V.column(j), yd)
+            assert np.array_equal(gpu_ctx.download(yd, n), Wh[:, j]), (gen, l, k, j)
+    gpu_ctx.vec_free(yd)
+    for o in (A, V, W):
+        o.destroy()

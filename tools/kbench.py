@@ -61,6 +61,11 @@ def main():
         run("dot %dx%d" % (kk, kk), "dot", lambda: V.dot(W, M))
         Qm = np.asfortranarray(np.eye(m, 64) * 0.5 + 1e-3)
         run("mult %dx%d" % (kk, kk), "mult", lambda: W.mult(1.0, 0.0, V, Qm))
+    # block product W = A V: one pass over the matrix for all the columns
+    for kk in (1, 8, 32):
+        V.set_active(0, kk)
+        W.set_active(0, kk)
+        run("matmult %d cols" % kk, "matmult", lambda: V.matmult(A, W))
     W.destroy()
     V.set_active(0, 64)
     run("scale", "scale", lambda: V.scale(3, 1.0000001))
