@@ -326,41 +326,32 @@ static PetscErrorCode SVDConverged(SVD svd, PetscReal sigma, PetscReal res, Pets
   return 0;
 }
 
-/* gklanczos.c:67-107 */
+/* y_jy = A x_jx (or A^T x_jx) between columns of two bases */
+static PetscErrorCode SVDMatMultColumns(SVD svd, PetscBool trans, BV X, PetscInt jx, BV Y, PetscInt jy) {
+  PetscErrorCode ierr;
+  Vec x, y;
+  ierr = BVGetColumn(X, jx, &x);CHKERRQ(ierr);
+  ierr = BVGetColumn(Y, jy, &y);CHKERRQ(ierr);
+  ierr = SVDMatMult(svd, trans, x, y);
+  if (!ierr) ierr = BVRestoreColumn(X, jx, &x);
+  if (!ierr) ierr = BVRestoreColumn(Y, jy, &y);
+  CHKERRQ(ierr);
+  return 0;
+}
+
+/* Golub-Kahan-Lanczos bidiagonalisation with both bases orthogonalised, columns k..n
+ * (gklanczos.c:67-107): alpha_i = ||u_i||, beta_i = ||v_{i+1}|| before normalisation; v_n is
+ * left unnormalised for the caller */
 static PetscErrorCode SVDTwoSideLanczos(SVD svd, PetscReal *alpha, PetscReal *beta, BV V, BV U, PetscInt k, PetscInt n) {
   PetscErrorCode ierr;
-  PetscInt i;
-  Vec u, v;
-  ierr = BVGetColumn(V, k, &v);CHKERRQ(ierr);
-  ierr = BVGetColumn(U, k, &u);CHKERRQ(ierr);
-  ierr = SVDMatMult(svd, PETSC_FALSE, v, u);CHKERRQ(ierr);
-  ierr = BVRestoreColumn(V, k, &v);CHKERRQ(ierr);
-  ierr = BVRestoreColumn(U, k, &u);CHKERRQ(ierr);
-  ierr = BVOrthogonalizeColumn(U, k, NULL, alpha + k, NULL);CHKERRQ(ierr);
-  ierr = BVScaleColumn(U, k, 1.0 / alpha[k]);CHKERRQ(ierr);
-  for (i = k + 1; i < n; i++) {
-    ierr = BVGetColumn(V, i, &v);CHKERRQ(ierr);
-    ierr = BVGetColumn(U, i - 1, &u);CHKERRQ(ierr);
-    ierr = SVDMatMult(svd, PETSC_TRUE, u, v);CHKERRQ(ierr);
-    ierr = BVRestoreColumn(V, i, &v);CHKERRQ(ierr);
-    ierr = BVRestoreColumn(U, i - 1, &u);CHKERRQ(ierr);
-    ierr = BVOrthogonalizeColumn(V, i, NULL, beta + i - 1, NULL);CHKERRQ(ierr);
-    ierr = BVScaleColumn(V, i, 1.0 / beta[i - 1]);CHKERRQ(ierr);
-
-    ierr = BVGetColumn(V, i, &v);CHKERRQ(ierr);
-    ierr = BVGetColumn(U, i, &u);CHKERRQ(ierr);
-    ierr = SVDMatMult(svd, PETSC_FALSE, v, u);CHKERRQ(ierr);
-    ierr = BVRestoreColumn(V, i, &v);CHKERRQ(ierr);
-    ierr = BVRestoreColumn(U, i, &u);CHKERRQ(ierr);
-    ierr = BVOrthogonalizeColumn(U, i, NULL, alpha + i, NULL);CHKERRQ(ierr);
+  for (PetscInt i = k; i < n; i++) {
+    ierr = SVDMatMultColumns(svd, PETSC_FALSE, V, i, U, i);CHKERRQ(ierr);              /* u_i = A v_i */
+    ierr = BVOrthogonalizeColumn(U, i, NULL, &alpha[i], NULL);CHKERRQ(ierr);
     ierr = BVScaleColumn(U, i, 1.0 / alpha[i]);CHKERRQ(ierr);
+    ierr = SVDMatMultColumns(svd, PETSC_TRUE, U, i, V, i + 1);CHKERRQ(ierr);           /* v_{i+1} = A^T u_i */
+    ierr = BVOrthogonalizeColumn(V, i + 1, NULL, &beta[i], NULL);CHKERRQ(ierr);
+    if (i + 1 < n) { ierr = BVScaleColumn(V, i + 1, 1.0 / beta[i]);CHKERRQ(ierr); }
   }
-  ierr = BVGetColumn(V, n, &v);CHKERRQ(ierr);
-  ierr = BVGetColumn(U, n - 1, &u);CHKERRQ(ierr);
-  ierr = SVDMatMult(svd, PETSC_TRUE, u, v);CHKERRQ(ierr);
-  ierr = BVRestoreColumn(V, n, &v);CHKERRQ(ierr);
-  ierr = BVRestoreColumn(U, n - 1, &u);CHKERRQ(ierr);
-  ierr = BVOrthogonalizeColumn(V, n, NULL, beta + n - 1, NULL);CHKERRQ(ierr);
   return 0;
 }
 
@@ -410,21 +401,13 @@ static PetscErrorCode SVDOneSideTRLanczosCGS(SVD svd, PetscReal *alpha, PetscRea
   Vec ui, ui1, vi;
   const BVOrthogRefineType refine = V->orthog_ref;
   const PetscReal eta = V->orthog_eta;
-  ierr = BVGetColumn(V, k, &vi);CHKERRQ(ierr);
-  ierr = BVGetColumn(U, k, &ui);CHKERRQ(ierr);
-  ierr = SVDMatMult(svd, PETSC_FALSE, vi, ui);CHKERRQ(ierr);
-  ierr = BVRestoreColumn(V, k, &vi);CHKERRQ(ierr);
-  ierr = BVRestoreColumn(U, k, &ui);CHKERRQ(ierr);
+  ierr = SVDMatMultColumns(svd, PETSC_FALSE, V, k, U, k);CHKERRQ(ierr);
   if (l > 0) {
     for (i = 0; i < l; i++) work[i] = beta[i + nconv];
     ierr = BVMultColumn(U, -1.0, 1.0, k, work);CHKERRQ(ierr);
   }
   for (i = k + 1; i <= n; i++) {
-    ierr = BVGetColumn(V, i, &vi);CHKERRQ(ierr);
-    ierr = BVGetColumn(U, i - 1, &ui1);CHKERRQ(ierr);
-    ierr = SVDMatMult(svd, PETSC_TRUE, ui1, vi);CHKERRQ(ierr);
-    ierr = BVRestoreColumn(V, i, &vi);CHKERRQ(ierr);
-    ierr = BVRestoreColumn(U, i - 1, &ui1);CHKERRQ(ierr);
+    ierr = SVDMatMultColumns(svd, PETSC_TRUE, U, i - 1, V, i);CHKERRQ(ierr);
     ierr = BVNormColumn(U, i - 1, NORM_2, &a);CHKERRQ(ierr);
     if (refine == BV_ORTHOG_REFINE_IFNEEDED) {
       ierr = BVSetActiveColumns(V, 0, i + 1);CHKERRQ(ierr);
@@ -443,11 +426,7 @@ static PetscErrorCode SVDOneSideTRLanczosCGS(SVD svd, PetscReal *alpha, PetscRea
     if (i < n) {
       ierr = BVScaleColumn(V, i, 1.0 / b);CHKERRQ(ierr);
       if (fabs(b) < 10 * PETSC_MACHINE_EPSILON) SETERRQ(1, "Recurrence generated a zero vector; use a two-sided variant");
-      ierr = BVGetColumn(V, i, &vi);CHKERRQ(ierr);
-      ierr = BVGetColumn(U, i, &ui);CHKERRQ(ierr);
-      ierr = SVDMatMult(svd, PETSC_FALSE, vi, ui);CHKERRQ(ierr);
-      ierr = BVRestoreColumn(V, i, &vi);CHKERRQ(ierr);
-      ierr = BVRestoreColumn(U, i, &ui);CHKERRQ(ierr);
+      ierr = SVDMatMultColumns(svd, PETSC_FALSE, V, i, U, i);CHKERRQ(ierr);
       ierr = BVGetColumn(U, i, &ui);CHKERRQ(ierr);
       ierr = BVGetColumn(U, i - 1, &ui1);CHKERRQ(ierr);
       ierr = VecAXPY(ui, -b, ui1);CHKERRQ(ierr);
