@@ -50,7 +50,7 @@ static void eps_set_from_options(EPS eps, int argc, char **argv) {
 static void svd_set_from_options(SVD svd, int argc, char **argv) {
   PetscInt nsv, ncv, mpd;
   int it = opt_find(argc, argv, "-svd_type");
-  if (it && it + 1 < argc) CHK(SVDSetType(svd, argv[it + 1]));       /* cross | trlanczos */
+  if (it && it + 1 < argc) CHK(SVDSetType(svd, argv[it + 1]));       /* cross | trlanczos | lanczos | cyclic */
   CHK(SVDGetDimensions(svd, &nsv, &ncv, &mpd));
   nsv = (PetscInt)opt_int(argc, argv, "-svd_nsv", nsv);
   CHK(SVDSetDimensions(svd, nsv, (PetscInt)opt_int(argc, argv, "-svd_ncv", 0), (PetscInt)opt_int(argc, argv, "-svd_mpd", 0)));
@@ -58,6 +58,7 @@ static void svd_set_from_options(SVD svd, int argc, char **argv) {
   if (opt_find(argc, argv, "-svd_largest")) CHK(SVDSetWhichSingularTriplets(svd, SVD_LARGEST));
   if (opt_find(argc, argv, "-svd_smallest")) CHK(SVDSetWhichSingularTriplets(svd, SVD_SMALLEST));
   if (opt_find(argc, argv, "-svd_trlanczos_oneside")) CHK(SVDTRLanczosSetOneSide(svd, PETSC_TRUE));
+  if (opt_find(argc, argv, "-svd_lanczos_oneside")) CHK(SVDLanczosSetOneSide(svd, PETSC_TRUE));
 }
 
 /* the report of EPSErrorView(eps,EPS_ERROR_RELATIVE,NULL), after the solver lines the

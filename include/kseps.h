@@ -302,12 +302,13 @@ PetscErrorCode SlepcCompareLargestReal(PetscScalar, PetscScalar, PetscScalar, Pe
 PetscErrorCode SlepcCompareSmallestReal(PetscScalar, PetscScalar, PetscScalar, PetscScalar, PetscInt *, void *);
 PetscErrorCode SlepcCompareLargestImaginary(PetscScalar, PetscScalar, PetscScalar, PetscScalar, PetscInt *, void *);
 PetscErrorCode SlepcCompareSmallestImaginary(PetscScalar, PetscScalar, PetscScalar, PetscScalar, PetscInt *, void *);
+PetscErrorCode SlepcCompareSmallestPosReal(PetscScalar, PetscScalar, PetscScalar, PetscScalar, PetscInt *, void *);
 PetscErrorCode SlepcSortEigenvalues(SlepcCompareFn cmp, void *ctx, PetscInt n, PetscScalar *eigr, PetscScalar *eigi, PetscInt *perm);
 
 /* ------------------------------------------------------------------ EPS */
 typedef enum { EPS_HEP = 1, EPS_NHEP = 3 } EPSProblemType;
 typedef enum { EPS_LARGEST_MAGNITUDE = 1, EPS_SMALLEST_MAGNITUDE, EPS_LARGEST_REAL, EPS_SMALLEST_REAL,
-               EPS_LARGEST_IMAGINARY, EPS_SMALLEST_IMAGINARY } EPSWhich;
+               EPS_LARGEST_IMAGINARY, EPS_SMALLEST_IMAGINARY, EPS_WHICH_USER = 11 } EPSWhich;
 typedef enum { EPS_ERROR_ABSOLUTE = 0, EPS_ERROR_RELATIVE = 1 } EPSErrorType;
 typedef enum { EPS_CONVERGED_TOL = 1, EPS_CONVERGED_USER = 2, EPS_DIVERGED_ITS = -1, EPS_DIVERGED_BREAKDOWN = -2,
                EPS_DIVERGED_SYMMETRY_LOST = -3, EPS_CONVERGED_ITERATING = 0 } EPSConvergedReason;
@@ -327,6 +328,8 @@ PetscErrorCode EPSSetProblemType(EPS eps, EPSProblemType type);                 
 PetscErrorCode EPSSetDimensions(EPS eps, PetscInt nev, PetscInt ncv, PetscInt mpd);
 PetscErrorCode EPSSetTolerances(EPS eps, PetscReal tol, PetscInt maxits);
 PetscErrorCode EPSSetWhichEigenpairs(EPS eps, EPSWhich which);
+/* user ordering of the eigenvalues (epsopts.c, EPSSetEigenvalueComparison); sets EPS_WHICH_USER */
+PetscErrorCode EPSSetEigenvalueComparison(EPS eps, SlepcCompareFn cmp, void *ctx);
 PetscErrorCode EPSSetConvergenceTest(EPS eps, EPSConv conv);                     /* epsopts.c; default relative */
 PetscErrorCode EPSSetInitialSpace(EPS eps, PetscInt n, Vec *is);                 /* epssetup.c:449-460 */
 PetscErrorCode EPSKrylovSchurSetRestart(EPS eps, PetscReal keep);                /* krylovschur.c:290 */
@@ -357,8 +360,10 @@ PetscErrorCode EPSDestroy(EPS *eps);
 /* ------------------------------------------------------------------ SVD */
 /* Singular value solvers on the same kernels (include/slepcsvd.h of the reference):
  * "cross" (default, svdsetup.c:112-114; the eigenproblem of A^T A, src/svd/impls/cross/cross.c)
- * and "trlanczos" (thick-restart Lanczos bidiagonalisation,
- * src/svd/impls/trlanczos/trlanczos.c).  The operator may be rectangular; its transpose is
+ * "trlanczos" (thick-restart Lanczos bidiagonalisation, src/svd/impls/trlanczos/trlanczos.c),
+ * "lanczos" (explicitly restarted Golub-Kahan-Lanczos, src/svd/impls/lanczos/gklanczos.c) and
+ * "cyclic" (the eigenproblem of [0 A; A^T 0] through a shell operator on device vectors,
+ * src/svd/impls/cyclic/cyclic.c).  The operator may be rectangular; its transpose is
  * built explicitly with MatTranspose. */
 typedef enum { SVD_LARGEST = 0, SVD_SMALLEST = 1 } SVDWhich;
 typedef enum { SVD_ERROR_ABSOLUTE = 0, SVD_ERROR_RELATIVE = 1 } SVDErrorType;
@@ -378,7 +383,9 @@ PetscErrorCode SVDSetWhichSingularTriplets(SVD svd, SVDWhich which);
 PetscErrorCode SVDSetConvergenceTest(SVD svd, SVDConv conv);
 PetscErrorCode SVDSetInitialSpace(SVD svd, PetscInt n, Vec *is);                 /* svdsetup.c:222-232 */
 PetscErrorCode SVDTRLanczosSetOneSide(SVD svd, PetscBool oneside);               /* trlanczos.c:400-426 */
+PetscErrorCode SVDLanczosSetOneSide(SVD svd, PetscBool oneside);                 /* gklanczos.c:292-330 */
 PetscErrorCode SVDCrossGetEPS(SVD svd, EPS *eps);
+PetscErrorCode SVDCyclicGetEPS(SVD svd, EPS *eps);
 PetscErrorCode SVDGetBV(SVD svd, BV *V, BV *U);
 PetscErrorCode SVDSetUp(SVD svd);                                                /* svdsetup.c:98-205 */
 PetscErrorCode SVDSolve(SVD svd);                                                /* svdsolve.c:80-128 */

@@ -130,7 +130,7 @@ class SVD:
 
     def __init__(self, mult, mult_t, M, N, nsv=1, ncv=0, mpd=0, tol=None, max_it=0, which="largest",
                  solver="cross", oneside=False, conv="rel", v0=None, orthog_refine=REFINE_IFNEEDED):
-        if solver not in ("cross", "trlanczos"):
+        if solver not in ("cross", "trlanczos", "lanczos", "cyclic"):
             raise ValueError("unknown solver " + solver)
         self.M, self.N = M, N
         self.swapped = M < N                      # svdsetup.c:139-158: the solver works with the tall one
@@ -169,6 +169,10 @@ class SVD:
             raise ValueError("nsv bigger than ncv")
         if self.solver == "trlanczos":
             self._setup_trlanczos()
+        elif self.solver == "lanczos":
+            self._setup_trlanczos()        # SVDSetUp_Lanczos (gklanczos.c:46-64) sets the same things up
+        elif self.solver == "cyclic":
+            self._setup_cyclic()
         else:
             self._setup_cross()
         return self
@@ -238,6 +242,44 @@ class SVD:
         self.errest = np.zeros(self.ncv)
         self.perm = np.arange(self.ncv)
 
+    def _setup_cyclic(self):
+        """``SVDSetUp_Cyclic`` (src/svd/impls/cyclic/cyclic.c:81-226), shell variant: EPS on
+        H(A) = [0 A; A^T 0] of order rows+cols; its positive eigenvalues are the singular
+        values, its eigenvectors hold [u; v]/sqrt(2)."""
+        m, n = self.rows, self.cols
+
+        def cyclic_mult(x, y):
+            self._matmult(False, x[m:], y[:m])
+            self._matmult(True, x[:m], y[m:])
+
+        def smallest_pos_real(ar, ai, br, bi):
+            """``SlepcCompareSmallestPosReal`` (slepcsc.c)."""
+            aisright, bisright = ar > 0.0, br > 0.0
+            if aisright == bisright:
+                if aisright:
+                    return -1 if ar < br else (1 if ar > br else 0)
+                return 1 if ar < br else (-1 if ar > br else 0)       # both non-positive: the larger first
+            return -1 if aisright else 1
+        v0 = None
+        if self.v0 is not None and not self.swapped:
+            v0 = np.concatenate([np.zeros(m), self.v0])
+        which = "largest_real"
+        if self.which != "largest":
+            dsmod.COMPARE["_smallest_pos_real"] = smallest_pos_real
+            which = "_smallest_pos_real"
+        self.eps = EPS(cyclic_mult, m + n, hermitian=True, nev=self.nsv, ncv=self.ncv, mpd=self.mpd,
+                       tol=1e-8 / 10.0 if self.tol is None else self.tol, max_it=self.max_it, which=which, v0=v0)
+        self.eps.conv = self.conv
+        self.eps.setup()
+        self.ncv, self.mpd, self.max_it = min(self.eps.ncv, min(self.M, self.N)), self.eps.mpd, self.eps.max_it
+        if self.tol is None:
+            self.tol = 1e-8
+        self.V = BV(n, self.eps.ncv)
+        self.U = BV(m, self.eps.ncv)
+        self.sigma = np.zeros(self.eps.ncv)
+        self.errest = np.zeros(self.eps.ncv)
+        self.perm = np.arange(self.eps.ncv)
+
     # -- solve ------------------------------------------------------------------------
     def solve(self):
         """``SVDSolve`` (svdsolve.c:80-128)."""
@@ -246,6 +288,12 @@ class SVD:
         self.nconv = 0
         if self.solver == "trlanczos":
             self._solve_trlanczos()
+            self._have_left = True
+        elif self.solver == "lanczos":
+            self._solve_lanczos()
+            self._have_left = not self.oneside
+        elif self.solver == "cyclic":
+            self._solve_cyclic()
             self._have_left = True
         else:
             self._solve_cross()
@@ -392,6 +440,103 @@ class SVD:
         if self.oneside:
             for i in range(self.nconv):
                 U.orthonormalize_column(i, False)
+
+    def _one_side_lanczos(self, alpha, beta, u, u1, k, n):
+        """``SVDOneSideLanczos`` (gklanczos.c:109-169): the left vectors are not kept, only the
+        current and the previous one."""
+        V = self.V
+        bvl, bvk = V.l, V.k
+        self._matmult(False, V.col(k), u)
+        for i in range(k + 1, n + 1):
+            self._matmult(True, u, V.col(i))
+            a = np.sqrt(float(V.comm.allreduce_sum(np.array([u @ u]))[0]))
+            V.set_active_columns(0, i)
+            work = np.array(V.dot_column(i), dtype=float)
+            u *= 1.0 / a
+            V.mult_column(-1.0 / a, 1.0 / a, i, work.copy())
+            work = np.array(V.dot_column(i), dtype=float)
+            V.mult_column(-1.0, 1.0, i, work.copy())
+            b = V.norm_column(i)
+            if i < n:
+                if abs(b) < 10 * EPSILON:
+                    raise ArithmeticError("Recurrence generated a zero vector; use a two-sided variant")
+                V.scale_column(i, 1.0 / b)
+                self._matmult(False, V.col(i), u1)
+                u1 -= b * u
+                u, u1 = u1, u
+            alpha[i - 1] = a
+            beta[i - 1] = b
+        V.set_active_columns(bvl, bvk)
+
+    def _solve_lanczos(self):
+        """``SVDSolve_Lanczos`` (gklanczos.c:171-275): explicit restart with the first
+        unconverged right singular vector."""
+        V, U, ds = self.V, self.U, self.ds
+        ld = ds.ld
+        w = np.zeros(ld)
+        u = np.zeros(self.rows)
+        u1 = np.zeros(self.rows)
+        if not self.nini:
+            V.col(0)[:] = splitmix64_uniform(np.arange(self.cols, dtype=np.uint64))
+            V.scale_column(0, 1.0 / V.norm_column(0))
+        while self.reason == ITERATING:
+            self.its += 1
+            nv = min(self.nconv + self.mpd, self.ncv)
+            V.set_active_columns(self.nconv, nv)
+            alpha, beta = ds.T[:ld], ds.T[ld:2 * ld]
+            if self.oneside:
+                self._one_side_lanczos(alpha, beta, u, u1, self.nconv, nv)
+            else:
+                U.set_active_columns(self.nconv, nv)
+                self._two_side_lanczos(alpha, beta, self.nconv, nv)
+            lastbeta = beta[nv - 1]
+            ds.set_dimensions(nv, nv, self.nconv, 0)
+            ds.set_state(dsmod.STATE_INTERMEDIATE)
+            ds.solve(w)
+            ds.sort(w)
+            k = 0
+            conv = True
+            for i in range(self.nconv, nv):
+                self.sigma[i] = w[i]
+                resnorm = abs(ds.U[nv - 1, i]) * lastbeta
+                self.errest[i] = self._converged(self.sigma[i], resnorm)
+                if conv:
+                    if self.errest[i] < self.tol:
+                        k += 1
+                    else:
+                        conv = False
+            if self.nconv + k >= self.nsv:
+                self.reason = CONVERGED_TOL
+            elif self.its >= self.max_it:
+                self.reason = DIVERGED_ITS
+            if self.reason == ITERATING:
+                # restart vector: the first unconverged right vector, V(:,nconv:nv) * VT(k+nconv, nconv:nv)^T
+                V.mult_column(1.0, 0.0, nv, ds.VT[k + self.nconv, self.nconv:nv].copy())
+            V.op_multinplace(ds.VT[:nv, :nv].copy(), self.nconv, self.nconv + k, True)
+            if not self.oneside:
+                U.op_multinplace(ds.U[:nv, :nv].copy(), self.nconv, self.nconv + k, False)
+            if self.reason == ITERATING:
+                V.copy_column(nv, self.nconv + k)
+            self.nconv += k
+
+    def _solve_cyclic(self):
+        """``SVDSolve_Cyclic`` (cyclic.c:228-267).  The eigenvector of H(A) of unit norm holds
+        u/sqrt(2) and v/sqrt(2): both halves are scaled by sqrt(2) (the reference revision at
+        hand divides instead, which leaves vectors of norm 1/2)."""
+        e = self.eps
+        e.solve()
+        self.its, self.reason = e.its, e.reason
+        m = self.rows
+        j = 0
+        for i in range(e.nconv):
+            lam, _ = e.get_eigenvalue(i)
+            if lam > 0.0:
+                xr, _ = e.get_eigenvector(i)
+                self.sigma[j] = lam
+                self.U.col(j)[:] = xr[:m] * np.sqrt(2.0)
+                self.V.col(j)[:] = xr[m:] * np.sqrt(2.0)
+                j += 1
+        self.nconv = j
 
     def _solve_cross(self):
         """``SVDSolve_Cross`` (cross.c:174-200)."""

@@ -598,6 +598,17 @@ CMP(SlepcCompareSmallestReal, ar, br, >, <)
 CMP(SlepcCompareLargestImaginary, fabs(ai), fabs(bi), <, >)
 CMP(SlepcCompareSmallestImaginary, fabs(ai), fabs(bi), >, <)
 
+/* slepcsc.c:310-329: positive real parts first, then by increasing magnitude */
+PetscErrorCode SlepcCompareSmallestPosReal(PetscScalar ar, PetscScalar ai, PetscScalar br, PetscScalar bi, PetscInt *result, void *ctx) {
+  const PetscBool aisright = ar > 0.0, bisright = br > 0.0;
+  (void)ctx;
+  if (aisright == bisright) {
+    const PetscReal a = SlepcAbsEigenvalue(ar, ai), b = SlepcAbsEigenvalue(br, bi);
+    *result = a > b ? 1 : (a < b ? -1 : 0);
+  } else *result = aisright ? -1 : 1;
+  return 0;
+}
+
 PetscErrorCode SlepcSortEigenvalues(SlepcCompareFn cmp, void *ctx, PetscInt n, PetscScalar *eigr, PetscScalar *eigi, PetscInt *perm) {
   PetscErrorCode ierr;
   PetscScalar re, im;

@@ -92,6 +92,15 @@ PetscErrorCode EPSSetWhichEigenpairs(EPS eps, EPSWhich which) {
   return 0;
 }
 
+PetscErrorCode EPSSetEigenvalueComparison(EPS eps, SlepcCompareFn cmp, void *ctx) {
+  if (!eps || !cmp) SETERRQ(PETSC_ERR_ARG_NULL, "Null argument");
+  if (ctx) SETERRQ(PETSC_ERR_SUP, "A context for the comparison routine is not available");
+  eps->usercmp = cmp;
+  eps->which = EPS_WHICH_USER;
+  eps->state = 0;
+  return 0;
+}
+
 PetscErrorCode EPSSetInitialSpace(EPS eps, PetscInt n, Vec *is) {
   PetscErrorCode ierr;
   PetscInt i;
@@ -176,7 +185,7 @@ PetscErrorCode EPSSetUp(EPS eps) {
   if (eps->ishermitian && (eps->which == EPS_LARGEST_IMAGINARY || eps->which == EPS_SMALLEST_IMAGINARY)) SETERRQ(1, "Wrong value of eps->which");
   if (!eps->keep) eps->keep = 0.5;
   if (eps->tol == 0.0) eps->tol = 1e-8;                                                   /* SLEPC_DEFAULT_TOL */
-  eps->cmp = cmps[eps->which];
+  eps->cmp = eps->which == EPS_WHICH_USER ? eps->usercmp : cmps[eps->which];
 
   /* EPSAllocateSolution(eps,1) */
   ierr = BVGetSizes(eps->V, NULL, NULL, &oldm);CHKERRQ(ierr);

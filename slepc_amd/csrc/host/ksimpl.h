@@ -48,6 +48,7 @@ struct _p_EPS {
   PetscReal tol;
   EPSWhich which;
   SlepcCompareFn cmp;
+  SlepcCompareFn usercmp;   /* EPSSetEigenvalueComparison */
   PetscReal keep;
   PetscBool lock, keep_set;
   EPSConv conv;             /* convergence test: relative (default) or absolute */

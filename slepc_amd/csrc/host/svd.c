@@ -14,9 +14,10 @@ struct _p_SVD {
   Mat OP, A, AT;            /* operator as given; the tall one and its transpose (one of them is OP) */
   BV U, V;
   DS ds;
-  EPS eps;                  /* cross */
+  EPS eps;                  /* cross, cyclic */
   Mat cross_mat; Vec cross_w;
-  int type;                 /* 0 cross, 1 trlanczos */
+  Mat cyclic_mat; Vec cx1, cx2, cy1, cy2;   /* cyclic: [0 A; A^T 0] and views of the two halves of its vectors */
+  int type;                 /* 0 cross, 1 trlanczos, 2 lanczos, 3 cyclic */
   PetscBool oneside, leftbasis;
   PetscInt nsv, ncv, mpd, max_it;
   PetscReal tol;
@@ -32,7 +33,7 @@ struct _p_SVD {
 
 #define SVDCheckSolved(svd) do { if ((svd)->state < 2) SETERRQ(PETSC_ERR_ARG_WRONGSTATE, "Must call SVDSolve() first: Parameter #1"); } while (0)
 
-static const char *svd_type_names[] = { "cross", "trlanczos" };
+static const char *svd_type_names[] = { "cross", "trlanczos", "lanczos", "cyclic" };
 
 PetscErrorCode SVDCreate(void *ctx, SVD *outsvd) {
   PetscErrorCode ierr;
@@ -63,6 +64,8 @@ PetscErrorCode SVDSetType(SVD svd, const char *type) {
   int t;
   if (!strcmp(type, "cross")) t = 0;
   else if (!strcmp(type, "trlanczos")) t = 1;
+  else if (!strcmp(type, "lanczos")) t = 2;
+  else if (!strcmp(type, "cyclic")) t = 3;
   else SETERRQ(PETSC_ERR_ARG_UNKNOWN_TYPE, "Unknown SVD type given: %s", type);
   if (t != svd->type) { svd->type = t; svd->state = 0; }
   return 0;
@@ -119,6 +122,11 @@ PetscErrorCode SVDSetConvergenceTest(SVD svd, SVDConv conv) {
 PetscErrorCode SVDTRLanczosSetOneSide(SVD svd, PetscBool oneside) {
   if (!svd) SETERRQ(PETSC_ERR_ARG_NULL, "Null SVD");
   svd->oneside = oneside ? PETSC_TRUE : PETSC_FALSE;
+  return 0;
+}
+PetscErrorCode SVDLanczosSetOneSide(SVD svd, PetscBool oneside) {
+  if (!svd) SETERRQ(PETSC_ERR_ARG_NULL, "Null SVD");
+  if (svd->oneside != (oneside ? PETSC_TRUE : PETSC_FALSE)) { svd->oneside = oneside ? PETSC_TRUE : PETSC_FALSE; svd->state = 0; }
   return 0;
 }
 PetscErrorCode SVDGetBV(SVD svd, BV *V, BV *U) {
@@ -178,6 +186,8 @@ static PetscErrorCode MatCreateVecs_Cross(Mat B, Vec *right, Vec *left) {
   if (left) { ierr = MatCreateVecs(svd->A, left, NULL);CHKERRQ(ierr); }
   return 0;
 }
+
+PetscErrorCode SVDCyclicGetEPS(SVD svd, EPS *eps) { return SVDCrossGetEPS(svd, eps); }
 
 PetscErrorCode SVDCrossGetEPS(SVD svd, EPS *eps) {
   PetscErrorCode ierr;
@@ -268,7 +278,128 @@ static PetscErrorCode SVDSetUp_Cross(SVD svd) {
   return 0;
 }
 
-/* trlanczos.c:59-75 */
+/* ---- cyclic: the shell matrix [0 A; A^T 0] (cyclic.c:45-79) ------------------------------- */
+/* The two halves of a vector of the shell are addressed through views placed on its storage
+ * (device memory for the "hip" vectors: nothing is copied). */
+static PetscErrorCode MatMult_Cyclic(Mat B, Vec x, Vec y) {
+  PetscErrorCode ierr;
+  SVD svd;
+  ierr = MatShellGetContext(B, (void **)&svd);CHKERRQ(ierr);
+  const PetscInt64 m = svd->A->n;
+  ierr = VecPlaceArray(svd->cx1, x->array);CHKERRQ(ierr);
+  ierr = VecPlaceArray(svd->cx2, x->array + m);CHKERRQ(ierr);
+  ierr = VecPlaceArray(svd->cy1, y->array);CHKERRQ(ierr);
+  ierr = VecPlaceArray(svd->cy2, y->array + m);CHKERRQ(ierr);
+  ierr = SVDMatMult(svd, PETSC_FALSE, svd->cx2, svd->cy1);
+  if (!ierr) ierr = SVDMatMult(svd, PETSC_TRUE, svd->cx1, svd->cy2);
+  VecResetArray(svd->cx1); VecResetArray(svd->cx2); VecResetArray(svd->cy1); VecResetArray(svd->cy2);
+  CHKERRQ(ierr);
+  return 0;
+}
+static PetscErrorCode MatCreateVecs_Cyclic(Mat B, Vec *right, Vec *left) {
+  PetscErrorCode ierr;
+  SVD svd;
+  ierr = MatShellGetContext(B, (void **)&svd);CHKERRQ(ierr);
+  const Vec t = svd->cx1;
+  if (right) { ierr = VecCreateWithOps(t->ops, t->ctx, B->n, B->N, B->row0, PETSC_TRUE, right);CHKERRQ(ierr); }
+  if (left) { ierr = VecCreateWithOps(t->ops, t->ctx, B->n, B->N, B->row0, PETSC_TRUE, left);CHKERRQ(ierr); }
+  return 0;
+}
+
+/* cyclic.c:81-226, shell variant */
+static PetscErrorCode SVDSetUp_Cyclic(SVD svd) {
+  PetscErrorCode ierr;
+  PetscInt64 M, N, m, n;
+  EPS eps;
+  Vec tl, tr;
+  ierr = MatGetSize(svd->A, &M, &N);CHKERRQ(ierr);
+  ierr = MatGetLocalSize(svd->A, &m, &n);CHKERRQ(ierr);
+  if (svd->cyclic_mat) {           /* the shape may have changed */
+    ierr = MatDestroy(&svd->cyclic_mat);CHKERRQ(ierr);
+    ierr = VecDestroy(&svd->cx1);CHKERRQ(ierr); ierr = VecDestroy(&svd->cx2);CHKERRQ(ierr);
+    ierr = VecDestroy(&svd->cy1);CHKERRQ(ierr); ierr = VecDestroy(&svd->cy2);CHKERRQ(ierr);
+  }
+  ierr = MatCreateVecs(svd->A, &tr, &tl);CHKERRQ(ierr);
+  ierr = VecCreateWithOps(tl->ops, tl->ctx, m, M, tl->row0, PETSC_FALSE, &svd->cx1);CHKERRQ(ierr);
+  ierr = VecCreateWithOps(tr->ops, tr->ctx, n, N, tr->row0, PETSC_FALSE, &svd->cx2);CHKERRQ(ierr);
+  ierr = VecCreateWithOps(tl->ops, tl->ctx, m, M, tl->row0, PETSC_FALSE, &svd->cy1);CHKERRQ(ierr);
+  ierr = VecCreateWithOps(tr->ops, tr->ctx, n, N, tr->row0, PETSC_FALSE, &svd->cy2);CHKERRQ(ierr);
+  ierr = MatCreateShell(svd->ctx, m + n, M + N, tl->row0 + tr->row0, svd, MatMult_Cyclic, MatCreateVecs_Cyclic, &svd->cyclic_mat);CHKERRQ(ierr);
+  ierr = VecDestroy(&tl);CHKERRQ(ierr);
+  ierr = VecDestroy(&tr);CHKERRQ(ierr);
+  ierr = SVDCyclicGetEPS(svd, &eps);CHKERRQ(ierr);
+  ierr = EPSSetOperators(eps, svd->cyclic_mat, NULL);CHKERRQ(ierr);
+  ierr = EPSSetProblemType(eps, EPS_HEP);CHKERRQ(ierr);
+  if (svd->which == SVD_LARGEST) { ierr = EPSSetWhichEigenpairs(eps, EPS_LARGEST_REAL);CHKERRQ(ierr); }
+  else { ierr = EPSSetEigenvalueComparison(eps, SlepcCompareSmallestPosReal, NULL);CHKERRQ(ierr); }
+  ierr = EPSSetDimensions(eps, svd->nsv, svd->ncv, svd->mpd);CHKERRQ(ierr);
+  ierr = EPSSetTolerances(eps, svd->tol == 0.0 ? 1e-8 / 10.0 : svd->tol, svd->max_it);CHKERRQ(ierr);
+  ierr = EPSSetConvergenceTest(eps, svd->conv == SVD_CONV_ABS ? EPS_CONV_ABS : EPS_CONV_REL);CHKERRQ(ierr);
+  if (svd->V->type_name[0]) {
+    BV ev;
+    ierr = EPSGetBV(eps, &ev);CHKERRQ(ierr);
+    if (!ev->type_name[0]) { ierr = BVSetType(ev, svd->V->type_name);CHKERRQ(ierr); }
+  }
+  /* a right initial vector v0 of the tall operator becomes [0; v0] (cyclic.c:183-213) */
+  if (svd->nini > 0 && svd->IS[0]->n == n) {
+    Vec x;
+    ierr = MatCreateVecs(svd->cyclic_mat, &x, NULL);CHKERRQ(ierr);
+    ierr = VecSet(x, 0.0);CHKERRQ(ierr);
+    ierr = VecPlaceArray(svd->cx2, x->array + m);CHKERRQ(ierr);
+    ierr = VecCopy(svd->IS[0], svd->cx2);
+    VecResetArray(svd->cx2);
+    if (!ierr) ierr = EPSSetInitialSpace(eps, 1, &x);
+    VecDestroy(&x);
+    CHKERRQ(ierr);
+  }
+  ierr = EPSSetUp(eps);CHKERRQ(ierr);
+  ierr = EPSGetDimensions(eps, NULL, &svd->ncv, &svd->mpd);CHKERRQ(ierr);
+  ierr = EPSGetTolerances(eps, NULL, &svd->max_it);CHKERRQ(ierr);
+  if (svd->tol == 0.0) svd->tol = 1e-8;
+  svd->leftbasis = PETSC_TRUE;
+  /* the bases hold every eigenvector the EPS may return; the reported ncv is capped as the reference does */
+  ierr = SVDAllocateSolution(svd, 0);CHKERRQ(ierr);
+  svd->ncv = (PetscInt)PetscMin((PetscInt64)svd->ncv, PetscMin(M, N));
+  return 0;
+}
+
+/* cyclic.c:228-267.  A unit eigenvector of the shell holds u/sqrt(2) and v/sqrt(2): both
+ * halves are scaled by sqrt(2) (the reference revision at hand divides instead, which leaves
+ * singular vectors of norm 1/2). */
+static PetscErrorCode SVDSolve_Cyclic(SVD svd) {
+  PetscErrorCode ierr;
+  PetscInt i, j, nconv;
+  PetscScalar sigma;
+  EPSConvergedReason reason;
+  Vec x;
+  const PetscInt64 m = svd->A->n;
+  ierr = EPSSolve(svd->eps);CHKERRQ(ierr);
+  ierr = EPSGetConverged(svd->eps, &nconv);CHKERRQ(ierr);
+  ierr = EPSGetIterationNumber(svd->eps, &svd->its);CHKERRQ(ierr);
+  ierr = EPSGetConvergedReason(svd->eps, &reason);CHKERRQ(ierr);
+  svd->reason = (SVDConvergedReason)reason;
+  ierr = MatCreateVecs(svd->cyclic_mat, &x, NULL);CHKERRQ(ierr);
+  for (i = 0, j = 0; i < nconv && j < svd->nalloc; i++) {
+    ierr = EPSGetEigenpair(svd->eps, i, &sigma, NULL, x, NULL);
+    if (!ierr && sigma > 0.0) {
+      svd->sigma[j] = sigma;
+      ierr = VecPlaceArray(svd->cx1, x->array);
+      if (!ierr) ierr = VecPlaceArray(svd->cx2, x->array + m);
+      if (!ierr) ierr = BVInsertVec(svd->U, j, svd->cx1);
+      if (!ierr) ierr = BVScaleColumn(svd->U, j, sqrt(2.0));
+      if (!ierr) ierr = BVInsertVec(svd->V, j, svd->cx2);
+      if (!ierr) ierr = BVScaleColumn(svd->V, j, sqrt(2.0));
+      VecResetArray(svd->cx1); VecResetArray(svd->cx2);
+      j++;
+    }
+    if (ierr) { VecDestroy(&x); CHKERRQ(ierr); }
+  }
+  svd->nconv = j;
+  ierr = VecDestroy(&x);CHKERRQ(ierr);
+  return 0;
+}
+
+/* trlanczos.c:59-75; SVDSetUp_Lanczos (gklanczos.c:46-64) sets the same things up */
 static PetscErrorCode SVDSetUp_TRLanczos(SVD svd) {
   PetscErrorCode ierr;
   PetscInt64 N;
@@ -276,7 +407,7 @@ static PetscErrorCode SVDSetUp_TRLanczos(SVD svd) {
   ierr = SVDSetDimensions_Default(svd);CHKERRQ(ierr);
   if (svd->ncv > svd->nsv + svd->mpd) SETERRQ(1, "The value of ncv must not be larger than nev+mpd");
   if (!svd->max_it) svd->max_it = (PetscInt)PetscMax(N / svd->ncv, (PetscInt64)100);
-  svd->leftbasis = PETSC_TRUE;
+  svd->leftbasis = (svd->type == 2 && svd->oneside) ? PETSC_FALSE : PETSC_TRUE;
   ierr = SVDAllocateSolution(svd, 1);CHKERRQ(ierr);
   ierr = DSSetType(svd->ds, "svd");CHKERRQ(ierr);
   ierr = DSSetCompact(svd->ds, PETSC_TRUE);CHKERRQ(ierr);
@@ -303,14 +434,15 @@ PetscErrorCode SVDSetUp(SVD svd) {
   if (svd->ncv > PetscMin(M, N)) svd->ncv = (PetscInt)PetscMin(M, N);
   if (svd->nsv > PetscMin(M, N)) svd->nsv = (PetscInt)PetscMin(M, N);
   if (svd->ncv && svd->nsv > svd->ncv) SETERRQ(PETSC_ERR_ARG_OUTOFRANGE, "nsv bigger than ncv");
-  if (svd->type == 1) { ierr = SVDSetUp_TRLanczos(svd);CHKERRQ(ierr); }
+  if (svd->type == 1 || svd->type == 2) { ierr = SVDSetUp_TRLanczos(svd);CHKERRQ(ierr); }
+  else if (svd->type == 3) { ierr = SVDSetUp_Cyclic(svd);CHKERRQ(ierr); }
   else { ierr = SVDSetUp_Cross(svd);CHKERRQ(ierr); }
   if (svd->tol == 0.0) svd->tol = 1e-8;
   ierr = DSSetSlepcSC(svd->ds, svd->which == SVD_LARGEST ? SlepcCompareLargestReal : SlepcCompareSmallestReal, NULL);CHKERRQ(ierr);
   /* initial vectors: right vectors of the operator as given; with a wide operator they would
    * be left vectors of the tall one and are ignored (svdsetup.c:160-164,183-189) */
   k = 0;
-  if (svd->type == 1 && svd->nini > 0 && M >= N) {
+  if ((svd->type == 1 || svd->type == 2) && svd->nini > 0 && M >= N) {
     k = svd->nini;
     if (k > svd->ncv) SETERRQ(1, "The number of initial vectors is larger than ncv");
     ierr = BVInsertVecs(svd->V, 0, &k, svd->IS, PETSC_TRUE);CHKERRQ(ierr);
@@ -531,6 +663,120 @@ static PetscErrorCode SVDSolve_TRLanczos(SVD svd) {
   return 0;
 }
 
+/* gklanczos.c:109-169: the left vectors are not kept, only the current one (u) and the next
+ * (u1); the norm of u travels with the first Gram-Schmidt pass of the new right vector */
+static PetscErrorCode SVDOneSideLanczos(SVD svd, PetscReal *alpha, PetscReal *beta, BV V, Vec u, Vec u1, PetscInt k, PetscInt n, PetscScalar *work) {
+  PetscErrorCode ierr;
+  PetscInt i, bvl, bvk;
+  PetscReal a, b;
+  Vec z, tmp;
+  ierr = BVGetActiveColumns(V, &bvl, &bvk);CHKERRQ(ierr);
+  ierr = BVGetColumn(V, k, &z);CHKERRQ(ierr);
+  ierr = SVDMatMult(svd, PETSC_FALSE, z, u);CHKERRQ(ierr);
+  ierr = BVRestoreColumn(V, k, &z);CHKERRQ(ierr);
+  for (i = k + 1; i <= n; i++) {
+    ierr = BVGetColumn(V, i, &z);CHKERRQ(ierr);
+    ierr = SVDMatMult(svd, PETSC_TRUE, u, z);CHKERRQ(ierr);
+    ierr = BVRestoreColumn(V, i, &z);CHKERRQ(ierr);
+    ierr = VecNorm(u, NORM_2, &a);CHKERRQ(ierr);
+    ierr = BVSetActiveColumns(V, 0, i);CHKERRQ(ierr);
+    ierr = BVDotColumn(V, i, work);CHKERRQ(ierr);
+    ierr = VecScale(u, 1.0 / a);CHKERRQ(ierr);
+    ierr = BVMultColumn(V, -1.0 / a, 1.0 / a, i, work);CHKERRQ(ierr);
+    /* second pass: h = V^T z, z = z - V h */
+    ierr = BVDotColumn(V, i, work);CHKERRQ(ierr);
+    ierr = BVMultColumn(V, -1.0, 1.0, i, work);CHKERRQ(ierr);
+    ierr = BVNormColumn(V, i, NORM_2, &b);CHKERRQ(ierr);
+    if (i < n) {
+      if (fabs(b) < 10 * PETSC_MACHINE_EPSILON) SETERRQ(1, "Recurrence generated a zero vector; use a two-sided variant");
+      ierr = BVScaleColumn(V, i, 1.0 / b);CHKERRQ(ierr);
+      ierr = BVGetColumn(V, i, &z);CHKERRQ(ierr);
+      ierr = SVDMatMult(svd, PETSC_FALSE, z, u1);CHKERRQ(ierr);
+      ierr = BVRestoreColumn(V, i, &z);CHKERRQ(ierr);
+      ierr = VecAXPY(u1, -b, u);CHKERRQ(ierr);
+      tmp = u; u = u1; u1 = tmp;
+    }
+    alpha[i - 1] = a;
+    beta[i - 1] = b;
+  }
+  ierr = BVSetActiveColumns(V, bvl, bvk);CHKERRQ(ierr);
+  return 0;
+}
+
+/* gklanczos.c:171-275: explicit restart with the first unconverged right singular vector */
+static PetscErrorCode SVDSolve_Lanczos(SVD svd) {
+  PetscErrorCode ierr;
+  PetscReal *alpha, *beta, lastbeta, norm, resnorm;
+  PetscScalar *swork = NULL, *w = NULL, *Q, *PT;
+  PetscInt i, k, j, nv, ld;
+  Vec u = NULL, u1 = NULL;
+  PetscBool conv;
+  ierr = DSGetLeadingDimension(svd->ds, &ld);CHKERRQ(ierr);
+  w = (PetscScalar *)malloc((size_t)ld * sizeof(*w));
+  swork = (PetscScalar *)malloc((size_t)(svd->ncv + 2) * sizeof(*swork));
+  if (!w || !swork) { free(w); free(swork); SETERRQ(PETSC_ERR_MEM, "Out of memory"); }
+#define LCHK2(e) do { ierr = (e); if (ierr) { free(w); free(swork); VecDestroy(&u); VecDestroy(&u1); CHKERRQ(ierr); } } while (0)
+  if (svd->oneside) {
+    LCHK2(MatCreateVecs(svd->A, NULL, &u));
+    LCHK2(MatCreateVecs(svd->A, NULL, &u1));
+  }
+  /* normalize start vector */
+  if (!svd->nini) {
+    LCHK2(BVSetRandomColumn(svd->V, 0));
+    LCHK2(BVNormColumn(svd->V, 0, NORM_2, &norm));
+    LCHK2(BVScaleColumn(svd->V, 0, 1.0 / norm));
+  }
+  while (svd->reason == SVD_CONVERGED_ITERATING) {
+    svd->its++;
+    nv = PetscMin(svd->nconv + svd->mpd, svd->ncv);
+    LCHK2(BVSetActiveColumns(svd->V, svd->nconv, nv));
+    LCHK2(DSGetArrayReal(svd->ds, DS_MAT_T, &alpha));
+    beta = alpha + ld;
+    if (svd->oneside) LCHK2(SVDOneSideLanczos(svd, alpha, beta, svd->V, u, u1, svd->nconv, nv, swork));
+    else {
+      LCHK2(BVSetActiveColumns(svd->U, svd->nconv, nv));
+      LCHK2(SVDTwoSideLanczos(svd, alpha, beta, svd->V, svd->U, svd->nconv, nv));
+    }
+    lastbeta = beta[nv - 1];
+    /* SVD of the bidiagonal matrix */
+    LCHK2(DSSetDimensions(svd->ds, nv, nv, svd->nconv, 0));
+    LCHK2(DSSetState(svd->ds, DS_STATE_INTERMEDIATE));
+    LCHK2(DSSolve(svd->ds, w, NULL));
+    LCHK2(DSSort(svd->ds, w, NULL, NULL, NULL, NULL));
+    /* error estimates */
+    k = 0;
+    conv = PETSC_TRUE;
+    LCHK2(DSGetArray(svd->ds, DS_MAT_U, &Q));
+    for (i = svd->nconv; i < nv; i++) {
+      svd->sigma[i] = w[i];
+      resnorm = fabs(Q[nv - 1 + i * ld]) * lastbeta;
+      LCHK2(SVDConverged(svd, svd->sigma[i], resnorm, &svd->errest[i]));
+      if (conv) {
+        if (svd->errest[i] < svd->tol) k++;
+        else conv = PETSC_FALSE;
+      }
+    }
+    if (svd->nconv + k >= svd->nsv) svd->reason = SVD_CONVERGED_TOL;
+    else if (svd->its >= svd->max_it) svd->reason = SVD_DIVERGED_ITS;
+    /* restart vector: the first unconverged right singular vector, kept in column nv */
+    if (svd->reason == SVD_CONVERGED_ITERATING) {
+      LCHK2(DSGetArray(svd->ds, DS_MAT_VT, &PT));
+      for (j = svd->nconv; j < nv; j++) swork[j - svd->nconv] = PT[k + svd->nconv + j * ld];
+      LCHK2(BVMultColumn(svd->V, 1.0, 0.0, nv, swork));
+    }
+    /* converged singular vectors */
+    LCHK2(UpdateBasisDS(svd->ds, DS_MAT_VT, svd->V, PETSC_TRUE, svd->nconv, svd->nconv + k));
+    if (!svd->oneside) LCHK2(UpdateBasisDS(svd->ds, DS_MAT_U, svd->U, PETSC_FALSE, svd->nconv, svd->nconv + k));
+    if (svd->reason == SVD_CONVERGED_ITERATING) LCHK2(BVCopyColumn(svd->V, nv, svd->nconv + k));
+    svd->nconv += k;
+  }
+#undef LCHK2
+  free(w); free(swork);
+  ierr = VecDestroy(&u);CHKERRQ(ierr);
+  ierr = VecDestroy(&u1);CHKERRQ(ierr);
+  return 0;
+}
+
 /* cross.c:174-200 */
 static PetscErrorCode SVDSolve_Cross(SVD svd) {
   PetscErrorCode ierr;
@@ -567,6 +813,8 @@ PetscErrorCode SVDSolve(SVD svd) {
   svd->nconv = 0;
   for (i = 0; i < svd->ncv; i++) { svd->sigma[i] = 0.0; svd->errest[i] = 0.0; svd->perm[i] = i; }
   if (svd->type == 1) { ierr = SVDSolve_TRLanczos(svd);CHKERRQ(ierr); }
+  else if (svd->type == 2) { ierr = SVDSolve_Lanczos(svd);CHKERRQ(ierr); }
+  else if (svd->type == 3) { ierr = SVDSolve_Cyclic(svd);CHKERRQ(ierr); }
   else { ierr = SVDSolve_Cross(svd);CHKERRQ(ierr); }
   svd->state = svd->leftbasis ? 3 : 2;
   /* sort singular triplets: ascending permutation (insertion sort, stable), reversed for "largest" */
@@ -673,6 +921,11 @@ PetscErrorCode SVDDestroy(SVD *psvd) {
   ierr = EPSDestroy(&svd->eps);CHKERRQ(ierr);
   ierr = MatDestroy(&svd->cross_mat);CHKERRQ(ierr);
   ierr = VecDestroy(&svd->cross_w);CHKERRQ(ierr);
+  ierr = MatDestroy(&svd->cyclic_mat);CHKERRQ(ierr);
+  ierr = VecDestroy(&svd->cx1);CHKERRQ(ierr);
+  ierr = VecDestroy(&svd->cx2);CHKERRQ(ierr);
+  ierr = VecDestroy(&svd->cy1);CHKERRQ(ierr);
+  ierr = VecDestroy(&svd->cy2);CHKERRQ(ierr);
   if (svd->A && svd->A != svd->OP) { ierr = MatDestroy(&svd->A);CHKERRQ(ierr); }
   if (svd->AT && svd->AT != svd->OP) { ierr = MatDestroy(&svd->AT);CHKERRQ(ierr); }
   ierr = BVDestroy(&svd->V);CHKERRQ(ierr);

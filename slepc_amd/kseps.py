@@ -229,6 +229,7 @@ SIGNATURES = {
     "SlepcCompareSmallestReal": (Err, [C.c_double] * 4 + [C.POINTER(C.c_int), vp]),
     "SlepcCompareLargestImaginary": (Err, [C.c_double] * 4 + [C.POINTER(C.c_int), vp]),
     "SlepcCompareSmallestImaginary": (Err, [C.c_double] * 4 + [C.POINTER(C.c_int), vp]),
+    "SlepcCompareSmallestPosReal": (Err, [C.c_double] * 4 + [C.POINTER(C.c_int), vp]),
     "SlepcSortEigenvalues": (Err, [COMPARE_FN, vp, C.c_int, c_dp, c_dp, C.POINTER(C.c_int)]),
     "EPSCreate": (Err, [vp, C.POINTER(vp)]),
     "EPSSetOperators": (Err, [vp, MatP, MatP]),
@@ -272,6 +273,9 @@ SIGNATURES = {
     "SVDSetConvergenceTest": (Err, [vp, C.c_int]),
     "SVDSetInitialSpace": (Err, [vp, C.c_int, C.POINTER(VecP)]),
     "SVDTRLanczosSetOneSide": (Err, [vp, C.c_int]),
+    "SVDLanczosSetOneSide": (Err, [vp, C.c_int]),
+    "SVDCyclicGetEPS": (Err, [vp, C.POINTER(vp)]),
+    "EPSSetEigenvalueComparison": (Err, [vp, COMPARE_FN, vp]),
     "SVDCrossGetEPS": (Err, [vp, C.POINTER(vp)]),
     "SVDGetBV": (Err, [vp, C.POINTER(BVP), C.POINTER(BVP)]),
     "SVDSetUp": (Err, [vp]),
@@ -467,6 +471,7 @@ class SVD:
 
     def set_oneside(self, oneside=True):
         check(self.lib.SVDTRLanczosSetOneSide(self.h, 1 if oneside else 0))
+        check(self.lib.SVDLanczosSetOneSide(self.h, 1 if oneside else 0))
 
     def set_bv_type(self, name):
         V, U = BVP(), BVP()

@@ -389,7 +389,7 @@ def test_libraries_export_declared_symbols():
     for header, libpath, table in (("ksgpu.h", ksgpu.LIB_PATH, ksgpu.SIGNATURES), ("kseps.h", K.LIB_PATH, K.SIGNATURES)):
         text = open(os.path.join(root, "include", header)).read()
         text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-        names = set(re.findall(r"\b((?:ksg_|KS|Vec|Mat|BV|DS|EPS|Slepc)\w+)\s*\(", text))
+        names = set(re.findall(r"\b((?:ksg_|KS|Vec|Mat|BV|DS|EPS|SVD|Slepc)\w+)\s*\(", text))
         names = {n for n in names if not n.endswith("Fn") and n not in ("EPSMonitorFn",)}
         dll = C.CDLL(libpath)
         missing = [n for n in sorted(names) if not hasattr(dll, n)]

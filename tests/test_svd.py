@@ -89,7 +89,8 @@ def _oracle(A, **kw):
 
 
 # ---- the oracle against the golden files -------------------------------------------------
-@pytest.mark.parametrize("solver,oneside", [("cross", False), ("trlanczos", False), ("trlanczos", True)])
+@pytest.mark.parametrize("solver,oneside", [("cross", False), ("trlanczos", False), ("trlanczos", True),
+                                            ("lanczos", False), ("lanczos", True), ("cyclic", False)])
 def test_oracle_goldens(solver, oneside):
     A = grcar(30, 30)
     kw = dict(nsv=1, solver=solver, oneside=oneside, tol=1e-6, max_it=1000)      # test1.c:68-69
@@ -121,6 +122,12 @@ CASES = {
     "grcar_trl_smallest": (lambda: grcar(30, 30), dict(nsv=1, solver="trlanczos", which="smallest", tol=1e-6, max_it=1000)),
     "bidiag_wide_trl_abs": (lambda: bidiag(20, 22), dict(nsv=2, solver="trlanczos", conv="abs")),
     "bidiag_wide_cross": (lambda: bidiag(20, 22), dict(nsv=2, solver="cross")),
+    "grcar_rect_lanczos": (lambda: grcar(35, 30), dict(nsv=4, solver="lanczos")),
+    "grcar_rect_lanczos_oneside": (lambda: grcar(35, 30), dict(nsv=4, solver="lanczos", oneside=True)),
+    "bidiag_wide_lanczos": (lambda: bidiag(20, 22), dict(nsv=2, solver="lanczos", conv="abs")),
+    "grcar_rect_cyclic": (lambda: grcar(35, 30), dict(nsv=4, solver="cyclic")),
+    "grcar_cyclic_smallest": (lambda: grcar(30, 30), dict(nsv=1, solver="cyclic", which="smallest", tol=1e-6, max_it=1000)),
+    "bidiag_wide_cyclic": (lambda: bidiag(20, 22), dict(nsv=2, solver="cyclic")),
     "rdb200_cross": (rdb200, dict(nsv=4, solver="cross")),
     "rdb200_trl": (rdb200, dict(nsv=4, solver="trlanczos")),
 }
@@ -149,7 +156,9 @@ def _check_against_oracle(be, name):
         gu, gv = r["vectors"][i]
         s = np.sign(gv @ v)
         assert np.abs(s * gv - v).max() < 1e-6 and np.abs(s * gu - u).max() < 1e-6
-        assert abs(np.linalg.norm(gu) - 1) < 1e-12 and abs(np.linalg.norm(gv) - 1) < 1e-12
+        # the two halves of an eigenvector of [0 A; A^T 0] have norm 1/sqrt(2) only as far as it has converged
+        ntol = 1e-7 if kw["solver"] == "cyclic" else 1e-12
+        assert abs(np.linalg.norm(gu) - 1) < ntol and abs(np.linalg.norm(gv) - 1) < ntol
 
 
 @pytest.fixture(scope="module")
@@ -227,7 +236,7 @@ def test_gpu_svd_matches_oracle(be_gpu, name):
 @pytest.mark.gpu
 def test_gpu_svd_goldens(be_gpu):
     csr, nc = _csr(grcar(30, 30))
-    for solver in ("cross", "trlanczos"):
+    for solver in ("cross", "trlanczos", "lanczos", "cyclic"):
         kw = dict(nsv=1, solver=solver, tol=1e-6, max_it=1000)
         s1 = common.solve_svd(be_gpu, csr, nc, **kw)["sigma"][0]
         sn = common.solve_svd(be_gpu, csr, nc, which="smallest", **kw)["sigma"][0]
@@ -299,4 +308,6 @@ def test_examples_match_reference_output():
     assert _run_example("ex8") == EX8_1
     assert _run_example("ex8", "-svd_type", "trlanczos") == EX8_1
     assert _run_example("ex8", "-svd_type", "trlanczos", "-svd_trlanczos_oneside") == EX8_1
+    assert _run_example("ex8", "-svd_type", "lanczos") == EX8_1
+    assert _run_example("ex8", "-svd_type", "cyclic") == EX8_1
     assert _run_example("ex14", "-file", os.path.join(MATDIR, "rdb200.petsc"), "-svd_nsv", "4", "-terse") == EX14_1
