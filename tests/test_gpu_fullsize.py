@@ -138,3 +138,35 @@ def test_first_restarts_match_oracle_fullsize(gpu_ctx, lap):
         assert np.abs(got[i][1] - want[i][1]).max() <= 1e-7 * max(want[i][1].max(), 1e-30) + 1e-12
     eps.destroy()
     A.destroy()
+
+
+def test_block_product_and_residual_fullsize(gpu_ctx, lap):
+    """At 16.7M rows: the one-pass block product equals one product per column bit for bit and
+    reproduces the stencil on integer data; the store-free residual norm equals the norm of
+    A x - k x formed on the host."""
+    from slepc_amd import ksgpu
+    A, _ = lap
+    n = G * G
+    m = 5
+    V, W = ksgpu.DeviceBV(gpu_ctx, n, m), ksgpu.DeviceBV(gpu_ctx, n, m)
+    for j in range(m):
+        gpu_ctx.vec_fill_hash(V.column(j), n, 0, 77 + j)
+    x_int = (np.arange(n, dtype=np.int64) * 40503 % 17 - 8).astype(np.float64)
+    gpu_ctx.upload(V.column(2), x_int)
+    V.matmult(A, W)
+    yd = gpu_ctx.vec_alloc(n)
+    for j in range(m):
+        A.mult(V.column(j), yd)
+        assert np.array_equal(gpu_ctx.download(yd, n), gpu_ctx.download(W.column(j), n))
+    assert np.array_equal(gpu_ctx.download(W.column(2), n), _stencil_apply(x_int))
+    # residual of column 0 with a shift: against the host in extended precision
+    x = gpu_ctx.download(V.column(0), n)
+    ax = gpu_ctx.download(W.column(0), n)
+    k = 3.75
+    r = ax.astype(np.longdouble) - np.longdouble(k) * x
+    want = float(np.sqrt(np.sum(r * r)))
+    got = A.residual_norm(k, 0.0, V.column(0))
+    assert abs(got - want) <= 1e-12 * want
+    gpu_ctx.vec_free(yd)
+    V.destroy()
+    W.destroy()
