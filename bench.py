@@ -75,6 +75,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--grid", type=int, default=4096, help="grid columns; each GPU owns grid x grid rows")
     ap.add_argument("--nev", type=int, default=32)
+    ap.add_argument("--eps-type", default="krylovschur", choices=["krylovschur", "arnoldi", "lanczos"],
+                    help="driver on the same kernels (default: the Krylov-Schur path of the metric)")
     ap.add_argument("--workload", default="ex2", choices=["ex2", "lap3d", "markov", "rmat"],
                     help="ex2/lap3d: --grid points per side and GPU (weak scaling); markov: --grid is m of "
                          "ex5 (nonsymmetric, largest real); rmat: --grid is the R-MAT scale (graph Laplacian); "
@@ -161,6 +163,9 @@ def main():
         eps.set_which(K.EPS_LARGEST_REAL)
     else:
         eps.set_problem_type(K.EPS_HEP)
+    if args.eps_type != "krylovschur":
+        eps.set_type(args.eps_type)
+        wname = wname.replace("Krylov-Schur", "explicitly restarted " + args.eps_type.capitalize())
     eps.set_dimensions(args.nev)
     eps.set_tolerances(args.tol, W + Ksteps)     # default tol 1e-8; stop after W+K restarts
     eps.set_bv_type("hip")

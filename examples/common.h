@@ -35,6 +35,15 @@ static void eps_set_from_options(EPS eps, int argc, char **argv) {
   PetscInt nev, ncv, mpd;
   int it = opt_find(argc, argv, "-eps_type");
   if (it && it + 1 < argc) CHK(EPSSetType(eps, argv[it + 1]));       /* krylovschur | arnoldi | lanczos */
+  it = opt_find(argc, argv, "-eps_lanczos_reorthog");                  /* local | full | selective | periodic | partial | delayed */
+  if (it && it + 1 < argc) {
+    static const char *names[] = { "local", "full", "selective", "periodic", "partial", "delayed" };
+    int r = -1;
+    for (int q = 0; q < 6; q++) if (!strcmp(argv[it + 1], names[q])) r = q;
+    if (r < 0) { fprintf(stderr, "unknown reorthogonalization %s\n", argv[it + 1]); exit(1); }
+    CHK(EPSLanczosSetReorthog(eps, (EPSLanczosReorthogType)r));
+  }
+  if (opt_find(argc, argv, "-eps_arnoldi_delayed")) CHK(EPSArnoldiSetDelayed(eps, PETSC_TRUE));
   CHK(EPSGetDimensions(eps, &nev, &ncv, &mpd));
   nev = (PetscInt)opt_int(argc, argv, "-eps_nev", nev);
   CHK(EPSSetDimensions(eps, nev, (PetscInt)opt_int(argc, argv, "-eps_ncv", 0), (PetscInt)opt_int(argc, argv, "-eps_mpd", 0)));

@@ -255,6 +255,8 @@ PetscErrorCode BVNormVec(BV bv, Vec v, NormType type, PetscReal *val);
 PetscErrorCode BVMatMult(BV V, Mat A, BV W);
 PetscErrorCode BVOrthogonalizeVec(BV bv, Vec v, PetscScalar *H, PetscReal *norm, PetscBool *lindep);
 PetscErrorCode BVOrthogonalizeColumn(BV bv, PetscInt j, PetscScalar *H, PetscReal *norm, PetscBool *lindep);
+/* against the columns i < j with which[i] set only; modified Gram-Schmidt (bvorthog.c:587-633) */
+PetscErrorCode BVOrthogonalizeSomeColumn(BV bv, PetscInt j, const PetscBool *which, PetscScalar *H, PetscReal *norm, PetscBool *lindep);
 PetscErrorCode BVOrthonormalizeColumn(BV bv, PetscInt j, PetscBool replace, PetscReal *norm, PetscBool *lindep);
 /* QR factorisation of the active columns (bvorthog.c:768-859): V <- Q with V0 = Q R.  R is a
  * host column-major array with leading dimension ldr >= k (only the block [l,k) x [l,k) is
@@ -320,8 +322,7 @@ PetscErrorCode EPSCreate(void *ctx, EPS *eps);                                  
 PetscErrorCode EPSSetOperators(EPS eps, Mat A, Mat B);                           /* B must be NULL */
 /* "krylovschur" (default; krylovschur.c, ks-symm.c), "arnoldi" (explicit restart,
  * src/eps/impls/krylov/arnoldi/arnoldi.c) or "lanczos" (explicit restart, symmetric problems,
- * full reorthogonalisation: src/eps/impls/krylov/lanczos/lanczos.c with
- * -eps_lanczos_reorthog full) */
+ * src/eps/impls/krylov/lanczos/lanczos.c; reorthogonalisation chosen with EPSLanczosSetReorthog) */
 PetscErrorCode EPSSetType(EPS eps, const char *type);                            /* epsbasic.c */
 PetscErrorCode EPSGetType(EPS eps, const char **type);
 PetscErrorCode EPSSetProblemType(EPS eps, EPSProblemType type);                  /* epsopts.c:946-989 */
@@ -332,6 +333,10 @@ PetscErrorCode EPSSetWhichEigenpairs(EPS eps, EPSWhich which);
 PetscErrorCode EPSSetEigenvalueComparison(EPS eps, SlepcCompareFn cmp, void *ctx);
 PetscErrorCode EPSSetConvergenceTest(EPS eps, EPSConv conv);                     /* epsopts.c; default relative */
 PetscErrorCode EPSSetInitialSpace(EPS eps, PetscInt n, Vec *is);                 /* epssetup.c:449-460 */
+/* reorthogonalisation of the "lanczos" type (lanczos.c:740-790; the default is local) */
+typedef enum { EPS_LANCZOS_REORTHOG_LOCAL = 0, EPS_LANCZOS_REORTHOG_FULL, EPS_LANCZOS_REORTHOG_SELECTIVE,
+               EPS_LANCZOS_REORTHOG_PERIODIC, EPS_LANCZOS_REORTHOG_PARTIAL, EPS_LANCZOS_REORTHOG_DELAYED } EPSLanczosReorthogType;
+PetscErrorCode EPSLanczosSetReorthog(EPS eps, EPSLanczosReorthogType reorthog);
 PetscErrorCode EPSKrylovSchurSetRestart(EPS eps, PetscReal keep);                /* krylovschur.c:290 */
 PetscErrorCode EPSKrylovSchurSetLocking(EPS eps, PetscBool lock);
 /* Arnoldi with delayed reorthogonalisation (-eps_arnoldi_delayed, arnoldi.c:168-175;

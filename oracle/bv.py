@@ -275,14 +275,20 @@ class BV:
         return onorm, norm
 
     def _mgs1(self, j, want_onorm, want_norm):
-        """``BVOrthogonalizeMGS1`` (bvorthog.c:197-227), column variant."""
+        """``BVOrthogonalizeMGS1`` (bvorthog.c:197-227), column variant; ``self._which``
+        (set by ``orthogonalize_some_column``) restricts the columns used."""
         nc = self.nc
         buf = self.get_buffer()
         w = self.col(j)
+        which = getattr(self, "_which", None)
         onrm = nrm = None
         if want_onorm:
             onrm = float(np.sqrt(self.comm.allreduce_sum(np.array([w @ w]))[0]))
+        if which is not None:
+            buf[:nc + j] = 0.0
         for i in range(-nc, j):
+            if which is not None and i >= 0 and not which[i]:
+                continue
             vi = self.col(i)
             dot = float(self.comm.allreduce_sum(np.array([w @ vi]))[0])
             buf[nc + i] = dot
@@ -349,6 +355,60 @@ class BV:
         ksave, lsave = self.k, self.l
         self.l = -self.nc
         nrm, lindep = self._gs(j, True, True)
+        self.k, self.l = ksave, lsave
+        if H is not None:
+            h = self._hcol(j)
+            for i in range(self.l, j):
+                H[i - self.l] = h[self.nc + i]
+        return nrm, lindep
+
+    def orthogonalize_vec(self, v):
+        """``BVOrthogonalizeVec`` (bvorthog.c:391-418) with modified Gram-Schmidt: v against the
+        active columns [0,k) in place, refinement as configured.  Returns (norm, lindep)."""
+        if self.orthog_type != MGS:
+            raise ValueError("only the MGS variant is restated")
+        k = self.k
+
+        def vnorm():
+            return float(np.sqrt(self.comm.allreduce_sum(np.array([v @ v]))[0]))
+
+        def mgs1(want_onorm, want_norm):
+            onrm = vnorm() if want_onorm else None
+            for i in range(-self.nc, k):
+                vi = self.col(i)
+                dot = float(self.comm.allreduce_sum(np.array([v @ vi]))[0])
+                v[:] -= dot * vi
+            return onrm, (vnorm() if want_norm else None)
+        if self.orthog_ref == REFINE_IFNEEDED:
+            onrm, nrm = mgs1(True, True)
+            l = 1
+            while l < 3 and nrm and nrm < self.orthog_eta * onrm:
+                l += 1
+                onrm = nrm
+                _, nrm = mgs1(False, True)
+            lindep = not (nrm and nrm >= self.orthog_eta * onrm)
+        elif self.orthog_ref == REFINE_NEVER:
+            mgs1(False, False)
+            nrm = vnorm()
+            lindep = not nrm
+        else:
+            mgs1(False, False)
+            onrm, nrm = mgs1(True, True)
+            lindep = not (nrm and nrm >= self.orthog_eta * onrm)
+        return nrm, lindep
+
+    def orthogonalize_some_column(self, j, which, H=None):
+        """``BVOrthogonalizeSomeColumn`` (bvorthog.c:587-633): modified Gram-Schmidt against
+        the columns i < j with which[i] set (and the constraints).  Returns (norm, lindep)."""
+        if self.orthog_type != MGS:
+            raise ValueError("Operation only available for MGS orthogonalization")
+        ksave, lsave = self.k, self.l
+        self.l = -self.nc
+        self._which = which
+        try:
+            nrm, lindep = self._gs(j, True, True)
+        finally:
+            self._which = None
         self.k, self.l = ksave, lsave
         if H is not None:
             h = self._hcol(j)

@@ -10,6 +10,7 @@ Follows ``src/eps/impls/krylov/krylovschur/ks-symm.c:30-111``,
 """
 import numpy as np
 
+from . import bv as bvmod
 from . import ds as dsmod
 from .bv import BV, SelfComm, EPSILON, REFINE_IFNEEDED, REFINE_NEVER, REFINE_ALWAYS
 
@@ -41,7 +42,7 @@ class EPS:
     def __init__(self, matvec, n_local, N=None, hermitian=True, nev=1, ncv=0, mpd=0,
                  tol=1e-8, max_it=0, which=None, keep=0.5, lock=True, comm=None,
                  row0=0, v0=None, monitor=None, solver="krylovschur", delayed=False,
-                 orthog_refine=REFINE_IFNEEDED):
+                 orthog_refine=REFINE_IFNEEDED, reorthog="local"):
         self.matvec = matvec
         self.n = int(n_local)
         self.N = int(N if N is not None else n_local)
@@ -52,6 +53,9 @@ class EPS:
         self.conv = "rel"                            # EPSSetConvergenceTest
         self.delayed = delayed                       # EPSArnoldiSetDelayed (arnoldi.c:168-175)
         self.orthog_refine = orthog_refine           # -bv_orthog_refine
+        if reorthog not in ("local", "full", "selective", "periodic", "partial", "delayed"):
+            raise ValueError("unknown reorthogonalization " + reorthog)
+        self.reorthog = reorthog                     # EPSLanczosSetReorthog; the reference's default is local
         self.nev, self.ncv, self.mpd = nev, ncv, mpd
         self.tol = tol                               # default 1e-8: epssetup.c:184
         self.max_it = max_it
@@ -94,6 +98,11 @@ class EPS:
         ncv = self.ncv
         self.V = BV(self.n, ncv + 1, N=self.N, comm=self.comm)   # EPSAllocateSolution(eps,1)
         self.V.orthog_ref = self.orthog_refine
+        if self.solver == "lanczos" and self.reorthog != "full":
+            self.V.orthog_type = bvmod.MGS            # EPSSetUp_Lanczos lanczos.c:77-81
+        if self.solver == "lanczos" and self.reorthog == "selective":
+            self.AV = BV(self.n, ncv + 1, N=self.N, comm=self.comm)
+            self.AV.orthog_type, self.AV.orthog_ref = bvmod.MGS, self.orthog_refine
         self.eigr = np.zeros(ncv + 1)
         self.eigi = np.zeros(ncv + 1)
         self.errest = np.zeros(ncv + 1)
@@ -413,6 +422,207 @@ class EPS:
         ds.set_dimensions(self.nconv, 0, 0)
         ds.set_state(dsmod.STATE_RAW)
 
+    # -- Lanczos recurrences with cheaper reorthogonalisation (lanczos.c:110-541) ------------
+    def _local_lanczos(self, alpha, beta, k, m):
+        """``EPSLocalLanczos`` (lanczos.c:110-148): against the two previous vectors (and the
+        locked ones) only."""
+        V = self.V
+        which = [True] * k + [False] * (m + 1 - k)
+        hwork = np.zeros(m + 1)
+        V.set_active_columns(0, m)
+        M, breakdown = m, False
+        for j in range(k, m):
+            self._apply(V.col(j), V.col(j + 1))
+            which[j] = True
+            if j - 2 >= k:
+                which[j - 2] = False
+            beta[j], breakdown = V.orthogonalize_some_column(j + 1, which, hwork)
+            alpha[j] = hwork[j]
+            if breakdown:
+                M = j + 1
+                break
+            V.scale_column(j + 1, 1.0 / beta[j])
+        return M, breakdown
+
+    def _selective_lanczos(self, alpha, beta, k, m, anorm):
+        """``EPSSelectiveLanczos`` (lanczos.c:213-288): local reorthogonalisation plus
+        orthogonalisation against the nearly converged Ritz vectors."""
+        V, AV = self.V, self.AV
+        sqrteps = np.sqrt(np.finfo(float).eps)
+        which = [True] * k + [False] * (m + 1 - k)
+        hwork = np.zeros(m + 1)
+        nritz = 0
+        M, breakdown = m, False
+        for j in range(k, m):
+            V.set_active_columns(0, m)
+            self._apply(V.col(j), V.col(j + 1))
+            which[j] = True
+            if j - 2 >= k:
+                which[j - 2] = False
+            norm, breakdown = V.orthogonalize_some_column(j + 1, which, hwork)
+            alpha[j] = hwork[j]
+            beta[j] = norm
+            if breakdown:
+                M = j + 1
+                break
+            n = j - k + 1
+            T = np.diag(alpha[k:k + n]) + np.diag(beta[k:k + n - 1], 1) + np.diag(beta[k:k + n - 1], -1)
+            ritz, Y = np.linalg.eigh(T)                       # DenseTridiagonal (stevr)
+            for i in range(n):
+                anorm = max(anorm, abs(ritz[i]))
+            nritzo = sum(1 for i in range(n) if norm * abs(Y[n - 1, i]) < sqrteps * anorm)
+            if nritzo > nritz:
+                nritz = 0
+                for i in range(n):
+                    if norm * abs(Y[n - 1, i]) < sqrteps * anorm:
+                        V.set_active_columns(k, k + n)
+                        V.multvec(1.0, 0.0, AV.col(nritz), Y[:, i].copy())
+                        nritz += 1
+            if nritz > 0:
+                AV.set_active_columns(0, nritz)
+                norm, breakdown = AV.orthogonalize_vec(V.col(j + 1))
+                if breakdown:
+                    M = j + 1
+                    break
+            V.scale_column(j + 1, 1.0 / norm)
+        return M, breakdown
+
+    @staticmethod
+    def _update_omega(omega, omega_old, j, alpha, beta, eps1, anorm):
+        """``update_omega`` (lanczos.c:290-318); beta is indexed as the reference's beta-1."""
+        T = eps1 * anorm
+        binv = 1.0 / beta[j + 1]
+        omega_old[0] = beta[1] * omega[1] + (alpha[0] - alpha[j]) * omega[0] - beta[j] * omega_old[0]
+        omega_old[0] = binv * (omega_old[0] + T) if omega_old[0] > 0 else binv * (omega_old[0] - T)
+        for k in range(1, j - 1):
+            omega_old[k] = beta[k + 1] * omega[k + 1] + (alpha[k] - alpha[j]) * omega[k] + beta[k] * omega[k - 1] - beta[j] * omega_old[k]
+            omega_old[k] = binv * (omega_old[k] + T) if omega_old[k] > 0 else binv * (omega_old[k] - T)
+        omega_old[j - 1] = binv * T
+        for k in range(j):
+            omega[k] = omega_old[k]
+            omega_old[k] = omega[k]
+        omega[j] = eps1
+
+    @staticmethod
+    def _compute_int(which, off, mu, j, delta, eta):
+        """``compute_int`` (lanczos.c:320-357) on which[off:off+j]."""
+        found, maxpos, mx = False, 0, 0.0
+        for i in range(j):
+            if abs(mu[i]) >= delta:
+                which[off + i] = True
+                found = True
+            else:
+                which[off + i] = False
+            if abs(mu[i]) > mx:
+                maxpos, mx = i, abs(mu[i])
+        if not found:
+            which[off + maxpos] = True
+        for i in range(j):
+            if which[off + i]:
+                for kk in range(i, -1, -1):
+                    if abs(mu[kk]) < eta or which[off + kk]:
+                        break
+                    which[off + kk] = True
+                for kk in range(i + 1, j):
+                    if abs(mu[kk]) < eta or which[off + kk]:
+                        break
+                    which[off + kk] = True
+
+    def _partial_lanczos(self, alpha, beta, k, m, anorm):
+        """``EPSPartialLanczos`` (lanczos.c:359-468): periodic or partial reorthogonalisation
+        steered by the omega recurrence that estimates the loss of orthogonality."""
+        V = self.V
+        macheps = np.finfo(float).eps
+        omega = np.zeros(m + 2)
+        omega_old = np.zeros(m + 2)
+        which = [True] * k + [False] * (m + 1 - k)
+        which2 = [False] * (m + 1)
+        hwork = np.zeros(m + 1)
+        reorth = force_reorth = fro = False
+        estimate_anorm = False
+        eps1 = np.sqrt(float(self.N)) * macheps / 2
+        delta = np.sqrt(macheps) / np.sqrt(float(self.ncv))
+        eta = macheps ** 0.75 / np.sqrt(float(self.ncv))
+        if anorm < 0.0:
+            anorm = 1.0
+            estimate_anorm = True
+        V.set_active_columns(0, m)
+        M, breakdown = m, False
+        for j in range(k, m):
+            self._apply(V.col(j), V.col(j + 1))
+            if fro:
+                norm, breakdown = V.orthogonalize_column(j + 1, hwork)
+                alpha[j] = hwork[j]
+            else:
+                which[j] = True
+                if j - 2 >= k:
+                    which[j - 2] = False
+                norm, breakdown = V.orthogonalize_some_column(j + 1, which, hwork)
+                alpha[j] = hwork[j]
+                beta[j] = norm
+                if estimate_anorm:
+                    anorm = max(anorm, abs(alpha[j]) + norm + beta[j - 1]) if j > k else max(anorm, abs(alpha[j]) + norm)
+                reorth = False
+                if j > k:
+                    # the reference passes alpha, beta-1 with absolute index j
+                    bsh = np.concatenate(([0.0], beta))          # bsh[i] = beta[i-1]
+                    self._update_omega(omega, omega_old, j, alpha, bsh, eps1, anorm)
+                    for i in range(j - k):
+                        if abs(omega[i]) > delta:
+                            reorth = True
+                if reorth or force_reorth:
+                    for i in range(k):
+                        which2[i] = False
+                    for i in range(k, j + 1):
+                        which2[i] = True
+                    if self.reorthog == "periodic":
+                        force_reorth = not force_reorth
+                        for i in range(j - k):
+                            omega[i] = eps1
+                    else:
+                        if force_reorth:
+                            force_reorth = False
+                        else:
+                            force_reorth = True
+                            self._compute_int(which2, k, omega, j - k, delta, eta)
+                            for i in range(j - k):
+                                if which2[i + k]:
+                                    omega[i] = eps1
+                    norm, breakdown = V.orthogonalize_some_column(j + 1, which2, hwork)
+            if breakdown or norm < self.N * anorm * macheps:
+                M = j + 1
+                breakdown = True if breakdown else breakdown
+                break
+            if not fro and norm * delta < anorm * eps1:
+                fro = True
+            beta[j] = norm
+            V.scale_column(j + 1, 1.0 / norm)
+        return M, breakdown
+
+    def _basic_lanczos(self, alpha, beta, k, m, anorm):
+        """``EPSBasicLanczos`` (lanczos.c:470-541)."""
+        r = self.reorthog
+        if r == "local":
+            return self._local_lanczos(alpha, beta, k, m)
+        if r == "full":
+            return self._full_lanczos(alpha, beta, k, m)
+        if r == "selective":
+            return self._selective_lanczos(alpha, beta, k, m, anorm)
+        if r in ("periodic", "partial"):
+            return self._partial_lanczos(alpha, beta, k, m, anorm)
+        n = m
+        T = np.zeros((n + 1, n + 1))
+        if self.V.orthog_ref == REFINE_NEVER:
+            _, betam, breakdown = self._delayed_arnoldi1(T, k, n)
+        else:
+            _, betam, breakdown = self._delayed_arnoldi(T, k, n)
+        for i in range(k, n - 1):
+            alpha[i] = T[i, i]
+            beta[i] = T[i + 1, i]
+        alpha[n - 1] = T[n - 1, n - 1]
+        beta[n - 1] = betam
+        return n, breakdown
+
     def _solve_lanczos(self):
         """``EPSSolve_Lanczos`` (src/eps/impls/krylov/lanczos/lanczos.c:543-726) with full
         reorthogonalisation (``EPSBasicLanczos`` -> ``EPSFullLanczos``, :499-541): explicit
@@ -433,7 +643,7 @@ class EPS:
             self.its += 1
             n = min(nconv + self.mpd, ncv)
             d, e = ds.d, ds.e
-            n, breakdown = self._full_lanczos(d, e, nconv, n)
+            n, breakdown = self._basic_lanczos(d, e, nconv, n, anorm)
             beta = e[n - 1]
             ds.set_dimensions(n, nconv, 0)
             ds.set_state(dsmod.STATE_INTERMEDIATE)
@@ -447,6 +657,10 @@ class EPS:
                 resnorm = beta * abs(Y[n - 1, i]) + macheps * anorm
                 bnd[i] = resnorm / abs(ritz[i])                    # EPSConvergedRelative
                 conv[i] = "C" if bnd[i] < self.tol else "N"
+            if self.reorthog == "local":                     # purge repeated ritz values (:598-603)
+                for i in range(nconv + 1, n):
+                    if conv[i] == "C" and abs((ritz[i] - ritz[i - 1]) / ritz[i]) < self.tol:
+                        conv[i] = "R"
             if not breakdown:
                 restart = nconv
                 while restart < n and conv[restart] != "N":
@@ -488,6 +702,33 @@ class EPS:
                     Y[:n, x] = Y[:n, i]
                     Y[:n, i] = tmp
             V.mult_in_place(ds.get_mat_Q(), nconv, k)
+            if self.reorthog == "local":                     # purge spurious ritz values (:661-695)
+                w = np.zeros(self.n)
+                for i in range(nconv, k):
+                    vi = V.col(i)
+                    vi *= 1.0 / np.sqrt(float(V.comm.allreduce_sum(np.array([vi @ vi]))[0]))
+                    self._apply(vi, w)
+                    w -= ritz[i] * vi
+                    norm = np.sqrt(float(V.comm.allreduce_sum(np.array([w @ w]))[0]))
+                    bnd[i] = norm / abs(ritz[i])
+                    if bnd[i] >= self.tol:
+                        conv[i] = "S"
+                i = nconv
+                while i < k:
+                    if conv[i] != "C":
+                        j = i + 1
+                        while j < k and conv[j] != "C":
+                            j += 1
+                        if j >= k:
+                            break
+                        ritz[j], ritz[i] = ritz[i], ritz[j]
+                        bnd[j], bnd[i] = bnd[i], bnd[j]
+                        conv[j], conv[i] = conv[i], conv[j]
+                        tmp = V.col(i).copy()
+                        V.col(i)[:] = V.col(j)
+                        V.col(j)[:] = tmp
+                    i += 1
+                k = i
             for i in range(nconv, n):
                 self.eigr[i] = ritz[i]
                 self.errest[i] = bnd[i]
@@ -497,6 +738,8 @@ class EPS:
             self.reason = self._stopping(nconv)
             if self.reason == ITERATING:
                 V.copy_column(n, nconv)
+                if self.reorthog == "local" and not breakdown:
+                    _, breakdown = V.orthonormalize_column(nconv, False)
                 if breakdown:
                     if self._get_start_vector(nconv):
                         self.reason = DIVERGED_BREAKDOWN

@@ -488,14 +488,16 @@ static PetscErrorCode BV_NormVecOrColumn(BV bv, PetscInt j, Vec v, PetscReal *nr
 }
 
 /* bvorthog.c:197-227 */
-static PetscErrorCode BVOrthogonalizeMGS1(BV bv, PetscInt j, Vec v, PetscScalar *h, PetscScalar *c, PetscReal *onrm, PetscReal *nrm) {
+static PetscErrorCode BVOrthogonalizeMGS1(BV bv, PetscInt j, Vec v, const PetscBool *which, PetscScalar *h, PetscScalar *c, PetscReal *onrm, PetscReal *nrm) {
   PetscErrorCode ierr;
   PetscInt i;
   PetscScalar dot, *cc = CC(bv, c), *hh = HH(bv, j, h);
   Vec vi, w = v;
   if (!v) { ierr = BVGetColumn(bv, j, &w);CHKERRQ(ierr); }
   if (onrm) { ierr = BVNormVec(bv, w, NORM_2, onrm);CHKERRQ(ierr); }
+  if (which) for (i = 0; i < bv->nc + j; i++) cc[i] = 0.0;       /* columns left out contribute nothing */
   for (i = -bv->nc; i < j; i++) {
+    if (which && i >= 0 && !which[i]) continue;
     ierr = BVGetColumn(bv, i, &vi);CHKERRQ(ierr);
     ierr = VecDot(w, vi, &dot);CHKERRQ(ierr);
     cc[bv->nc + i] = dot;
@@ -545,7 +547,7 @@ static PetscErrorCode BVOrthogonalizeCGS1(BV bv, PetscInt j, Vec v, PetscScalar 
 }
 
 /* bvorthog.c:290-361 */
-static PetscErrorCode BVOrthogonalizeGS(BV bv, PetscInt j, Vec v, PetscReal *norm, PetscBool *lindep) {
+static PetscErrorCode BVOrthogonalizeGS(BV bv, PetscInt j, Vec v, const PetscBool *which, PetscReal *norm, PetscBool *lindep) {
   PetscErrorCode ierr;
   PetscScalar *h, *c, *hh;
   PetscReal onrm = 0.0, nrm = 0.0;
@@ -554,7 +556,7 @@ static PetscErrorCode BVOrthogonalizeGS(BV bv, PetscInt j, Vec v, PetscReal *nor
   const PetscBool dolindep = lindep ? PETSC_TRUE : PETSC_FALSE;
   if (v) { k = bv->k; h = bv->h; c = bv->c; }
   else { k = j; h = NULL; c = NULL; }
-#define GS1(on, nr) (mgs ? BVOrthogonalizeMGS1(bv, k, v, h, c, on, nr) : BVOrthogonalizeCGS1(bv, k, v, h, c, on, nr))
+#define GS1(on, nr) (mgs ? BVOrthogonalizeMGS1(bv, k, v, which, h, c, on, nr) : BVOrthogonalizeCGS1(bv, k, v, h, c, on, nr))
   hh = HH(bv, k, h);
   for (i = 0; i < bv->nc + k; i++) hh[i] = 0.0;                   /* BV_CleanCoefficients */
   switch (bv->orthog_ref) {
@@ -606,7 +608,7 @@ PetscErrorCode BVOrthogonalizeVec(BV bv, Vec v, PetscScalar *H, PetscReal *norm,
   bv->l = -bv->nc;
   ierr = BV_AllocateCoeffs(bv);CHKERRQ(ierr);
   ierr = BVGetBuffer(bv, NULL, NULL);CHKERRQ(ierr);
-  ierr = BVOrthogonalizeGS(bv, 0, v, norm, lindep);
+  ierr = BVOrthogonalizeGS(bv, 0, v, NULL, norm, lindep);
   bv->k = ksave; bv->l = lsave;
   CHKERRQ(ierr);
   if (H) for (i = bv->l; i < bv->k; i++) H[i - bv->l] = bv->h[bv->nc + i];     /* BV_StoreCoefficients */
@@ -623,7 +625,27 @@ PetscErrorCode BVOrthogonalizeColumn(BV bv, PetscInt j, PetscScalar *H, PetscRea
   ksave = bv->k; lsave = bv->l;
   bv->l = -bv->nc;
   ierr = BVGetBuffer(bv, NULL, NULL);CHKERRQ(ierr);
-  ierr = BVOrthogonalizeGS(bv, j, NULL, norm, lindep);
+  ierr = BVOrthogonalizeGS(bv, j, NULL, NULL, norm, lindep);
+  bv->k = ksave; bv->l = lsave;
+  CHKERRQ(ierr);
+  if (H) { PetscScalar *hh = HH(bv, j, NULL); for (i = bv->l; i < j; i++) H[i - bv->l] = hh[bv->nc + i]; }
+  bv->state++;
+  return 0;
+}
+
+/* bvorthog.c:587-633: modified Gram-Schmidt against the columns i < j with which[i] set */
+PetscErrorCode BVOrthogonalizeSomeColumn(BV bv, PetscInt j, const PetscBool *which, PetscScalar *H, PetscReal *norm, PetscBool *lindep) {
+  PetscErrorCode ierr;
+  PetscInt i, ksave, lsave;
+  BVCheckSizes(bv);
+  if (!which) SETERRQ(PETSC_ERR_ARG_NULL, "Null array");
+  if (j < 0) SETERRQ(PETSC_ERR_ARG_OUTOFRANGE, "Index j must be non-negative");
+  if (j >= bv->m) SETERRQ(PETSC_ERR_ARG_OUTOFRANGE, "Index j=%d but BV only has %d columns", j, bv->m);
+  if (bv->orthog_type != BV_ORTHOG_MGS) SETERRQ(PETSC_ERR_SUP, "Operation only available for MGS orthogonalization");
+  ksave = bv->k; lsave = bv->l;
+  bv->l = -bv->nc;
+  ierr = BVGetBuffer(bv, NULL, NULL);CHKERRQ(ierr);
+  ierr = BVOrthogonalizeGS(bv, j, NULL, which, norm, lindep);
   bv->k = ksave; bv->l = lsave;
   CHKERRQ(ierr);
   if (H) { PetscScalar *hh = HH(bv, j, NULL); for (i = bv->l; i < j; i++) H[i - bv->l] = hh[bv->nc + i]; }
@@ -643,13 +665,13 @@ PetscErrorCode BVOrthonormalizeColumn(BV bv, PetscInt j, PetscBool replace, Pets
   ksave = bv->k; lsave = bv->l;
   bv->l = -bv->nc;
   ierr = BVGetBuffer(bv, NULL, NULL);CHKERRQ(ierr);
-  ierr = BVOrthogonalizeGS(bv, j, NULL, &nrm, &lndep);
+  ierr = BVOrthogonalizeGS(bv, j, NULL, NULL, &nrm, &lndep);
   if (!ierr && replace && (nrm == 0.0 || lndep)) {
     ierr = BVSetRandomColumn(bv, j);
-    if (!ierr) ierr = BVOrthogonalizeGS(bv, j, NULL, &nrm, &lndep);
+    if (!ierr) ierr = BVOrthogonalizeGS(bv, j, NULL, NULL, &nrm, &lndep);
     if (!ierr && (nrm == 0.0 || lndep)) {
       ierr = BVSetRandomColumn(bv, j);
-      if (!ierr) ierr = BVOrthogonalizeGS(bv, j, NULL, &nrm, &lndep);
+      if (!ierr) ierr = BVOrthogonalizeGS(bv, j, NULL, NULL, &nrm, &lndep);
     }
   }
   bv->k = ksave; bv->l = lsave;

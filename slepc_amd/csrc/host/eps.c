@@ -3,6 +3,7 @@
  * on the device.  Follows src/eps/interface/{epsbasic,epsopts,epssetup,epssolve,
  * epsdefault}.c, src/eps/impls/krylov/epskrylov.c and
  * src/eps/impls/krylov/krylovschur/{krylovschur,ks-symm}.c of the reference. */
+#include "dense.h"
 #include "ksimpl.h"
 
 #define EPSCheckSolved(eps) do { if ((eps)->state < 2) SETERRQ(PETSC_ERR_ARG_WRONGSTATE, "Must call EPSSolve() first: Parameter #1"); } while (0)
@@ -136,6 +137,13 @@ PetscErrorCode EPSSetConvergenceTest(EPS eps, EPSConv conv) {
   eps->conv = conv;
   return 0;
 }
+/* lanczos.c:740-790 */
+PetscErrorCode EPSLanczosSetReorthog(EPS eps, EPSLanczosReorthogType reorthog) {
+  if (!eps) SETERRQ(PETSC_ERR_ARG_NULL, "Null EPS");
+  if (reorthog < EPS_LANCZOS_REORTHOG_LOCAL || reorthog > EPS_LANCZOS_REORTHOG_DELAYED) SETERRQ(PETSC_ERR_ARG_OUTOFRANGE, "Invalid reorthogonalization type");
+  if (eps->reorthog != reorthog) { eps->reorthog = reorthog; eps->state = 0; }
+  return 0;
+}
 /* arnoldi.c:168-175 */
 PetscErrorCode EPSArnoldiSetDelayed(EPS eps, PetscBool delayed) { if (!eps) SETERRQ(PETSC_ERR_ARG_NULL, "Null EPS"); eps->delayed = delayed ? PETSC_TRUE : PETSC_FALSE; return 0; }
 PetscErrorCode EPSKrylovSchurSetLocking(EPS eps, PetscBool lock) { if (!eps) SETERRQ(PETSC_ERR_ARG_NULL, "Null EPS"); eps->lock = lock; return 0; }
@@ -213,6 +221,20 @@ PetscErrorCode EPSSetUp(EPS eps) {
     ierr = DSSetExtraRow(eps->ds, PETSC_TRUE);CHKERRQ(ierr);
   } else if (eps->type == 2) {                     /* EPSSetUp_Lanczos lanczos.c:47-108 */
     if (!eps->ishermitian) SETERRQ(PETSC_ERR_SUP, "Requested method is only available for Hermitian problems");
+    if (eps->reorthog != EPS_LANCZOS_REORTHOG_FULL) eps->V->orthog_type = BV_ORTHOG_MGS;     /* lanczos.c:77-81 */
+    if (eps->reorthog == EPS_LANCZOS_REORTHOG_SELECTIVE) {                                   /* lanczos.c:82-91 */
+      if (eps->AV && eps->AV->m != eps->V->m) { ierr = BVDestroy(&eps->AV);CHKERRQ(ierr); }
+      if (!eps->AV) {
+        ierr = BVCreate(eps->ctx, &eps->AV);CHKERRQ(ierr);
+        ierr = BVSetType(eps->AV, eps->V->type_name);CHKERRQ(ierr);
+        ierr = BVSetSizesFromVec(eps->AV, eps->V->t, eps->V->m);CHKERRQ(ierr);
+      }
+      ierr = BVSetOrthogonalization(eps->AV, BV_ORTHOG_MGS, eps->V->orthog_ref, eps->V->orthog_eta, eps->V->orthog_block);CHKERRQ(ierr);
+    }
+    if (eps->reorthog == EPS_LANCZOS_REORTHOG_LOCAL && eps->nwork < 1) {                     /* EPSSetWorkVecs(eps,1) */
+      ierr = VecDuplicate(eps->V->t, &eps->work[0]);CHKERRQ(ierr);
+      eps->nwork = 1;
+    }
     ierr = DSSetType(eps->ds, "hep");CHKERRQ(ierr);
     ierr = DSSetCompact(eps->ds, PETSC_TRUE);CHKERRQ(ierr);
     ierr = DSSetExtraRow(eps->ds, PETSC_FALSE);CHKERRQ(ierr);
@@ -616,17 +638,245 @@ static PetscErrorCode EPSSolve_Arnoldi(EPS eps) {
   return 0;
 }
 
-/* lanczos.c:543-726 with full reorthogonalisation (EPSBasicLanczos -> EPSFullLanczos,
- * lanczos.c:499-541): explicit restart with the wanted unconverged Ritz vector, converged
- * Ritz vectors locked in front */
+/* ---- Lanczos recurrences with cheaper reorthogonalisation (lanczos.c:110-541) ----------------- */
+/* one Lanczos step with local reorthogonalisation: column j+1 = OP v_j made orthogonal to the
+ * locked columns and to v_{j-1}, v_j */
+static PetscErrorCode LanczosLocalStep(EPS eps, PetscInt j, PetscInt k, PetscBool *which, PetscScalar *hwork, PetscReal *alpha, PetscReal *norm, PetscBool *breakdown) {
+  PetscErrorCode ierr;
+  Vec vj, vj1;
+  ierr = BVGetColumn(eps->V, j, &vj);CHKERRQ(ierr);
+  ierr = BVGetColumn(eps->V, j + 1, &vj1);CHKERRQ(ierr);
+  ierr = STApply(eps, vj, vj1);CHKERRQ(ierr);
+  ierr = BVRestoreColumn(eps->V, j, &vj);CHKERRQ(ierr);
+  ierr = BVRestoreColumn(eps->V, j + 1, &vj1);CHKERRQ(ierr);
+  which[j] = PETSC_TRUE;
+  if (j - 2 >= k) which[j - 2] = PETSC_FALSE;
+  ierr = BVOrthogonalizeSomeColumn(eps->V, j + 1, which, hwork, norm, breakdown);CHKERRQ(ierr);
+  *alpha = hwork[j];
+  return 0;
+}
+
+/* lanczos.c:110-148 */
+static PetscErrorCode EPSLocalLanczos(EPS eps, PetscReal *alpha, PetscReal *beta, PetscInt k, PetscInt *M, PetscBool *breakdown, PetscBool *which, PetscScalar *hwork) {
+  PetscErrorCode ierr;
+  PetscInt i, j, m = *M;
+  for (i = 0; i <= m; i++) which[i] = i < k ? PETSC_TRUE : PETSC_FALSE;
+  ierr = BVSetActiveColumns(eps->V, 0, m);CHKERRQ(ierr);
+  for (j = k; j < m; j++) {
+    ierr = LanczosLocalStep(eps, j, k, which, hwork, &alpha[j], &beta[j], breakdown);CHKERRQ(ierr);
+    if (*breakdown) { *M = j + 1; break; }
+    ierr = BVScaleColumn(eps->V, j + 1, 1.0 / beta[j]);CHKERRQ(ierr);
+  }
+  return 0;
+}
+
+/* lanczos.c:213-288: local reorthogonalisation plus orthogonalisation against the nearly
+ * converged Ritz vectors, which are kept in eps->AV */
+static PetscErrorCode EPSSelectiveLanczos(EPS eps, PetscReal *alpha, PetscReal *beta, PetscInt k, PetscInt *M, PetscBool *breakdown, PetscReal anorm, PetscBool *which, PetscScalar *hwork) {
+  PetscErrorCode ierr = 0;
+  PetscInt i, j, m = *M, n, nritz = 0, nritzo;
+  Vec vj1, av;
+  PetscReal *d, *e, norm;
+  PetscScalar *Y;
+  const PetscReal sqrteps = sqrt(PETSC_MACHINE_EPSILON);
+  d = (PetscReal *)calloc((size_t)2 * (m + 1), sizeof(*d));
+  Y = (PetscScalar *)calloc((size_t)m * m + 1, sizeof(*Y));
+  if (!d || !Y) { free(d); free(Y); SETERRQ(PETSC_ERR_MEM, "Out of memory"); }
+  e = d + m + 1;
+#define SCHK(call) do { ierr = (call); if (ierr) { free(d); free(Y); CHKERRQ(ierr); } } while (0)
+  for (i = 0; i <= m; i++) which[i] = i < k ? PETSC_TRUE : PETSC_FALSE;
+  for (j = k; j < m; j++) {
+    SCHK(BVSetActiveColumns(eps->V, 0, m));
+    SCHK(LanczosLocalStep(eps, j, k, which, hwork, &alpha[j], &norm, breakdown));
+    beta[j] = norm;
+    if (*breakdown) { *M = j + 1; break; }
+    /* eigenvalues and eigenvectors Y of the tridiagonal block (DenseTridiagonal, :150-211) */
+    n = j - k + 1;
+    for (i = 0; i < n; i++) { d[i] = alpha[i + k]; e[i] = beta[i + k]; }
+    memset(Y, 0, (size_t)n * n * sizeof(*Y));
+    for (i = 0; i < n; i++) Y[i + (size_t)i * n] = 1.0;
+    if (ksd_steqr(n, d, e, Y, n, n)) { free(d); free(Y); SETERRQ(PETSC_ERR_LIB, "Error in the tridiagonal eigensolver"); }
+    for (i = 0; i < n; i++) if (fabs(d[i]) > anorm) anorm = fabs(d[i]);          /* estimate ||A|| */
+    /* nearly converged Ritz vectors */
+    nritzo = 0;
+    for (i = 0; i < n; i++) if (norm * fabs(Y[(size_t)i * n + n - 1]) < sqrteps * anorm) nritzo++;
+    if (nritzo > nritz) {
+      nritz = 0;
+      for (i = 0; i < n; i++) {
+        if (norm * fabs(Y[(size_t)i * n + n - 1]) < sqrteps * anorm) {
+          SCHK(BVSetActiveColumns(eps->V, k, k + n));
+          SCHK(BVGetColumn(eps->AV, nritz, &av));
+          SCHK(BVMultVec(eps->V, 1.0, 0.0, av, Y + (size_t)i * n));
+          SCHK(BVRestoreColumn(eps->AV, nritz, &av));
+          nritz++;
+        }
+      }
+    }
+    if (nritz > 0) {
+      SCHK(BVGetColumn(eps->V, j + 1, &vj1));
+      SCHK(BVSetActiveColumns(eps->AV, 0, nritz));
+      SCHK(BVOrthogonalizeVec(eps->AV, vj1, hwork, &norm, breakdown));
+      SCHK(BVRestoreColumn(eps->V, j + 1, &vj1));
+      if (*breakdown) { *M = j + 1; break; }
+    }
+    SCHK(BVScaleColumn(eps->V, j + 1, 1.0 / norm));
+  }
+#undef SCHK
+  free(d); free(Y);
+  return 0;
+}
+
+/* lanczos.c:290-318: recurrence for the estimated loss of orthogonality; beta is the
+ * reference's beta-1 (beta[i] here is the norm of step i-1) */
+static void update_omega(PetscReal *omega, PetscReal *omega_old, PetscInt j, const PetscReal *alpha, const PetscReal *beta, PetscReal eps1, PetscReal anorm) {
+  PetscInt k;
+  const PetscReal T = eps1 * anorm, binv = 1.0 / beta[j + 1];
+  omega_old[0] = beta[1] * omega[1] + (alpha[0] - alpha[j]) * omega[0] - beta[j] * omega_old[0];
+  omega_old[0] = omega_old[0] > 0 ? binv * (omega_old[0] + T) : binv * (omega_old[0] - T);
+  for (k = 1; k < j - 1; k++) {
+    omega_old[k] = beta[k + 1] * omega[k + 1] + (alpha[k] - alpha[j]) * omega[k] + beta[k] * omega[k - 1] - beta[j] * omega_old[k];
+    omega_old[k] = omega_old[k] > 0 ? binv * (omega_old[k] + T) : binv * (omega_old[k] - T);
+  }
+  omega_old[j - 1] = binv * T;
+  for (k = 0; k < j; k++) { omega[k] = omega_old[k]; omega_old[k] = omega[k]; }
+  omega[j] = eps1;
+}
+
+/* lanczos.c:320-357: the columns to reorthogonalise against, as intervals around the entries
+ * of mu that exceed delta, extended while they exceed eta */
+static void compute_int(PetscBool *which, const PetscReal *mu, PetscInt j, PetscReal delta, PetscReal eta) {
+  PetscInt i, k, maxpos = 0;
+  PetscReal max = 0.0;
+  PetscBool found = PETSC_FALSE;
+  for (i = 0; i < j; i++) {
+    if (fabs(mu[i]) >= delta) { which[i] = PETSC_TRUE; found = PETSC_TRUE; }
+    else which[i] = PETSC_FALSE;
+    if (fabs(mu[i]) > max) { maxpos = i; max = fabs(mu[i]); }
+  }
+  if (!found) which[maxpos] = PETSC_TRUE;
+  for (i = 0; i < j; i++) {
+    if (which[i]) {
+      for (k = i; k >= 0; k--) { if (fabs(mu[k]) < eta || which[k]) break; else which[k] = PETSC_TRUE; }
+      for (k = i + 1; k < j; k++) { if (fabs(mu[k]) < eta || which[k]) break; else which[k] = PETSC_TRUE; }
+    }
+  }
+}
+
+/* lanczos.c:359-468: periodic or partial reorthogonalisation */
+static PetscErrorCode EPSPartialLanczos(EPS eps, PetscReal *alpha, PetscReal *beta, PetscInt k, PetscInt *M, PetscBool *breakdown, PetscReal anorm, PetscBool *which, PetscScalar *hwork) {
+  PetscErrorCode ierr = 0;
+  PetscInt i, j, m = *M;
+  Vec vj, vj1;
+  PetscReal norm = 0.0, *omega, *omega_old, eps1, delta, eta;
+  PetscBool *which2, reorth = PETSC_FALSE, force_reorth = PETSC_FALSE, fro = PETSC_FALSE, estimate_anorm = PETSC_FALSE;
+  omega = (PetscReal *)calloc((size_t)2 * (m + 2), sizeof(*omega));
+  which2 = (PetscBool *)calloc((size_t)m + 2, sizeof(*which2));
+  if (!omega || !which2) { free(omega); free(which2); SETERRQ(PETSC_ERR_MEM, "Out of memory"); }
+  omega_old = omega + m + 2;
+#define PCHK(call) do { ierr = (call); if (ierr) { free(omega); free(which2); CHKERRQ(ierr); } } while (0)
+  eps1 = sqrt((PetscReal)eps->n) * PETSC_MACHINE_EPSILON / 2;
+  delta = sqrt(PETSC_MACHINE_EPSILON) / sqrt((PetscReal)eps->ncv);
+  eta = pow(PETSC_MACHINE_EPSILON, 3.0 / 4.0) / sqrt((PetscReal)eps->ncv);
+  if (anorm < 0.0) { anorm = 1.0; estimate_anorm = PETSC_TRUE; }
+  for (i = 0; i <= m; i++) which[i] = i < k ? PETSC_TRUE : PETSC_FALSE;
+  PCHK(BVSetActiveColumns(eps->V, 0, m));
+  for (j = k; j < m; j++) {
+    if (fro) {
+      /* Lanczos step with full reorthogonalisation */
+      PCHK(BVGetColumn(eps->V, j, &vj));
+      PCHK(BVGetColumn(eps->V, j + 1, &vj1));
+      PCHK(STApply(eps, vj, vj1));
+      PCHK(BVRestoreColumn(eps->V, j, &vj));
+      PCHK(BVRestoreColumn(eps->V, j + 1, &vj1));
+      PCHK(BVOrthogonalizeColumn(eps->V, j + 1, hwork, &norm, breakdown));
+      alpha[j] = hwork[j];
+    } else {
+      PCHK(LanczosLocalStep(eps, j, k, which, hwork, &alpha[j], &norm, breakdown));
+      beta[j] = norm;
+      if (estimate_anorm) {
+        if (j > k) anorm = PetscMax(anorm, fabs(alpha[j]) + norm + beta[j - 1]);
+        else anorm = PetscMax(anorm, fabs(alpha[j]) + norm);
+      }
+      /* is reorthogonalisation needed? */
+      reorth = PETSC_FALSE;
+      if (j > k) {
+        update_omega(omega, omega_old, j, alpha, beta - 1, eps1, anorm);
+        for (i = 0; i < j - k; i++) if (fabs(omega[i]) > delta) reorth = PETSC_TRUE;
+      }
+      if (reorth || force_reorth) {
+        for (i = 0; i < k; i++) which2[i] = PETSC_FALSE;
+        for (i = k; i <= j; i++) which2[i] = PETSC_TRUE;
+        if (eps->reorthog == EPS_LANCZOS_REORTHOG_PERIODIC) {
+          force_reorth = force_reorth ? PETSC_FALSE : PETSC_TRUE;
+          for (i = 0; i < j - k; i++) omega[i] = eps1;
+        } else {
+          if (force_reorth) force_reorth = PETSC_FALSE;
+          else {
+            force_reorth = PETSC_TRUE;
+            compute_int(which2 + k, omega, j - k, delta, eta);
+            for (i = 0; i < j - k; i++) if (which2[i + k]) omega[i] = eps1;
+          }
+        }
+        PCHK(BVOrthogonalizeSomeColumn(eps->V, j + 1, which2, hwork, &norm, breakdown));
+      }
+    }
+    if (*breakdown || norm < eps->n * anorm * PETSC_MACHINE_EPSILON) { *M = j + 1; break; }
+    if (!fro && norm * delta < anorm * eps1) fro = PETSC_TRUE;      /* switch to full reorthogonalisation */
+    beta[j] = norm;
+    PCHK(BVScaleColumn(eps->V, j + 1, 1.0 / norm));
+  }
+#undef PCHK
+  free(omega); free(which2);
+  return 0;
+}
+
+/* lanczos.c:470-541 */
+static PetscErrorCode EPSBasicLanczos(EPS eps, PetscReal *alpha, PetscReal *beta, PetscInt k, PetscInt *m, PetscBool *breakdown, PetscReal anorm) {
+  PetscErrorCode ierr = 0;
+  PetscInt i, n = *m;
+  PetscReal betam;
+  PetscScalar *T;
+  if (eps->reorthog == EPS_LANCZOS_REORTHOG_FULL) return EPSFullLanczos(eps, alpha, beta, k, m, breakdown);
+  if (eps->reorthog == EPS_LANCZOS_REORTHOG_DELAYED) {
+    T = (PetscScalar *)calloc((size_t)n * n + 1, sizeof(*T));
+    if (!T) SETERRQ(PETSC_ERR_MEM, "Out of memory");
+    if (eps->V->orthog_ref == BV_ORTHOG_REFINE_NEVER) ierr = EPSDelayedArnoldi1(eps, T, n, k, m, &betam, breakdown);
+    else ierr = EPSDelayedArnoldi(eps, T, n, k, m, &betam, breakdown);
+    if (!ierr) {
+      for (i = k; i < n - 1; i++) { alpha[i] = T[(size_t)n * i + i]; beta[i] = T[(size_t)n * i + i + 1]; }
+      alpha[n - 1] = T[(size_t)n * (n - 1) + n - 1];
+      beta[n - 1] = betam;
+    }
+    free(T);
+    CHKERRQ(ierr);
+    return 0;
+  }
+  PetscBool *which = (PetscBool *)calloc((size_t)n + 2, sizeof(*which));
+  PetscScalar *hwork = (PetscScalar *)calloc((size_t)n + 2, sizeof(*hwork));
+  if (!which || !hwork) { free(which); free(hwork); SETERRQ(PETSC_ERR_MEM, "Out of memory"); }
+  switch (eps->reorthog) {
+    case EPS_LANCZOS_REORTHOG_LOCAL: ierr = EPSLocalLanczos(eps, alpha, beta, k, m, breakdown, which, hwork); break;
+    case EPS_LANCZOS_REORTHOG_SELECTIVE: ierr = EPSSelectiveLanczos(eps, alpha, beta, k, m, breakdown, anorm, which, hwork); break;
+    default: ierr = EPSPartialLanczos(eps, alpha, beta, k, m, breakdown, anorm, which, hwork); break;
+  }
+  free(which); free(hwork);
+  CHKERRQ(ierr);
+  return 0;
+}
+
+/* lanczos.c:543-726: explicit restart with the wanted unconverged Ritz vector, converged Ritz
+ * vectors locked in front; with local reorthogonalisation repeated and spurious Ritz values
+ * are purged */
 static PetscErrorCode EPSSolve_Lanczos(EPS eps) {
   PetscErrorCode ierr;
   PetscInt nconv = 0, i, j, k, l, x, n, restart, ncv = eps->ncv, r, ld;
   PetscScalar *Y, *ritz, stmp;
-  PetscReal *d, *e, *bnd, anorm = -1.0, beta, rtmp, resnorm;
+  PetscReal *d, *e, *bnd, anorm = -1.0, beta, rtmp, resnorm, norm;
   PetscInt *perm;
   PetscBool breakdown;
   char *conv, ctmp;
+  Vec vi, vj, w;
+  const PetscBool local = eps->reorthog == EPS_LANCZOS_REORTHOG_LOCAL ? PETSC_TRUE : PETSC_FALSE;
   ierr = DSGetLeadingDimension(eps->ds, &ld);CHKERRQ(ierr);
   ritz = (PetscScalar *)calloc((size_t)ncv + 1, sizeof(*ritz));
   bnd = (PetscReal *)calloc((size_t)ncv + 1, sizeof(*bnd));
@@ -641,7 +891,7 @@ static PetscErrorCode EPSSolve_Lanczos(EPS eps) {
     n = PetscMin(nconv + eps->mpd, ncv);
     LCHK(DSGetArrayReal(eps->ds, DS_MAT_T, &d));
     e = d + ld;
-    LCHK(EPSFullLanczos(eps, d, e, nconv, &n, &breakdown));
+    LCHK(EPSBasicLanczos(eps, d, e, nconv, &n, &breakdown, anorm));
     beta = e[n - 1];
     LCHK(DSSetDimensions(eps->ds, n, 0, nconv, 0));
     LCHK(DSSetState(eps->ds, DS_STATE_INTERMEDIATE));
@@ -654,9 +904,11 @@ static PetscErrorCode EPSSolve_Lanczos(EPS eps) {
     LCHK(DSGetArray(eps->ds, DS_MAT_Q, &Y));
     for (i = nconv; i < n; i++) {
       resnorm = beta * fabs(Y[n - 1 + (size_t)i * ld]) + PETSC_MACHINE_EPSILON * anorm;
-      bnd[i] = resnorm / fabs(ritz[i]);                                     /* EPSConvergedRelative */
+      bnd[i] = eps->conv == EPS_CONV_ABS ? resnorm : resnorm / fabs(ritz[i]);
       conv[i] = bnd[i] < eps->tol ? 'C' : 'N';
     }
+    /* purge repeated ritz values */
+    if (local) for (i = nconv + 1; i < n; i++) if (conv[i] == 'C' && fabs((ritz[i] - ritz[i - 1]) / ritz[i]) < eps->tol) conv[i] = 'R';
     /* restart vector: the wanted one among the unconverged Ritz vectors */
     if (!breakdown) {
       restart = nconv;
@@ -697,6 +949,40 @@ static PetscErrorCode EPSSolve_Lanczos(EPS eps) {
     }
     /* compute converged eigenvectors */
     LCHK(UpdateBasis(eps, DS_MAT_Q, nconv, k));
+    /* purge spurious ritz values: the true residual decides */
+    if (local) {
+      w = eps->work[0];
+      for (i = nconv; i < k; i++) {
+        LCHK(BVGetColumn(eps->V, i, &vi));
+        LCHK(VecNorm(vi, NORM_2, &norm));
+        LCHK(VecScale(vi, 1.0 / norm));
+        LCHK(STApply(eps, vi, w));
+        LCHK(VecAXPY(w, -ritz[i], vi));
+        LCHK(BVRestoreColumn(eps->V, i, &vi));
+        LCHK(VecNorm(w, NORM_2, &norm));
+        bnd[i] = eps->conv == EPS_CONV_ABS ? norm : norm / fabs(ritz[i]);
+        if (bnd[i] >= eps->tol) conv[i] = 'S';
+      }
+      for (i = nconv; i < k; i++) {
+        if (conv[i] != 'C') {
+          j = i + 1;
+          while (j < k && conv[j] != 'C') j++;
+          if (j >= k) break;
+          stmp = ritz[j]; ritz[j] = ritz[i]; ritz[i] = stmp;
+          rtmp = bnd[j]; bnd[j] = bnd[i]; bnd[i] = rtmp;
+          ctmp = conv[j]; conv[j] = conv[i]; conv[i] = ctmp;
+          /* swap eigenvectors i and j through the work vector */
+          LCHK(BVGetColumn(eps->V, i, &vi));
+          LCHK(BVGetColumn(eps->V, j, &vj));
+          LCHK(VecCopy(vi, w));
+          LCHK(VecCopy(vj, vi));
+          LCHK(VecCopy(w, vj));
+          LCHK(BVRestoreColumn(eps->V, i, &vi));
+          LCHK(BVRestoreColumn(eps->V, j, &vj));
+        }
+      }
+      k = i;
+    }
     /* store ritz values and estimated errors */
     for (i = nconv; i < n; i++) { eps->eigr[i] = ritz[i]; eps->errest[i] = bnd[i]; }
     nconv = k;
@@ -704,6 +990,7 @@ static PetscErrorCode EPSSolve_Lanczos(EPS eps) {
     EPSStoppingBasic(eps, eps->its, eps->max_it, nconv, eps->nev, &eps->reason);
     if (eps->reason == EPS_CONVERGED_ITERATING) {       /* copy restart vector */
       LCHK(BVCopyColumn(eps->V, n, nconv));
+      if (local && !breakdown) LCHK(BVOrthonormalizeColumn(eps->V, nconv, PETSC_FALSE, NULL, &breakdown));   /* reorthonormalise the restart vector */
       if (breakdown) {                                  /* use a random vector for restarting */
         LCHK(EPSGetStartVector(eps, nconv, &breakdown));
         if (breakdown) eps->reason = EPS_DIVERGED_BREAKDOWN;
@@ -918,6 +1205,7 @@ PetscErrorCode EPSDestroy(EPS *peps) {
   for (PetscInt j = 0; j < eps->nini && eps->IS; j++) { ierr = VecDestroy(&eps->IS[j]);CHKERRQ(ierr); }
   free(eps->IS);
   ierr = BVDestroy(&eps->V);CHKERRQ(ierr);
+  ierr = BVDestroy(&eps->AV);CHKERRQ(ierr);
   ierr = DSDestroy(&eps->ds);CHKERRQ(ierr);
   free(eps->eigr); free(eps->eigi); free(eps->errest); free(eps->perm);
   free(eps);

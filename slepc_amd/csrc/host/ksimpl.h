@@ -52,6 +52,8 @@ struct _p_EPS {
   PetscReal keep;
   PetscBool lock, keep_set;
   EPSConv conv;             /* convergence test: relative (default) or absolute */
+  EPSLanczosReorthogType reorthog;   /* Lanczos */
+  BV AV;                    /* Lanczos, selective: nearly converged Ritz vectors */
   PetscBool delayed;        /* Arnoldi: delayed reorthogonalisation (arnoldi.c:168-175) */
   Vec *IS; PetscInt nini;
   PetscScalar *eigr, *eigi;

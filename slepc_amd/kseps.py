@@ -32,6 +32,7 @@ EPS_CONVERGED_TOL, EPS_DIVERGED_ITS, EPS_DIVERGED_BREAKDOWN = 1, -1, -2
 BV_ORTHOG_CGS, BV_ORTHOG_MGS = 0, 1
 BV_ORTHOG_REFINE_IFNEEDED, BV_ORTHOG_REFINE_NEVER, BV_ORTHOG_REFINE_ALWAYS = 0, 1, 2
 BV_ORTHOG_BLOCK_GS, BV_ORTHOG_BLOCK_CHOL, BV_ORTHOG_BLOCK_TSQR = 0, 1, 2
+LANCZOS_REORTHOG = {"local": 0, "full": 1, "selective": 2, "periodic": 3, "partial": 4, "delayed": 5}
 DS_STATE_RAW, DS_STATE_INTERMEDIATE, DS_STATE_CONDENSED, DS_STATE_TRUNCATED = 0, 1, 2, 3
 DS_MAT_A, DS_MAT_Q, DS_MAT_X, DS_MAT_T = 0, 1, 2, 3
 
@@ -175,6 +176,7 @@ SIGNATURES = {
     "BVGetActiveColumns": (Err, [BVP, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "BVSetOrthogonalization": (Err, [BVP, C.c_int, C.c_int, C.c_double, C.c_int]),
     "BVOrthogonalize": (Err, [BVP, c_dp, C.c_int]),
+    "BVOrthogonalizeSomeColumn": (Err, [BVP, C.c_int, C.POINTER(C.c_int), c_dp, c_dp, C.POINTER(C.c_int)]),
     "BVGetColumn": (Err, [BVP, C.c_int, C.POINTER(VecP)]),
     "BVRestoreColumn": (Err, [BVP, C.c_int, C.POINTER(VecP)]),
     "BVGetBuffer": (Err, [BVP, C.POINTER(c_dp), C.POINTER(C.c_int)]),
@@ -244,6 +246,7 @@ SIGNATURES = {
     "EPSKrylovSchurSetRestart": (Err, [vp, C.c_double]),
     "EPSKrylovSchurSetLocking": (Err, [vp, C.c_int]),
     "EPSArnoldiSetDelayed": (Err, [vp, C.c_int]),
+    "EPSLanczosSetReorthog": (Err, [vp, C.c_int]),
     "EPSMonitorSet": (Err, [vp, MONITOR_FN, vp]),
     "EPSGetBV": (Err, [vp, C.POINTER(BVP)]),
     "EPSGetDS": (Err, [vp, C.POINTER(vp)]),
@@ -594,6 +597,9 @@ class EPS:
 
     def set_locking(self, lock):
         check(self.lib.EPSKrylovSchurSetLocking(self.h, 1 if lock else 0))
+
+    def set_lanczos_reorthog(self, name):
+        check(self.lib.EPSLanczosSetReorthog(self.h, LANCZOS_REORTHOG[name]))
 
     def set_arnoldi_delayed(self, delayed=True):
         check(self.lib.EPSArnoldiSetDelayed(self.h, 1 if delayed else 0))

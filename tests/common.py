@@ -238,7 +238,7 @@ def run_bv_test13(be):
 
 
 def solve_eps(be, csr, hermitian=True, nev=1, ncv=0, mpd=0, tol=0.0, max_it=0, which=None, v0=None,
-              keep=None, lock=True, want_vectors=False, solver=None, delayed=False, orthog_refine=None):
+              keep=None, lock=True, want_vectors=False, solver=None, delayed=False, orthog_refine=None, reorthog=None):
     """EPSCreate / EPSSetOperators / ... / EPSSolve / EPSGetEigenpair / EPSComputeError."""
     rp, ci, va = csr
     A = be.mat_csr(rp, ci, va)
@@ -247,6 +247,8 @@ def solve_eps(be, csr, hermitian=True, nev=1, ncv=0, mpd=0, tol=0.0, max_it=0, w
     eps.set_problem_type(K.EPS_HEP if hermitian else K.EPS_NHEP)
     if solver:
         eps.set_type(solver)
+    if reorthog:
+        eps.set_lanczos_reorthog(reorthog)
     if delayed:
         eps.set_arnoldi_delayed(True)
     if orthog_refine is not None:

@@ -78,10 +78,13 @@ CASES = {
     "markov_120": (lambda: mg.markov(120), False, dict(nev=6, which="largest_real", tol=1e-12)),
     # explicitly restarted Arnoldi (arnoldi.c) on the same kernels
     "lap2d_60x45_arnoldi": (lambda: mg.laplacian2d(60, 45), True, dict(nev=4, tol=1e-9, solver="arnoldi")),
-    "lap2d_60x45_lanczos": (lambda: mg.laplacian2d(60, 45), True, dict(nev=4, ncv=40, tol=1e-9, solver="lanczos")),
+    "lap2d_60x45_lanczos": (lambda: mg.laplacian2d(60, 45), True, dict(nev=4, ncv=40, tol=1e-9, solver="lanczos", reorthog="full")),
     "markov_15_arnoldi_delayed": (lambda: mg.markov(15), False, dict(nev=3, which="largest_real", tol=1e-7, solver="arnoldi", delayed=True)),
     "markov_15_arnoldi_delayed_never": (lambda: mg.markov(15), False, dict(nev=3, which="largest_real", tol=1e-7, solver="arnoldi", delayed=True,
                                                                           orthog_refine=K.BV_ORTHOG_REFINE_NEVER)),
+    "lap2d_40x30_lanczos_local": (lambda: mg.laplacian2d(40, 30), True, dict(nev=3, ncv=32, tol=1e-9, solver="lanczos", reorthog="local")),
+    "lap2d_40x30_lanczos_selective": (lambda: mg.laplacian2d(40, 30), True, dict(nev=3, ncv=32, tol=1e-9, solver="lanczos", reorthog="selective")),
+    "lap2d_40x30_lanczos_partial": (lambda: mg.laplacian2d(40, 30), True, dict(nev=3, ncv=32, tol=1e-9, solver="lanczos", reorthog="partial")),
     "markov_60_arnoldi": (lambda: mg.markov(60), False, dict(nev=4, which="largest_real", tol=1e-10, solver="arnoldi")),
 }
 

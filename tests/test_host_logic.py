@@ -269,19 +269,26 @@ def test_eps_goldens(be):
 
 
 @pytest.mark.parametrize("case", ["lap2d", "lap1d_locking_off", "markov", "markov_mag", "lap2d_arnoldi", "markov_arnoldi", "lap2d_lanczos",
-                                  "markov_arnoldi_delayed", "markov_arnoldi_delayed_never"])
+                                  "markov_arnoldi_delayed", "markov_arnoldi_delayed_never",
+                                  "lap2d_lanczos_local", "lap2d_lanczos_selective", "lap2d_lanczos_periodic",
+                                  "lap2d_lanczos_partial", "lap2d_lanczos_delayed"])
 def test_eps_matches_oracle_driver(be, case):
     """Same start vector, same kernels: the C driver and the oracle driver must take
     the same decisions (restarts, converged count) and agree to rounding."""
     from scipy.sparse import csr_matrix
     kw = dict(nev=5, tol=1e-10)
     herm = True
-    if case in ("lap2d", "lap2d_arnoldi", "lap2d_lanczos"):
+    if case.startswith("lap2d_lanczos_"):
+        csr = og.laplacian2d(31, 23)
+        kw.update(solver="lanczos", tol=1e-9, reorthog=case.rsplit("_", 1)[1], nev=4)
+        if case.endswith("delayed"):          # "may be unstable": it stagnates beyond two pairs here
+            kw.update(nev=2, tol=1e-8)
+    elif case in ("lap2d", "lap2d_arnoldi", "lap2d_lanczos"):
         csr = og.laplacian2d(31, 23)
         if case.endswith("arnoldi"):
             kw.update(solver="arnoldi", tol=1e-9)
         elif case.endswith("lanczos"):
-            kw.update(solver="lanczos", tol=1e-9)
+            kw.update(solver="lanczos", reorthog="full", tol=1e-9)
     elif case == "markov_arnoldi":
         csr = og.markov(18)
         herm = False

@@ -185,21 +185,21 @@ def test_eps_goldens_lanczos():
     the reference's runtest2_2_full, runtest4_1_lanczos, runtest8_1_lanczos
     (src/eps/examples/tests/makefile:260-265,294-298,374-383)."""
     g = golden("eps_tests.json")
-    e = _solve(og.laplacian1d(30), nev=4, solver="lanczos")
+    e = _solve(og.laplacian1d(30), nev=4, solver="lanczos", reorthog="full")
     assert _vals(e, 4) == g["test2"]["largest"] == g["test4"]["values"]
     assert all(e.compute_error(i) < 5e-8 for i in range(4))
-    e = _solve(og.laplacian1d(30), nev=4, which="smallest_real", solver="lanczos")
+    e = _solve(og.laplacian1d(30), nev=4, which="smallest_real", solver="lanczos", reorthog="full")
     assert _vals(e, 4) == g["test2"]["smallest"]
     # the 72 x 72 grid has double eigenvalues (7.99074 twice); restarted Lanczos with full
     # reorthogonalisation finds both copies, the golden Krylov-Schur run lists one: compare
     # the distinct values
-    e = _solve(og.laplacian2d(72), nev=4, ncv=20, solver="lanczos")
+    e = _solve(og.laplacian2d(72), nev=4, ncv=20, solver="lanczos", reorthog="full")
     assert sorted(set(_vals(e, 4)), reverse=True) == g["ex2"]["values"][:3]
     # test8: full reorthogonalisation with explicit restarts does find both copies of 7.88881
-    e = _solve(og.laplacian2d(20), nev=4, ncv=11, solver="lanczos")
+    e = _solve(og.laplacian2d(20), nev=4, ncv=11, solver="lanczos", reorthog="full")
     assert _vals(e, 4) == g["test8"]["values"]
     with pytest.raises(ValueError):
-        _solve(og.markov(6), hermitian=False, solver="lanczos")
+        _solve(og.markov(6), hermitian=False, solver="lanczos", reorthog="full")
 
 
 def test_eps_analytic_spectrum():
@@ -219,3 +219,17 @@ def test_matvec_variants_agree():
     y1 = og.csr_matvec(rp, ci, va, x, np.zeros_like(x))
     y2 = og.csr_matvec_fast(rp, ci, va, x, np.zeros_like(x))
     assert np.array_equal(y1, y2)
+
+
+@pytest.mark.parametrize("reorthog", ["local", "selective", "periodic", "partial", "delayed"])
+def test_eps_goldens_lanczos_reorthog(reorthog):
+    """runtest2_2_{local,selective,periodic,partial} of the reference
+    (src/eps/examples/tests/makefile:260-265; the golden file is test2_1.out), and the delayed
+    variant on the same problem."""
+    g = golden("eps_tests.json")
+    e = _solve(og.laplacian1d(30), nev=4, solver="lanczos", reorthog=reorthog)
+    assert _vals(e, 4) == g["test2"]["largest"]
+    assert all(e.compute_error(i) < 5e-8 for i in range(4))
+    if reorthog != "delayed":          # "may be unstable": the fourth smallest value does not converge with it
+        e = _solve(og.laplacian1d(30), nev=4, which="smallest_real", solver="lanczos", reorthog=reorthog)
+        assert _vals(e, 4) == g["test2"]["smallest"]
