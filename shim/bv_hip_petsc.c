@@ -4,7 +4,8 @@
  * NOT compiled in this repository (PETSc is not available here): this is the
  * binding a SLEPc maintainer adds next to src/sys/classes/bv/impls/svec/ and links
  * against libksgpu.so.  It fills struct _BVOps (include/slepc/private/bvimpl.h:35-64)
- * exactly as BVCreate_Svec does (svec.c:482-517), every slot forwarding to the C ABI
+ * exactly as BVCreate_Svec does (svec.c:482-517), every slot that is called without a NULL
+ * check (bvops.c, bvglobal.c, bvbasic.c) forwarding to the C ABI
  * of include/ksgpu.h.  Register with
  *     BVRegister("hip", BVCreate_HIP);          (include/slepcbv.h:196)
  * after SlepcInitialize and select with -bv_type hip.
@@ -110,11 +111,166 @@ static PetscErrorCode BVRestoreColumn_HIP(BV bv,PetscInt j,Vec *v)
   PetscFunctionReturn(0);
 }
 
-/* mult, multinplacetrans, dot, dotvec_local, norm_local, matmult, copy, resize,
-   getarray(read), destroy: the same three lines each, forwarding to ksg_bv_mult,
-   ksg_bv_multinplace(...,1), ksg_bv_dot, ksg_bv_dotvec_local, ksg_bv_norm_local,
-   ksg_bv_matmult (or MatMult on two column views), ksg_bv_copy, ksg_bv_resize,
-   ksg_vec_download into a host mirror, ksg_bv_destroy. */
+static PetscErrorCode BVMultInPlaceTranspose_HIP(BV V,Mat Q,PetscInt s,PetscInt e)
+{
+  PetscErrorCode ierr;
+  PetscScalar    *q;
+  PetscInt       ldq;
+
+  PetscFunctionBegin;
+  SYNC(V);
+  ierr = MatGetSize(Q,&ldq,NULL);CHKERRQ(ierr);
+  ierr = MatDenseGetArray(Q,&q);CHKERRQ(ierr);
+  KSG(ksg_bv_multinplace(((BV_HIP*)V->data)->bv,q,(int)ldq,(int)s,(int)e,1));   /* svec.c:85-100 */
+  ierr = MatDenseRestoreArray(Q,&q);CHKERRQ(ierr);
+  PetscFunctionReturn(0);
+}
+
+static PetscErrorCode BVMult_HIP(BV Y,PetscScalar alpha,PetscScalar beta,BV X,Mat Q)
+{
+  PetscErrorCode ierr;
+  PetscScalar    *q;
+  PetscInt       ldq;
+
+  PetscFunctionBegin;
+  SYNC(X); SYNC(Y);
+  ierr = MatGetSize(Q,&ldq,NULL);CHKERRQ(ierr);
+  ierr = MatDenseGetArray(Q,&q);CHKERRQ(ierr);
+  KSG(ksg_bv_mult(((BV_HIP*)Y->data)->bv,alpha,beta,((BV_HIP*)X->data)->bv,q,(int)ldq));   /* svec.c:27-49 */
+  ierr = MatDenseRestoreArray(Q,&q);CHKERRQ(ierr);
+  PetscFunctionReturn(0);
+}
+
+static PetscErrorCode BVDot_HIP(BV X,BV Y,Mat M)
+{
+  PetscErrorCode ierr;
+  PetscScalar    *m;
+  PetscInt       ldm;
+
+  PetscFunctionBegin;
+  SYNC(X); SYNC(Y);
+  ierr = MatGetSize(M,&ldm,NULL);CHKERRQ(ierr);
+  ierr = MatDenseGetArray(M,&m);CHKERRQ(ierr);
+  KSG(ksg_bv_dot(((BV_HIP*)X->data)->bv,((BV_HIP*)Y->data)->bv,m,(int)ldm));               /* svec.c:102-120 */
+  ierr = MatDenseRestoreArray(M,&m);CHKERRQ(ierr);
+  PetscFunctionReturn(0);
+}
+
+static PetscErrorCode BVDotVec_Local_HIP(BV X,Vec y,PetscScalar *m)
+{
+  PetscErrorCode    ierr;
+  const PetscScalar *py;
+
+  PetscFunctionBegin;
+  SYNC(X);
+  ierr = VecHIPGetArrayRead(y,&py);CHKERRQ(ierr);
+  KSG(ksg_bv_dotvec_local(((BV_HIP*)X->data)->bv,py,m));            /* svec.c:145-163: no reduction */
+  ierr = VecHIPRestoreArrayRead(y,&py);CHKERRQ(ierr);
+  PetscFunctionReturn(0);
+}
+
+static PetscErrorCode BVNorm_Local_HIP(BV bv,PetscInt j,NormType type,PetscReal *val)
+{
+  PetscFunctionBegin;
+  SYNC(bv);
+  KSG(ksg_bv_norm_local(((BV_HIP*)bv->data)->bv,(int)j,(int)type,val));   /* svec.c:199-214 */
+  PetscFunctionReturn(0);
+}
+
+/* W = A*V column by column through MatMult on the two column views, as BVMatMult_Svec does
+   (svec.c:216-262); an operator of the device type can take ksg_bv_matmult, one pass over the
+   matrix for all the columns, instead */
+static PetscErrorCode BVMatMult_HIP(BV V,Mat A,BV W)
+{
+  PetscErrorCode ierr;
+  PetscInt       j;
+  Vec            v,w;
+
+  PetscFunctionBegin;
+  for (j=0;j<V->k-V->l;j++) {
+    ierr = BVGetColumn(V,V->l+j,&v);CHKERRQ(ierr);
+    ierr = BVGetColumn(W,W->l+j,&w);CHKERRQ(ierr);
+    ierr = MatMult(A,v,w);CHKERRQ(ierr);
+    ierr = BVRestoreColumn(V,V->l+j,&v);CHKERRQ(ierr);
+    ierr = BVRestoreColumn(W,W->l+j,&w);CHKERRQ(ierr);
+  }
+  PetscFunctionReturn(0);
+}
+
+static PetscErrorCode BVCopy_HIP(BV V,BV W)
+{
+  PetscFunctionBegin;
+  SYNC(V); SYNC(W);
+  KSG(ksg_bv_copy(((BV_HIP*)V->data)->bv,((BV_HIP*)W->data)->bv));   /* svec.c:264-278 */
+  PetscFunctionReturn(0);
+}
+
+static PetscErrorCode BVResize_HIP(BV bv,PetscInt m,PetscBool copy)
+{
+  PetscFunctionBegin;
+  KSG(ksg_bv_resize(((BV_HIP*)bv->data)->bv,(int)m,(int)copy));      /* svec.c:280-310 */
+  PetscFunctionReturn(0);
+}
+
+/* BVGetArray hands out host memory (svec.c:339-402 with the CUDA variant copying back and
+   forth, sveccuda.cu:527-590): a host mirror of the whole storage, uploaded again on restore */
+static PetscErrorCode BVGetArray_HIP(BV bv,PetscScalar **a)
+{
+  PetscErrorCode ierr;
+  BV_HIP         *ctx = (BV_HIP*)bv->data;
+  PetscInt       j;
+  int64_t        nloc,ld;
+
+  PetscFunctionBegin;
+  KSG(ksg_bv_sizes(ctx->bv,&nloc,NULL,NULL,&ld));
+  ierr = PetscMalloc1((bv->nc+bv->m)*bv->n,a);CHKERRQ(ierr);
+  for (j=0;j<bv->nc+bv->m;j++) KSG(ksg_vec_download(ctx->ctx,*a+j*bv->n,ksg_bv_column(ctx->bv,(int)(j-bv->nc)),nloc));
+  PetscFunctionReturn(0);
+}
+
+static PetscErrorCode BVRestoreArray_HIP(BV bv,PetscScalar **a)
+{
+  PetscErrorCode ierr;
+  BV_HIP         *ctx = (BV_HIP*)bv->data;
+  PetscInt       j;
+
+  PetscFunctionBegin;
+  for (j=0;j<bv->nc+bv->m;j++) KSG(ksg_vec_upload(ctx->ctx,ksg_bv_column(ctx->bv,(int)(j-bv->nc)),*a+j*bv->n,bv->n));
+  ierr = PetscFree(*a);CHKERRQ(ierr);
+  PetscFunctionReturn(0);
+}
+
+static PetscErrorCode BVGetArrayRead_HIP(BV bv,const PetscScalar **a)
+{
+  PetscErrorCode ierr;
+
+  PetscFunctionBegin;
+  ierr = BVGetArray_HIP(bv,(PetscScalar**)a);CHKERRQ(ierr);
+  PetscFunctionReturn(0);
+}
+
+static PetscErrorCode BVRestoreArrayRead_HIP(BV bv,const PetscScalar **a)
+{
+  PetscErrorCode ierr;
+
+  PetscFunctionBegin;
+  ierr = PetscFree(*a);CHKERRQ(ierr);
+  PetscFunctionReturn(0);
+}
+
+static PetscErrorCode BVDestroy_HIP(BV bv)
+{
+  PetscErrorCode ierr;
+  BV_HIP         *ctx = (BV_HIP*)bv->data;
+
+  PetscFunctionBegin;
+  KSG(ksg_bv_destroy(ctx->bv));
+  KSG(ksg_ctx_destroy(ctx->ctx));
+  ierr = VecDestroy(&bv->cv[0]);CHKERRQ(ierr);
+  ierr = VecDestroy(&bv->cv[1]);CHKERRQ(ierr);
+  ierr = PetscFree(bv->data);CHKERRQ(ierr);
+  PetscFunctionReturn(0);
+}
 
 PETSC_EXTERN PetscErrorCode BVCreate_HIP(BV bv)
 {
@@ -142,13 +298,25 @@ PETSC_EXTERN PetscErrorCode BVCreate_HIP(BV bv)
   ierr = VecCreateMPIHIPWithArray(PetscObjectComm((PetscObject)bv->t),bs,nloc,PETSC_DECIDE,NULL,&bv->cv[0]);CHKERRQ(ierr);
   ierr = VecCreateMPIHIPWithArray(PetscObjectComm((PetscObject)bv->t),bs,nloc,PETSC_DECIDE,NULL,&bv->cv[1]);CHKERRQ(ierr);
 
-  bv->ops->multvec       = BVMultVec_HIP;
-  bv->ops->multinplace   = BVMultInPlace_HIP;
-  bv->ops->dotvec        = BVDotVec_HIP;
-  bv->ops->scale         = BVScale_HIP;
-  bv->ops->norm          = BVNorm_HIP;
-  bv->ops->getcolumn     = BVGetColumn_HIP;
-  bv->ops->restorecolumn = BVRestoreColumn_HIP;
-  /* ... remaining slots as listed above ... */
+  bv->ops->mult             = BVMult_HIP;
+  bv->ops->multvec          = BVMultVec_HIP;
+  bv->ops->multinplace      = BVMultInPlace_HIP;
+  bv->ops->multinplacetrans = BVMultInPlaceTranspose_HIP;
+  bv->ops->dot              = BVDot_HIP;
+  bv->ops->dotvec           = BVDotVec_HIP;
+  bv->ops->dotvec_local     = BVDotVec_Local_HIP;
+  bv->ops->scale            = BVScale_HIP;
+  bv->ops->norm             = BVNorm_HIP;
+  bv->ops->norm_local       = BVNorm_Local_HIP;
+  bv->ops->matmult          = BVMatMult_HIP;
+  bv->ops->copy             = BVCopy_HIP;
+  bv->ops->resize           = BVResize_HIP;
+  bv->ops->getcolumn        = BVGetColumn_HIP;
+  bv->ops->restorecolumn    = BVRestoreColumn_HIP;
+  bv->ops->getarray         = BVGetArray_HIP;
+  bv->ops->restorearray     = BVRestoreArray_HIP;
+  bv->ops->getarrayread     = BVGetArrayRead_HIP;
+  bv->ops->restorearrayread = BVRestoreArrayRead_HIP;
+  bv->ops->destroy          = BVDestroy_HIP;
   PetscFunctionReturn(0);
 }
