@@ -80,6 +80,12 @@ struct _VecOps {
   PetscErrorCode (*fillhash)(Vec x, uint64_t seed);     /* x[i] = f(seed, row0+i) */
   PetscErrorCode (*tohost)(Vec x, PetscScalar *host);   /* copy the local entries out */
   PetscErrorCode (*fromhost)(Vec x, const PetscScalar *host);
+  /* optional (may all be NULL): split-phase reductions of the back end.  redopen starts a
+   * batch on the context, dotpost queues x^T y and returns the index of its value, redclose
+   * reduces everything queued (BV posts included) at once and delivers the values. */
+  PetscErrorCode (*redopen)(void *ctx);
+  PetscErrorCode (*dotpost)(Vec x, Vec y, PetscInt *offset);
+  PetscErrorCode (*redclose)(void *ctx, PetscScalar *out, PetscInt count);
 };
 struct _p_Vec {
   const struct _VecOps *ops;
@@ -102,6 +108,10 @@ PetscErrorCode VecScale(Vec x, PetscScalar a);
 PetscErrorCode VecAXPY(Vec y, PetscScalar a, Vec x);
 PetscErrorCode VecDot(Vec x, Vec y, PetscScalar *r);
 PetscErrorCode VecNorm(Vec x, NormType type, PetscReal *r);
+PetscErrorCode VecDotBegin(Vec x, Vec y, PetscScalar *r);
+PetscErrorCode VecDotEnd(Vec x, Vec y, PetscScalar *r);
+PetscErrorCode VecNormBegin(Vec x, NormType type, PetscReal *r);
+PetscErrorCode VecNormEnd(Vec x, NormType type, PetscReal *r);
 PetscErrorCode VecGetSize(Vec x, PetscInt64 *N);
 PetscErrorCode VecGetLocalSize(Vec x, PetscInt64 *n);
 PetscErrorCode VecGetValuesHost(Vec x, PetscScalar *host);         /* stands in for VecGetArray */
@@ -193,6 +203,10 @@ struct _BVOps {
   PetscErrorCode (*getcolumn)(BV bv, PetscInt j, Vec *v);
   PetscErrorCode (*restorecolumn)(BV bv, PetscInt j, Vec *v);
   PetscErrorCode (*destroy)(BV bv);
+  /* optional (may be NULL): the first half of a split-phase dotvec (dotvec_begin of
+   * bvimpl.h:35-64) -- queues X(:,l:k)^T y in the batch opened on the context of the template
+   * vector and returns the index of its first value */
+  PetscErrorCode (*dotvec_post)(BV X, Vec y, PetscInt *offset);
 };
 
 /* struct _p_BV of bvimpl.h:66-105 (the fields this path uses). */
@@ -247,6 +261,18 @@ PetscErrorCode BVMultInPlaceTranspose(BV V, const PetscScalar *Q, PetscInt ldq, 
 PetscErrorCode BVDot(BV X, BV Y, PetscScalar *M, PetscInt ldm);
 PetscErrorCode BVDotVec(BV X, Vec y, PetscScalar *q);
 PetscErrorCode BVDotColumn(BV X, PetscInt j, PetscScalar *q);
+/* Split-phase reductions (bvglobal.c:190-310,732-830; VecDotBegin/End of PETSc): all the
+ * ...Begin calls of a group first, then the ...End calls in the same order; the first End
+ * completes the whole group with one reduction round.  Types without the optional post ops
+ * compute at Begin. */
+PetscErrorCode BVDotVecBegin(BV X, Vec y, PetscScalar *m);
+PetscErrorCode BVDotVecEnd(BV X, Vec y, PetscScalar *m);
+PetscErrorCode BVDotColumnBegin(BV X, PetscInt j, PetscScalar *m);
+PetscErrorCode BVDotColumnEnd(BV X, PetscInt j, PetscScalar *m);
+PetscErrorCode BVNormVecBegin(BV bv, Vec v, NormType type, PetscReal *val);
+PetscErrorCode BVNormVecEnd(BV bv, Vec v, NormType type, PetscReal *val);
+PetscErrorCode BVNormColumnBegin(BV bv, PetscInt j, NormType type, PetscReal *val);
+PetscErrorCode BVNormColumnEnd(BV bv, PetscInt j, NormType type, PetscReal *val);
 PetscErrorCode BVScale(BV bv, PetscScalar alpha);
 PetscErrorCode BVScaleColumn(BV bv, PetscInt j, PetscScalar alpha);
 PetscErrorCode BVNorm(BV bv, NormType type, PetscReal *val);

@@ -132,6 +132,18 @@ int ksg_bv_touch(ksg_bv bv);
  * (BVDotVec_Svec svec.c:122 -> BVDotVec_BLAS_Private bvblas.c:242). */
 int ksg_bv_dotvec(ksg_bv X, const double *y_dev, double *q_host);
 int ksg_bv_dotvec_local(ksg_bv X, const double *y_dev, double *q_host);          /* svec.c:145 */
+/* Split-phase reductions (the role of BVDotVecBegin/End, BVNormVecBegin/End, VecDotBegin/End,
+ * bvglobal.c:190-310, 732-830, which the delayed Arnoldi and the one-sided bidiagonalisations
+ * use to pay one reduction round per step, epskrylov.c:107-129, trlanczos.c:201-217).
+ * ksg_red_open starts a batch; each post launches its reduction into the next free slot of a
+ * device buffer and returns without synchronising (*offset = index of its first value);
+ * ksg_red_close does one all-reduce over all posted values and delivers them to the host in
+ * posting order.  Between open and close other operations may run; one batch per context.
+ * ksg_red_close with count < 0 abandons the batch (after a failed post). */
+int ksg_red_open(ksg_ctx ctx);
+int ksg_red_post_dotvec(ksg_bv X, const double *y_dev, int *offset);     /* X(:,l:k)^T y: k-l values */
+int ksg_red_post_dot(ksg_ctx ctx, const double *x_dev, const double *y_dev, int64_t n, int *offset);  /* x^T y: 1 value */
+int ksg_red_close(ksg_ctx ctx, double *out_host, int count);
 /* y = beta*y + alpha*X(:,l:k)*q; q is a HOST array of k-l coefficients
  * (BVMultVec_Svec svec.c:51 -> BVMultVec_BLAS_Private bvblas.c:65). */
 int ksg_bv_multvec(ksg_bv X, double alpha, double beta, double *y_dev, const double *q_host);

@@ -376,6 +376,56 @@ PetscErrorCode BVDotVec(BV X, Vec y, PetscScalar *q) {
   return 0;
 }
 
+/* ---- split phase (bvglobal.c:190-310, 732-830) -------------------------------------------- */
+PetscErrorCode BVDotVecBegin(BV X, Vec y, PetscScalar *m) {
+  PetscErrorCode ierr;
+  PetscBool batched = PETSC_FALSE;
+  PetscInt off;
+  BVCheckSizes(X);
+  if (!y) SETERRQ(PETSC_ERR_ARG_NULL, "Null vector");
+  if (X->n != y->n) SETERRQ(PETSC_ERR_ARG_INCOMP, "Mismatching local dimension X %lld, y %lld", (long long)X->n, (long long)y->n);
+  if (!m) { ierr = BVGetBuffer(X, &m, NULL);CHKERRQ(ierr); }
+  if (X->ops.dotvec_post) { ierr = KSRedJoin_Private(y->ops, y->ctx, &batched);CHKERRQ(ierr); }
+  if (!batched) { ierr = X->ops.dotvec(X, y, m);CHKERRQ(ierr); return 0; }
+  ierr = X->ops.dotvec_post(X, y, &off);
+  if (ierr) { KSRedAbandon_Private();CHKERRQ(ierr); }
+  KSRedRecord_Private(m, X->k - X->l, off, 0);
+  return 0;
+}
+PetscErrorCode BVDotVecEnd(BV X, Vec y, PetscScalar *m) { (void)X; (void)y; (void)m; return KSRedComplete_Private(); }
+
+PetscErrorCode BVDotColumnBegin(BV X, PetscInt j, PetscScalar *m) {
+  PetscErrorCode ierr;
+  PetscInt ksave;
+  Vec y;
+  BVCheckSizes(X);
+  if (j < 0) SETERRQ(PETSC_ERR_ARG_OUTOFRANGE, "Index j must be non-negative");
+  if (j >= X->m) SETERRQ(PETSC_ERR_ARG_OUTOFRANGE, "Index j=%d but BV only has %d columns", j, X->m);
+  ksave = X->k;
+  X->k = j;
+  ierr = BVGetColumn(X, j, &y);
+  if (!ierr) ierr = BVDotVecBegin(X, y, m);
+  if (!ierr) ierr = BVRestoreColumn(X, j, &y);
+  X->k = ksave;
+  CHKERRQ(ierr);
+  return 0;
+}
+PetscErrorCode BVDotColumnEnd(BV X, PetscInt j, PetscScalar *m) { (void)X; (void)j; (void)m; return KSRedComplete_Private(); }
+
+PetscErrorCode BVNormVecBegin(BV bv, Vec v, NormType type, PetscReal *val) { (void)bv; return VecNormBegin(v, type, val); }
+PetscErrorCode BVNormVecEnd(BV bv, Vec v, NormType type, PetscReal *val) { (void)bv; return VecNormEnd(v, type, val); }
+PetscErrorCode BVNormColumnBegin(BV bv, PetscInt j, NormType type, PetscReal *val) {
+  PetscErrorCode ierr;
+  Vec v;
+  BVCheckSizes(bv);
+  ierr = BVGetColumn(bv, j, &v);CHKERRQ(ierr);
+  ierr = VecNormBegin(v, type, val);
+  if (!ierr) ierr = BVRestoreColumn(bv, j, &v);
+  CHKERRQ(ierr);
+  return 0;
+}
+PetscErrorCode BVNormColumnEnd(BV bv, PetscInt j, NormType type, PetscReal *val) { (void)bv; (void)j; (void)type; (void)val; return KSRedComplete_Private(); }
+
 PetscErrorCode BVDotColumn(BV X, PetscInt j, PetscScalar *q) {
   PetscErrorCode ierr;
   PetscInt ksave;

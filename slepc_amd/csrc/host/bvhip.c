@@ -46,6 +46,12 @@ static PetscErrorCode BVDotVec_HIP(BV X, Vec y, PetscScalar *q) {
   CHKKSG(ksg_bv_dotvec(GBV(X), y->array, q));
   return 0;
 }
+static PetscErrorCode BVDotVecPost_HIP(BV X, Vec y, PetscInt *offset) {
+  PetscErrorCode ierr;
+  ierr = Sync(X);CHKERRQ(ierr);
+  CHKKSG(ksg_red_post_dotvec(GBV(X), y->array, offset));
+  return 0;
+}
 static PetscErrorCode BVDotVec_Local_HIP(BV X, Vec y, PetscScalar *q) {
   PetscErrorCode ierr;
   ierr = Sync(X);CHKERRQ(ierr);
@@ -136,5 +142,6 @@ PetscErrorCode BVCreate_HIP(BV bv) {
   bv->ops.getcolumn = BVGetColumn_HIP;
   bv->ops.restorecolumn = BVRestoreColumn_HIP;
   bv->ops.destroy = BVDestroy_HIP;
+  bv->ops.dotvec_post = BVDotVecPost_HIP;
   return 0;
 }

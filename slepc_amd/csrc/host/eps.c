@@ -354,14 +354,21 @@ static PetscErrorCode EPSDelayedArnoldi(EPS eps, PetscScalar *H, PetscInt ldh, P
     DCHK(BVRestoreColumn(eps->V, j, &vj));
     DCHK(BVRestoreColumn(eps->V, j + 1, &vj1));
 
-    DCHK(BVDotColumn(eps->V, j + 1, H + (size_t)ldh * j));
+    /* every reduction of the step in one group (epskrylov.c:112-135) */
+    DCHK(BVDotColumnBegin(eps->V, j + 1, H + (size_t)ldh * j));
     if (j > k) {
-      DCHK(BVDotColumn(eps->V, j, lhh));
+      DCHK(BVDotColumnBegin(eps->V, j, lhh));
       DCHK(BVGetColumn(eps->V, j, &vj));
-      DCHK(VecDot(vj, vj, &dot));
+      DCHK(VecDotBegin(vj, vj, &dot));
       DCHK(BVRestoreColumn(eps->V, j, &vj));
     }
-    if (j > k + 1) DCHK(BVNormVec(eps->V, u, NORM_2, &norm2));
+    if (j > k + 1) DCHK(BVNormVecBegin(eps->V, u, NORM_2, &norm2));
+    DCHK(BVDotColumnEnd(eps->V, j + 1, H + (size_t)ldh * j));
+    if (j > k) {
+      DCHK(BVDotColumnEnd(eps->V, j, lhh));
+      DCHK(VecDotEnd(NULL, NULL, &dot));
+    }
+    if (j > k + 1) DCHK(BVNormVecEnd(eps->V, u, NORM_2, &norm2));
 
     if (j > k) {
       norm1 = sqrt(dot);
@@ -416,11 +423,15 @@ static PetscErrorCode EPSDelayedArnoldi1(EPS eps, PetscScalar *H, PetscInt ldh, 
     ierr = STApply(eps, vj, vj1);CHKERRQ(ierr);
     ierr = BVRestoreColumn(eps->V, j + 1, &vj1);CHKERRQ(ierr);
     ierr = BVRestoreColumn(eps->V, j, &vj);CHKERRQ(ierr);
-    ierr = BVDotColumn(eps->V, j + 1, H + (size_t)ldh * j);CHKERRQ(ierr);
+    ierr = BVDotColumnBegin(eps->V, j + 1, H + (size_t)ldh * j);CHKERRQ(ierr);
     if (j > k) {
       ierr = BVGetColumn(eps->V, j, &vj);CHKERRQ(ierr);
-      ierr = VecDot(vj, vj, &dot);CHKERRQ(ierr);
+      ierr = VecDotBegin(vj, vj, &dot);CHKERRQ(ierr);
       ierr = BVRestoreColumn(eps->V, j, &vj);CHKERRQ(ierr);
+    }
+    ierr = BVDotColumnEnd(eps->V, j + 1, H + (size_t)ldh * j);CHKERRQ(ierr);
+    if (j > k) {
+      ierr = VecDotEnd(NULL, NULL, &dot);CHKERRQ(ierr);
       norm = sqrt(dot);
       ierr = BVScaleColumn(eps->V, j, 1.0 / norm);CHKERRQ(ierr);
       H[(size_t)ldh * (j - 1) + j] = norm;

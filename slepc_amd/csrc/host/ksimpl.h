@@ -17,6 +17,12 @@ void KSErrorTrace(const char *func, int line);
 /* a libksgpu call: its message becomes ours */
 #define CHKKSG(call) do { int rc_ = (call); if (rc_) return KSError(__func__, __LINE__, PETSC_ERR_LIB, "libksgpu: %s", ksg_last_error()); } while (0)
 
+/* split-phase reductions (vec.c) */
+PetscErrorCode KSRedJoin_Private(const struct _VecOps *ops, void *ctx, PetscBool *batched);
+void KSRedRecord_Private(PetscScalar *dst, PetscInt count, PetscInt offset, int root);
+PetscErrorCode KSRedComplete_Private(void);
+void KSRedAbandon_Private(void);
+
 #define PETSC_MACHINE_EPSILON 2.2204460492503131e-16
 #define PetscMax(a, b) ((a) < (b) ? (b) : (a))
 #define PetscMin(a, b) ((a) < (b) ? (a) : (b))

@@ -540,16 +540,24 @@ static PetscErrorCode SVDOneSideTRLanczosCGS(SVD svd, PetscReal *alpha, PetscRea
   }
   for (i = k + 1; i <= n; i++) {
     ierr = SVDMatMultColumns(svd, PETSC_TRUE, U, i - 1, V, i);CHKERRQ(ierr);
-    ierr = BVNormColumn(U, i - 1, NORM_2, &a);CHKERRQ(ierr);
+    /* the norm of the left vector and the coefficients of the right one in one group
+     * (trlanczos.c:201-217) */
+    ierr = BVNormColumnBegin(U, i - 1, NORM_2, &a);CHKERRQ(ierr);
     if (refine == BV_ORTHOG_REFINE_IFNEEDED) {
       ierr = BVSetActiveColumns(V, 0, i + 1);CHKERRQ(ierr);
       ierr = BVGetColumn(V, i, &vi);CHKERRQ(ierr);
-      ierr = BVDotVec(V, vi, work);CHKERRQ(ierr);
+      ierr = BVDotVecBegin(V, vi, work);CHKERRQ(ierr);
       ierr = BVRestoreColumn(V, i, &vi);CHKERRQ(ierr);
-      ierr = BVSetActiveColumns(V, 0, i);CHKERRQ(ierr);
     } else {
       ierr = BVSetActiveColumns(V, 0, i);CHKERRQ(ierr);
-      ierr = BVDotColumn(V, i, work);CHKERRQ(ierr);
+      ierr = BVDotColumnBegin(V, i, work);CHKERRQ(ierr);
+    }
+    ierr = BVNormColumnEnd(U, i - 1, NORM_2, &a);CHKERRQ(ierr);
+    if (refine == BV_ORTHOG_REFINE_IFNEEDED) {
+      ierr = BVDotVecEnd(V, NULL, work);CHKERRQ(ierr);
+      ierr = BVSetActiveColumns(V, 0, i);CHKERRQ(ierr);
+    } else {
+      ierr = BVDotColumnEnd(V, i, work);CHKERRQ(ierr);
     }
     ierr = BVScaleColumn(U, i - 1, 1.0 / a);CHKERRQ(ierr);
     for (j = 0; j < i; j++) work[j] = work[j] / a;
@@ -678,9 +686,11 @@ static PetscErrorCode SVDOneSideLanczos(SVD svd, PetscReal *alpha, PetscReal *be
     ierr = BVGetColumn(V, i, &z);CHKERRQ(ierr);
     ierr = SVDMatMult(svd, PETSC_TRUE, u, z);CHKERRQ(ierr);
     ierr = BVRestoreColumn(V, i, &z);CHKERRQ(ierr);
-    ierr = VecNorm(u, NORM_2, &a);CHKERRQ(ierr);
+    ierr = VecNormBegin(u, NORM_2, &a);CHKERRQ(ierr);
     ierr = BVSetActiveColumns(V, 0, i);CHKERRQ(ierr);
-    ierr = BVDotColumn(V, i, work);CHKERRQ(ierr);
+    ierr = BVDotColumnBegin(V, i, work);CHKERRQ(ierr);
+    ierr = VecNormEnd(u, NORM_2, &a);CHKERRQ(ierr);
+    ierr = BVDotColumnEnd(V, i, work);CHKERRQ(ierr);
     ierr = VecScale(u, 1.0 / a);CHKERRQ(ierr);
     ierr = BVMultColumn(V, -1.0 / a, 1.0 / a, i, work);CHKERRQ(ierr);
     /* second pass: h = V^T z, z = z - V h */

@@ -17,9 +17,13 @@ static PetscErrorCode VecFillHash_HIP(Vec x, uint64_t seed) { CHKKSG(ksg_vec_fil
 static PetscErrorCode VecToHost_HIP(Vec x, PetscScalar *h) { CHKKSG(ksg_vec_download((ksg_ctx)x->ctx, h, x->array, x->n)); return 0; }
 static PetscErrorCode VecFromHost_HIP(Vec x, const PetscScalar *h) { CHKKSG(ksg_vec_upload((ksg_ctx)x->ctx, x->array, h, x->n)); return 0; }
 
+static PetscErrorCode VecRedOpen_HIP(void *ctx) { CHKKSG(ksg_red_open((ksg_ctx)ctx)); return 0; }
+static PetscErrorCode VecDotPost_HIP(Vec x, Vec y, PetscInt *offset) { CHKKSG(ksg_red_post_dot((ksg_ctx)x->ctx, x->array, y->array, x->n, offset)); return 0; }
+static PetscErrorCode VecRedClose_HIP(void *ctx, PetscScalar *out, PetscInt count) { CHKKSG(ksg_red_close((ksg_ctx)ctx, out, count)); return 0; }
+
 static const struct _VecOps VecOps_HIP = {
   VecAlloc_HIP, VecFree_HIP, VecCopy_HIP, VecSet_HIP, VecScale_HIP, VecAXPY_HIP, VecDot_HIP, VecNorm2_HIP,
-  VecFillHash_HIP, VecToHost_HIP, VecFromHost_HIP
+  VecFillHash_HIP, VecToHost_HIP, VecFromHost_HIP, VecRedOpen_HIP, VecDotPost_HIP, VecRedClose_HIP
 };
 
 PetscErrorCode VecCreateHIP(ksg_ctx ctx, PetscInt64 n, PetscInt64 N, PetscInt64 row0, Vec *v) {
@@ -144,3 +148,89 @@ PetscErrorCode VecFillHash(Vec x, uint64_t seed) {
   x->state++;
   return 0;
 }
+
+/* ---- split-phase reductions -------------------------------------------------------------
+ * One group at a time: the ...Begin calls queue their reductions in the back end (or compute
+ * at once when the type has no post ops), the first ...End closes the group -- one reduction
+ * round -- and hands every queued value to its destination. */
+#define KS_RED_MAXENTRIES 64
+static struct {
+  const struct _VecOps *ops; void *ctx; int open, n; PetscInt total;
+  struct { PetscScalar *dst; PetscInt count, offset; int root; } e[KS_RED_MAXENTRIES];
+} ks_red;
+
+/* opens the group on (ops, ctx) if need be; *batched = whether the back end queues */
+PetscErrorCode KSRedJoin_Private(const struct _VecOps *ops, void *ctx, PetscBool *batched) {
+  PetscErrorCode ierr;
+  *batched = PETSC_FALSE;
+  if (!ops || !ops->redopen || !ops->dotpost || !ops->redclose) return 0;
+  if (ks_red.open && (ks_red.ops != ops || ks_red.ctx != ctx)) SETERRQ(PETSC_ERR_ORDER, "A group of split-phase reductions is open on another context");
+  if (!ks_red.open) {
+    ierr = ops->redopen(ctx);CHKERRQ(ierr);
+    ks_red.ops = ops; ks_red.ctx = ctx; ks_red.open = 1; ks_red.n = 0; ks_red.total = 0;
+  }
+  if (ks_red.n >= KS_RED_MAXENTRIES) SETERRQ(PETSC_ERR_SUP, "Too many reductions in one group");
+  *batched = PETSC_TRUE;
+  return 0;
+}
+
+/* records where the `count` values posted at `offset` go (root: deliver the square root) */
+void KSRedRecord_Private(PetscScalar *dst, PetscInt count, PetscInt offset, int root) {
+  ks_red.e[ks_red.n].dst = dst; ks_red.e[ks_red.n].count = count; ks_red.e[ks_red.n].offset = offset; ks_red.e[ks_red.n].root = root;
+  ks_red.n++;
+  if (offset + count > ks_red.total) ks_red.total = offset + count;
+}
+
+/* drops the open group after a failed post, so that the next group starts clean */
+void KSRedAbandon_Private(void) {
+  if (!ks_red.open) return;
+  ks_red.open = 0;
+  (void)ks_red.ops->redclose(ks_red.ctx, NULL, -1);
+}
+
+PetscErrorCode KSRedComplete_Private(void) {
+  PetscErrorCode ierr;
+  if (!ks_red.open) return 0;
+  ks_red.open = 0;
+  PetscScalar *out = (PetscScalar *)malloc((size_t)PetscMax(ks_red.total, 1) * sizeof(*out));
+  if (!out) SETERRQ(PETSC_ERR_MEM, "Out of memory");
+  ierr = ks_red.ops->redclose(ks_red.ctx, out, ks_red.total);
+  if (!ierr) for (int i = 0; i < ks_red.n; i++)
+    for (PetscInt j = 0; j < ks_red.e[i].count; j++) {
+      const PetscScalar v = out[ks_red.e[i].offset + j];
+      ks_red.e[i].dst[j] = ks_red.e[i].root ? sqrt(v) : v;
+    }
+  free(out);
+  CHKERRQ(ierr);
+  return 0;
+}
+
+PetscErrorCode VecDotBegin(Vec x, Vec y, PetscScalar *r) {
+  PetscErrorCode ierr;
+  PetscBool batched;
+  PetscInt off;
+  if (!x || !y || !r) SETERRQ(PETSC_ERR_ARG_NULL, "Null argument");
+  if (x->n != y->n) SETERRQ(PETSC_ERR_ARG_INCOMP, "Incompatible vector local lengths");
+  ierr = KSRedJoin_Private(x->ops, x->ctx, &batched);CHKERRQ(ierr);
+  if (!batched) return VecDot(x, y, r);
+  ierr = x->ops->dotpost(x, y, &off);
+  if (ierr) { KSRedAbandon_Private();CHKERRQ(ierr); }
+  KSRedRecord_Private(r, 1, off, 0);
+  return 0;
+}
+PetscErrorCode VecDotEnd(Vec x, Vec y, PetscScalar *r) { (void)x; (void)y; (void)r; return KSRedComplete_Private(); }
+
+PetscErrorCode VecNormBegin(Vec x, NormType type, PetscReal *r) {
+  PetscErrorCode ierr;
+  PetscBool batched;
+  PetscInt off;
+  if (!x || !r) SETERRQ(PETSC_ERR_ARG_NULL, "Null argument");
+  if (type != NORM_2 && type != NORM_FROBENIUS) SETERRQ(PETSC_ERR_SUP, "Only the 2-norm is available in split phase");
+  ierr = KSRedJoin_Private(x->ops, x->ctx, &batched);CHKERRQ(ierr);
+  if (!batched) return VecNorm(x, NORM_2, r);
+  ierr = x->ops->dotpost(x, x, &off);
+  if (ierr) { KSRedAbandon_Private();CHKERRQ(ierr); }
+  KSRedRecord_Private(r, 1, off, 1);
+  return 0;
+}
+PetscErrorCode VecNormEnd(Vec x, NormType type, PetscReal *r) { (void)x; (void)type; (void)r; return KSRedComplete_Private(); }

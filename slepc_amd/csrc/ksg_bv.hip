@@ -857,6 +857,66 @@ static int dotvec_impl(ksg_bv X, const double *y, double *q_host, int global) {
 extern "C" int ksg_bv_dotvec(ksg_bv X, const double *y, double *q) { return dotvec_impl(X, y, q, 1); }
 extern "C" int ksg_bv_dotvec_local(ksg_bv X, const double *y, double *q) { return dotvec_impl(X, y, q, 0); }
 
+/* ---- posted reductions ------------------------------------------------------------------
+ * Split-phase reductions (BVDotVecBegin/End, VecDotBegin/End, ... of the reference,
+ * bvglobal.c:190-310, which ride on PETSc's merged MPI_Allreduce): every post launches its
+ * reduction kernel into the next free slot of one device buffer and returns at once; the
+ * close does one all-reduce over all slots and one copy to the host.  A step of the delayed
+ * Arnoldi or of a one-sided bidiagonalisation thus costs one synchronisation. */
+extern "C" int ksg_red_open(ksg_ctx c) {
+  if (!c) KSG_FAIL(KSG_ERR_ARG, "ksg_red_open: NULL context");
+  if (c->batch_open) KSG_FAIL(KSG_ERR_ARG, "ksg_red_open: a batch of reductions is already open");
+  c->batch_open = 1;
+  c->batch_count = 0;
+  return KSG_OK;
+}
+
+static int red_slot(ksg_ctx c, int count, const char *name, double **d_out, int *offset) {
+  if (!c->batch_open) KSG_FAIL(KSG_ERR_ARG, "%s: no batch of reductions is open", name);
+  if (c->batch_count + count > KSG_RED_MAX) KSG_FAIL(KSG_ERR_UNSUPPORTED, "%s: more than %d values in one batch", name, KSG_RED_MAX);
+  *d_out = c->d_batch + c->batch_count;
+  if (offset) *offset = c->batch_count;
+  c->batch_count += count;
+  return KSG_OK;
+}
+
+extern "C" int ksg_red_post_dotvec(ksg_bv X, const double *y, int *offset) {
+  BV_CHECK(X, "ksg_red_post_dotvec");
+  if (!y) KSG_FAIL(KSG_ERR_ARG, "ksg_red_post_dotvec: NULL vector");
+  KSG_CHK(check_active(X, "ksg_red_post_dotvec"));
+  ksg_ctx c = X->ctx;
+  const int k = X->k - X->l;
+  double *d_out;
+  KSG_CHK(red_slot(c, k, "ksg_red_post_dotvec", &d_out, offset));
+  if (k == 0) return KSG_OK;
+  KSG_CHK(ksg_op_begin(c, KSG_EV_DOTVEC));
+  if (X->n) { KSG_CHK(ksg_launch_dotvec(c, bv_col(X, X->l), X->ld, k, y, X->n, d_out)); }
+  else KSG_HIP(hipMemsetAsync(d_out, 0, (size_t)k * sizeof(double), c->stream));
+  return ksg_op_end(c, KSG_EV_DOTVEC, 8.0 * (double)X->n * (k + 1), 2.0 * (double)X->n * k);
+}
+
+extern "C" int ksg_red_post_dot(ksg_ctx c, const double *x, const double *y, int64_t n, int *offset) {
+  if (!c || n < 0 || (n && (!x || !y))) KSG_FAIL(KSG_ERR_ARG, "ksg_red_post_dot: bad arguments");
+  double *d_out;
+  KSG_CHK(red_slot(c, 1, "ksg_red_post_dot", &d_out, offset));
+  KSG_CHK(ksg_op_begin(c, KSG_EV_VECOPS));
+  if (n) { KSG_CHK(ksg_launch_dotvec(c, x, 2, 1, y, n, d_out)); }
+  else KSG_HIP(hipMemsetAsync(d_out, 0, sizeof(double), c->stream));
+  return ksg_op_end(c, KSG_EV_VECOPS, (x == y ? 8.0 : 16.0) * (double)n, 2.0 * (double)n);
+}
+
+extern "C" int ksg_red_close(ksg_ctx c, double *out_host, int count) {
+  if (!c) KSG_FAIL(KSG_ERR_ARG, "ksg_red_close: NULL context");
+  if (!c->batch_open) KSG_FAIL(KSG_ERR_ARG, "ksg_red_close: no batch of reductions is open");
+  if (count < 0) { c->batch_open = 0; return KSG_OK; }      /* abandon: the values posted are dropped */
+  if (count != c->batch_count) KSG_FAIL(KSG_ERR_ARG, "ksg_red_close: %d values asked for, %d posted", count, c->batch_count);
+  c->batch_open = 0;
+  if (!count) return KSG_OK;
+  if (!out_host) KSG_FAIL(KSG_ERR_ARG, "ksg_red_close: NULL output");
+  KSG_HIP(hipSetDevice(c->device));
+  return ksg_comm_allreduce(c, c->d_batch, out_host, count, 0);
+}
+
 /* Applies the deferred update on its own.  The values written are bit for bit the ones
  * whose products ksg_spec holds: same kernel, same column groups, same order of sums. */
 static int apply_pending(ksg_ctx c, const ksg_pending &pd, double post) {

@@ -50,6 +50,8 @@ extern "C" int ksg_ctx_create(int device, ksg_ctx *out) {
   KSG_HIP(hipMalloc(&c->d_red, KSG_RED_MAX * sizeof(double)));
   KSG_HIP(hipHostMalloc(&c->h_red, KSG_RED_MAX * sizeof(double), hipHostMallocDefault));
   KSG_HIP(hipMalloc(&c->d_spec, (KSG_QMAX + 1) * sizeof(double)));
+  KSG_HIP(hipMalloc(&c->d_batch, KSG_RED_MAX * sizeof(double)));
+  c->batch_open = 0; c->batch_count = 0;
   *out = c;
   return KSG_OK;
 }
@@ -101,6 +103,7 @@ extern "C" int ksg_ctx_destroy(ksg_ctx c) {
   if (c->h_q) hipHostFree(c->h_q);
   hipFree(c->d_red);
   hipFree(c->d_spec);
+  hipFree(c->d_batch);
   hipHostFree(c->h_red);
   hipEventDestroy(c->ev_x_ready);
   hipEventDestroy(c->ev_halo_done);

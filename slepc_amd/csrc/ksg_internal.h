@@ -68,6 +68,8 @@ struct ksg_ctx_s {
   double *h_q;               /* pinned staging of the small host matrices */
   size_t hq_cap;
   double *d_spec;            /* KSG_QMAX+1 doubles: reduction left by a fused multvec */
+  double *d_batch;           /* KSG_RED_MAX doubles: results of posted reductions awaiting one all-reduce */
+  int batch_open, batch_count;
   ksg_spec spec;
   uint64_t gen;              /* bumped by every operation that may write device data */
   int fuse_dots;             /* 0 disables the fused reduction (ksg_ctx_set_option) */

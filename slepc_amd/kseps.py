@@ -62,7 +62,10 @@ class VecOps(C.Structure):
                 ("norm2", C.CFUNCTYPE(Err, VecP, c_dp)),
                 ("fillhash", C.CFUNCTYPE(Err, VecP, C.c_uint64)),
                 ("tohost", C.CFUNCTYPE(Err, VecP, c_dp)),
-                ("fromhost", C.CFUNCTYPE(Err, VecP, c_dp))]
+                ("fromhost", C.CFUNCTYPE(Err, VecP, c_dp)),
+                ("redopen", C.CFUNCTYPE(Err, C.c_void_p)),
+                ("dotpost", C.CFUNCTYPE(Err, VecP, VecP, C.POINTER(C.c_int))),
+                ("redclose", C.CFUNCTYPE(Err, C.c_void_p, c_dp, C.c_int))]
 
 
 VecStruct._fields_ = [("ops", C.POINTER(VecOps)), ("n", c_i64), ("N", c_i64), ("row0", c_i64),
@@ -114,7 +117,8 @@ class BVOps(C.Structure):
                 ("resize", C.CFUNCTYPE(Err, BVP, C.c_int, C.c_int)),
                 ("getcolumn", C.CFUNCTYPE(Err, BVP, C.c_int, C.POINTER(VecP))),
                 ("restorecolumn", C.CFUNCTYPE(Err, BVP, C.c_int, C.POINTER(VecP))),
-                ("destroy", C.CFUNCTYPE(Err, BVP))]
+                ("destroy", C.CFUNCTYPE(Err, BVP)),
+                ("dotvec_post", C.CFUNCTYPE(Err, BVP, VecP, C.POINTER(C.c_int)))]
 
 
 BVStruct._fields_ = [("ops", BVOps), ("type_name", C.c_char * 32), ("t", VecP), ("n", c_i64),
@@ -194,6 +198,12 @@ SIGNATURES = {
     "BVDot": (Err, [BVP, BVP, c_dp, C.c_int]),
     "BVDotVec": (Err, [BVP, VecP, c_dp]),
     "BVDotColumn": (Err, [BVP, C.c_int, c_dp]),
+    "BVDotVecBegin": (Err, [BVP, VecP, c_dp]), "BVDotVecEnd": (Err, [BVP, VecP, c_dp]),
+    "BVDotColumnBegin": (Err, [BVP, C.c_int, c_dp]), "BVDotColumnEnd": (Err, [BVP, C.c_int, c_dp]),
+    "BVNormVecBegin": (Err, [BVP, VecP, C.c_int, c_dp]), "BVNormVecEnd": (Err, [BVP, VecP, C.c_int, c_dp]),
+    "BVNormColumnBegin": (Err, [BVP, C.c_int, C.c_int, c_dp]), "BVNormColumnEnd": (Err, [BVP, C.c_int, C.c_int, c_dp]),
+    "VecDotBegin": (Err, [VecP, VecP, c_dp]), "VecDotEnd": (Err, [VecP, VecP, c_dp]),
+    "VecNormBegin": (Err, [VecP, C.c_int, c_dp]), "VecNormEnd": (Err, [VecP, C.c_int, c_dp]),
     "BVScale": (Err, [BVP, C.c_double]),
     "BVScaleColumn": (Err, [BVP, C.c_int, C.c_double]),
     "BVNorm": (Err, [BVP, C.c_int, c_dp]),

@@ -92,6 +92,10 @@ SIGNATURES = {
     "ksg_mat_col_sizes": (C.c_int, [C.c_void_p, C.POINTER(c_i64), C.POINTER(c_i64), C.POINTER(c_i64)]),
     "ksg_mat_get_csr": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "ksg_mat_transpose": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
+    "ksg_red_open": (C.c_int, [C.c_void_p]),
+    "ksg_red_post_dotvec": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]),
+    "ksg_red_post_dot": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, c_i64, C.POINTER(C.c_int)]),
+    "ksg_red_close": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.c_int]),
     "ksg_mat_mult": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "ksg_mat_residual_norm": (C.c_int, [C.c_void_p, C.c_double, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p,
                                         C.POINTER(C.c_double)]),

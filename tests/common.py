@@ -222,6 +222,56 @@ def run_bv_test4(be, trans=False):
     be.destroy_bv(Y)
 
 
+def run_split_phase(be, n=1000, m=7):
+    """A group of split-phase reductions (BVDotVecBegin/End, BVDotColumnBegin/End,
+    BVNormColumnBegin/End, BVNormVecBegin/End, VecDotBegin/End, VecNormBegin/End:
+    bvglobal.c:190-310, 732-830) delivers what the immediate calls deliver, to every
+    destination, whatever the order of the End calls; a second group starts clean."""
+    lib = be.lib
+    rng = np.random.default_rng(5)
+    A = rng.standard_normal((n, m))
+    X = be.bv(n, m)
+    for j in range(m):
+        be.set_col(X, j, A[:, j])
+    y = be.vec(n)
+    yh = rng.standard_normal(n)
+    K.check(lib.VecSetValuesHost(y.p, dp(yh)))
+    for rep in range(2):
+        K.check(lib.BVSetActiveColumns(X, 1, m - 1 - rep))
+        k = m - 2 - rep
+        ref_dv, ref_dc = np.zeros(k), np.zeros(3)
+        ref_nc, ref_nv, ref_d, ref_n = (C.c_double() for _ in range(4))
+        K.check(lib.BVDotVec(X, y.p, dp(ref_dv)))
+        K.check(lib.BVNormColumn(X, 2, K.NORM_2, C.byref(ref_nc)))
+        K.check(lib.BVNormVec(X, y.p, K.NORM_2, C.byref(ref_nv)))
+        K.check(lib.VecDot(y.p, y.p, C.byref(ref_d)))
+        K.check(lib.VecNorm(y.p, K.NORM_2, C.byref(ref_n)))
+        K.check(lib.BVDotColumn(X, 4, dp(ref_dc)))
+        dv, dc = np.full(k, np.nan), np.full(3, np.nan)
+        nc, nv, d, nn = (C.c_double(float("nan")) for _ in range(4))
+        K.check(lib.BVDotVecBegin(X, y.p, dp(dv)))
+        K.check(lib.BVNormColumnBegin(X, 2, K.NORM_2, C.byref(nc)))
+        K.check(lib.BVNormVecBegin(X, y.p, K.NORM_2, C.byref(nv)))
+        K.check(lib.VecDotBegin(y.p, y.p, C.byref(d)))
+        K.check(lib.VecNormBegin(y.p, K.NORM_2, C.byref(nn)))
+        K.check(lib.BVDotColumnBegin(X, 4, dp(dc)))
+        K.check(lib.VecNormEnd(y.p, K.NORM_2, C.byref(nn)))
+        K.check(lib.BVDotVecEnd(X, y.p, dp(dv)))
+        K.check(lib.BVNormColumnEnd(X, 2, K.NORM_2, C.byref(nc)))
+        K.check(lib.BVNormVecEnd(X, y.p, K.NORM_2, C.byref(nv)))
+        K.check(lib.VecDotEnd(y.p, y.p, C.byref(d)))
+        K.check(lib.BVDotColumnEnd(X, 4, dp(dc)))
+        assert np.array_equal(dv, ref_dv) and np.array_equal(dc, ref_dc)
+        assert d.value == ref_d.value
+        for got, ref in ((nc, ref_nc), (nv, ref_nv), (nn, ref_n)):
+            assert abs(got.value - ref.value) <= 4 * np.finfo(float).eps * ref.value
+        assert np.allclose(dv, A[:, 1:1 + k].T @ yh, rtol=1e-12, atol=1e-12)
+        assert np.allclose(dc, A[:, 1:4].T @ A[:, 4], rtol=1e-12, atol=1e-12)
+        assert np.isclose(nc.value, np.linalg.norm(A[:, 2]), rtol=1e-14)
+    y.destroy()
+    be.destroy_bv(X)
+
+
 def run_bv_test13(be):
     """bv/examples/tests/test13.c (q == NULL: coefficients in the BV buffer)."""
     g = golden("bv_misc.json")

@@ -418,3 +418,49 @@ def test_empty_local_block(gpu_ctx):
     W.mult(1.0, 0.0, G, np.asfortranarray(np.eye(5)))
     G.destroy()
     W.destroy()
+
+
+def test_posted_reductions(gpu_ctx):
+    """One batch of posted reductions (the device side of BVDotVecBegin/End and
+    VecDotBegin/End, bvglobal.c:190-310): the values arrive in posting order and are the
+    ones the immediate calls return, bit for bit; counts are checked; an abandoned batch
+    leaves the context usable."""
+    import ctypes as C
+    from slepc_amd import ksgpu
+    lib = ksgpu.load()
+    n, m = 50021, 12
+    G, O, rng = _mk(gpu_ctx, n, m, seed=9)
+    y = rng.standard_normal(n)
+    yd = gpu_ctx.vec_alloc(n)
+    gpu_ctx.upload(yd, y)
+    G.set_active(2, 11)
+    ref1 = G.dotvec(yd)
+    ref2 = gpu_ctx.vec_dot(yd, yd, n)
+    G.set_active(0, 5)
+    ref3 = G.dotvec(G.column(7))
+    off = [C.c_int(-1) for _ in range(3)]
+    ksgpu.check(lib.ksg_red_open(gpu_ctx.h))
+    G.set_active(2, 11)
+    ksgpu.check(lib.ksg_red_post_dotvec(G.h, yd, C.byref(off[0])))
+    ksgpu.check(lib.ksg_red_post_dot(gpu_ctx.h, yd, yd, n, C.byref(off[1])))
+    G.set_active(0, 5)
+    ksgpu.check(lib.ksg_red_post_dotvec(G.h, G.column(7), C.byref(off[2])))
+    assert [o.value for o in off] == [0, 9, 10]
+    out = (C.c_double * 15)()
+    assert lib.ksg_red_close(gpu_ctx.h, out, 14) != 0          # 15 were posted; the batch stays open
+    ksgpu.check(lib.ksg_red_close(gpu_ctx.h, out, 15))
+    got = np.array(out[:])
+    assert np.array_equal(got[:9], ref1) and got[9] == ref2 and np.array_equal(got[10:], ref3)
+    assert lib.ksg_red_close(gpu_ctx.h, out, 0) != 0           # nothing open
+    assert lib.ksg_red_post_dot(gpu_ctx.h, yd, yd, n, None) != 0
+    # abandoned batch, then a fresh one
+    ksgpu.check(lib.ksg_red_open(gpu_ctx.h))
+    assert lib.ksg_red_open(gpu_ctx.h) != 0
+    ksgpu.check(lib.ksg_red_post_dot(gpu_ctx.h, yd, yd, n, None))
+    ksgpu.check(lib.ksg_red_close(gpu_ctx.h, None, -1))
+    ksgpu.check(lib.ksg_red_open(gpu_ctx.h))
+    ksgpu.check(lib.ksg_red_post_dot(gpu_ctx.h, yd, yd, n, C.byref(off[0])))
+    ksgpu.check(lib.ksg_red_close(gpu_ctx.h, out, 1))
+    assert off[0].value == 0 and out[0] == ref2
+    gpu_ctx.vec_free(yd)
+    G.destroy()

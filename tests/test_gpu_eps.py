@@ -47,6 +47,11 @@ def test_bv_test13(be):
     common.run_bv_test13(be)
 
 
+def test_split_phase_reductions(be):
+    common.run_split_phase(be)
+    common.run_split_phase(be, n=37, m=6)
+
+
 def _fmt(vals, k, fmt="%.5f"):
     return [fmt % v[0] for v in vals[:k]]
 

@@ -188,6 +188,11 @@ def test_bv_test13(be):
     common.run_bv_test13(be)
 
 
+def test_split_phase_reductions(be):
+    common.run_split_phase(be)
+    common.run_split_phase(be, n=37, m=6)
+
+
 def test_bv_column_view_rules(be):
     """bvbasic.c:1152-1224: at most two outstanding columns, same Vec restored."""
     bv = be.bv(12, 4)
