@@ -261,10 +261,13 @@ PetscErrorCode BVMultInPlaceTranspose(BV V, const PetscScalar *Q, PetscInt ldq, 
 PetscErrorCode BVDot(BV X, BV Y, PetscScalar *M, PetscInt ldm);
 PetscErrorCode BVDotVec(BV X, Vec y, PetscScalar *q);
 PetscErrorCode BVDotColumn(BV X, PetscInt j, PetscScalar *q);
-/* Split-phase reductions (bvglobal.c:190-310,732-830; VecDotBegin/End of PETSc): all the
- * ...Begin calls of a group first, then the ...End calls in the same order; the first End
- * completes the whole group with one reduction round.  Types without the optional post ops
- * compute at Begin. */
+/* Split-phase reductions (bvglobal.c:190-310,361-470,732-830; VecDotBegin/End of PETSc): all
+ * the ...Begin calls of a group first, then the matching ...End calls in the same order, each
+ * with the object (and, for a BV, the active columns) of its Begin; the result is written to
+ * the array given to the End.  The first End completes the whole group with one reduction
+ * round.  PETSC_ERR_ORDER: a Begin after an End of an unfinished group;
+ * PETSC_ERR_ARG_WRONGSTATE: an End out of order or without Begin (the group is dropped).
+ * Types without the optional post ops compute at Begin and deliver at End. */
 PetscErrorCode BVDotVecBegin(BV X, Vec y, PetscScalar *m);
 PetscErrorCode BVDotVecEnd(BV X, Vec y, PetscScalar *m);
 PetscErrorCode BVDotColumnBegin(BV X, PetscInt j, PetscScalar *m);

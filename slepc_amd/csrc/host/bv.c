@@ -379,21 +379,32 @@ PetscErrorCode BVDotVec(BV X, Vec y, PetscScalar *q) {
 /* ---- split phase (bvglobal.c:190-310, 732-830) -------------------------------------------- */
 PetscErrorCode BVDotVecBegin(BV X, Vec y, PetscScalar *m) {
   PetscErrorCode ierr;
-  PetscBool batched = PETSC_FALSE;
+  PetscScalar *vals;
   PetscInt off;
+  (void)m;
   BVCheckSizes(X);
   if (!y) SETERRQ(PETSC_ERR_ARG_NULL, "Null vector");
   if (X->n != y->n) SETERRQ(PETSC_ERR_ARG_INCOMP, "Mismatching local dimension X %lld, y %lld", (long long)X->n, (long long)y->n);
-  if (!m) { ierr = BVGetBuffer(X, &m, NULL);CHKERRQ(ierr); }
-  if (X->ops.dotvec_post) { ierr = KSRedJoin_Private(y->ops, y->ctx, &batched);CHKERRQ(ierr); }
-  if (!batched) { ierr = X->ops.dotvec(X, y, m);CHKERRQ(ierr); return 0; }
-  ierr = X->ops.dotvec_post(X, y, &off);
+  ierr = KSRedBegin_Private(X, X->ops.dotvec_post ? y->ops : NULL, y->ctx, X->k - X->l, 0, &vals);CHKERRQ(ierr);
+  if (vals) ierr = X->ops.dotvec(X, y, vals);
+  else {
+    ierr = X->ops.dotvec_post(X, y, &off);
+    if (!ierr) KSRedPosted_Private(off);
+  }
   if (ierr) { KSRedAbandon_Private();CHKERRQ(ierr); }
-  KSRedRecord_Private(m, X->k - X->l, off, 0);
   return 0;
 }
-PetscErrorCode BVDotVecEnd(BV X, Vec y, PetscScalar *m) { (void)X; (void)y; (void)m; return KSRedComplete_Private(); }
 
+/* X must have the active columns it had at the Begin */
+PetscErrorCode BVDotVecEnd(BV X, Vec y, PetscScalar *m) {
+  PetscErrorCode ierr;
+  (void)y;
+  BVCheckSizes(X);
+  if (!m) { ierr = BVGetBuffer(X, &m, NULL);CHKERRQ(ierr); }
+  return KSRedEnd_Private(X, X->k - X->l, m);
+}
+
+/* bvglobal.c:361-470: the products of column j with columns l..j-1 */
 PetscErrorCode BVDotColumnBegin(BV X, PetscInt j, PetscScalar *m) {
   PetscErrorCode ierr;
   PetscInt ksave;
@@ -404,27 +415,53 @@ PetscErrorCode BVDotColumnBegin(BV X, PetscInt j, PetscScalar *m) {
   ksave = X->k;
   X->k = j;
   ierr = BVGetColumn(X, j, &y);
-  if (!ierr) ierr = BVDotVecBegin(X, y, m);
-  if (!ierr) ierr = BVRestoreColumn(X, j, &y);
+  if (!ierr) {
+    ierr = BVDotVecBegin(X, y, m);
+    { const PetscErrorCode ierr2 = BVRestoreColumn(X, j, &y); if (!ierr) ierr = ierr2; }
+  }
   X->k = ksave;
   CHKERRQ(ierr);
   return 0;
 }
-PetscErrorCode BVDotColumnEnd(BV X, PetscInt j, PetscScalar *m) { (void)X; (void)j; (void)m; return KSRedComplete_Private(); }
+PetscErrorCode BVDotColumnEnd(BV X, PetscInt j, PetscScalar *m) {
+  PetscErrorCode ierr;
+  PetscInt ksave;
+  BVCheckSizes(X);
+  if (j < 0 || j >= X->m) SETERRQ(PETSC_ERR_ARG_OUTOFRANGE, "Index j=%d out of range", j);
+  ksave = X->k;
+  X->k = j;
+  ierr = BVDotVecEnd(X, NULL, m);
+  X->k = ksave;
+  CHKERRQ(ierr);
+  return 0;
+}
 
+/* bvglobal.c:732-830; the entries belong to the vector, as in VecNormBegin/End */
 PetscErrorCode BVNormVecBegin(BV bv, Vec v, NormType type, PetscReal *val) { (void)bv; return VecNormBegin(v, type, val); }
 PetscErrorCode BVNormVecEnd(BV bv, Vec v, NormType type, PetscReal *val) { (void)bv; return VecNormEnd(v, type, val); }
+
+/* the entry is keyed by the storage of column j: a column view is the same Vec object for
+ * different columns */
 PetscErrorCode BVNormColumnBegin(BV bv, PetscInt j, NormType type, PetscReal *val) {
   PetscErrorCode ierr;
   Vec v;
   BVCheckSizes(bv);
   ierr = BVGetColumn(bv, j, &v);CHKERRQ(ierr);
   ierr = VecNormBegin(v, type, val);
-  if (!ierr) ierr = BVRestoreColumn(bv, j, &v);
+  { const PetscErrorCode ierr2 = BVRestoreColumn(bv, j, &v); if (!ierr) ierr = ierr2; }
   CHKERRQ(ierr);
   return 0;
 }
-PetscErrorCode BVNormColumnEnd(BV bv, PetscInt j, NormType type, PetscReal *val) { (void)bv; (void)j; (void)type; (void)val; return KSRedComplete_Private(); }
+PetscErrorCode BVNormColumnEnd(BV bv, PetscInt j, NormType type, PetscReal *val) {
+  PetscErrorCode ierr;
+  Vec v;
+  BVCheckSizes(bv);
+  ierr = BVGetColumn(bv, j, &v);CHKERRQ(ierr);
+  ierr = VecNormEnd(v, type, val);
+  { const PetscErrorCode ierr2 = BVRestoreColumn(bv, j, &v); if (!ierr) ierr = ierr2; }
+  CHKERRQ(ierr);
+  return 0;
+}
 
 PetscErrorCode BVDotColumn(BV X, PetscInt j, PetscScalar *q) {
   PetscErrorCode ierr;

@@ -360,13 +360,13 @@ static PetscErrorCode EPSDelayedArnoldi(EPS eps, PetscScalar *H, PetscInt ldh, P
       DCHK(BVDotColumnBegin(eps->V, j, lhh));
       DCHK(BVGetColumn(eps->V, j, &vj));
       DCHK(VecDotBegin(vj, vj, &dot));
-      DCHK(BVRestoreColumn(eps->V, j, &vj));
     }
     if (j > k + 1) DCHK(BVNormVecBegin(eps->V, u, NORM_2, &norm2));
     DCHK(BVDotColumnEnd(eps->V, j + 1, H + (size_t)ldh * j));
     if (j > k) {
       DCHK(BVDotColumnEnd(eps->V, j, lhh));
-      DCHK(VecDotEnd(NULL, NULL, &dot));
+      DCHK(VecDotEnd(vj, vj, &dot));
+      DCHK(BVRestoreColumn(eps->V, j, &vj));
     }
     if (j > k + 1) DCHK(BVNormVecEnd(eps->V, u, NORM_2, &norm2));
 
@@ -427,11 +427,11 @@ static PetscErrorCode EPSDelayedArnoldi1(EPS eps, PetscScalar *H, PetscInt ldh, 
     if (j > k) {
       ierr = BVGetColumn(eps->V, j, &vj);CHKERRQ(ierr);
       ierr = VecDotBegin(vj, vj, &dot);CHKERRQ(ierr);
-      ierr = BVRestoreColumn(eps->V, j, &vj);CHKERRQ(ierr);
     }
     ierr = BVDotColumnEnd(eps->V, j + 1, H + (size_t)ldh * j);CHKERRQ(ierr);
     if (j > k) {
-      ierr = VecDotEnd(NULL, NULL, &dot);CHKERRQ(ierr);
+      ierr = VecDotEnd(vj, vj, &dot);CHKERRQ(ierr);
+      ierr = BVRestoreColumn(eps->V, j, &vj);CHKERRQ(ierr);
       norm = sqrt(dot);
       ierr = BVScaleColumn(eps->V, j, 1.0 / norm);CHKERRQ(ierr);
       H[(size_t)ldh * (j - 1) + j] = norm;

@@ -18,9 +18,9 @@ void KSErrorTrace(const char *func, int line);
 #define CHKKSG(call) do { int rc_ = (call); if (rc_) return KSError(__func__, __LINE__, PETSC_ERR_LIB, "libksgpu: %s", ksg_last_error()); } while (0)
 
 /* split-phase reductions (vec.c) */
-PetscErrorCode KSRedJoin_Private(const struct _VecOps *ops, void *ctx, PetscBool *batched);
-void KSRedRecord_Private(PetscScalar *dst, PetscInt count, PetscInt offset, int root);
-PetscErrorCode KSRedComplete_Private(void);
+PetscErrorCode KSRedBegin_Private(const void *owner, const struct _VecOps *ops, void *ctx, PetscInt count, int root, PetscScalar **vals);
+void KSRedPosted_Private(PetscInt dev_off);
+PetscErrorCode KSRedEnd_Private(const void *owner, PetscInt count, PetscScalar *out);
 void KSRedAbandon_Private(void);
 
 #define PETSC_MACHINE_EPSILON 2.2204460492503131e-16

@@ -150,87 +150,119 @@ PetscErrorCode VecFillHash(Vec x, uint64_t seed) {
 }
 
 /* ---- split-phase reductions -------------------------------------------------------------
- * One group at a time: the ...Begin calls queue their reductions in the back end (or compute
- * at once when the type has no post ops), the first ...End closes the group -- one reduction
- * round -- and hands every queued value to its destination. */
+ * The role of PetscSplitReduction (bvglobal.c:227-241, 276-290): one group at a time.  Every
+ * ...Begin appends an entry; on a back end with the post ops its kernel is queued on the
+ * device, otherwise the value is computed at once and parked here.  The first ...End
+ * completes the group -- one reduction round and one copy for all queued kernels --, and each
+ * End hands out the entry it is paired with, in the order of the Begins. */
 #define KS_RED_MAXENTRIES 64
+#define KS_RED_MAXVALUES  8192
 static struct {
-  const struct _VecOps *ops; void *ctx; int open, n; PetscInt total;
-  struct { PetscScalar *dst; PetscInt count, offset; int root; } e[KS_RED_MAXENTRIES];
+  const struct _VecOps *ops; void *ctx;            /* back end with a batch open (NULL: none) */
+  int state;                                       /* 0: collecting Begins, 1: handing out at Ends */
+  int n, nend; PetscInt nvals, nposted;
+  struct { const void *owner; PetscInt count, off, dev_off; int root; } e[KS_RED_MAXENTRIES];
+  PetscScalar vals[KS_RED_MAXVALUES];
 } ks_red;
 
-/* opens the group on (ops, ctx) if need be; *batched = whether the back end queues */
-PetscErrorCode KSRedJoin_Private(const struct _VecOps *ops, void *ctx, PetscBool *batched) {
+static void KSRedReset(void) { ks_red.ops = NULL; ks_red.ctx = NULL; ks_red.state = 0; ks_red.n = ks_red.nend = 0; ks_red.nvals = ks_red.nposted = 0; }
+
+/* drops the group (after a failure), so that the next one starts clean */
+void KSRedAbandon_Private(void) {
+  if (ks_red.ops) (void)ks_red.ops->redclose(ks_red.ctx, NULL, -1);
+  KSRedReset();
+}
+
+/* Appends an entry of `count` values for `owner`.  With the post ops of (ops, ctx) present the
+ * batch of the back end is opened if need be and *vals = NULL: the caller posts its kernel and
+ * reports the index it got with KSRedPosted_Private.  Otherwise *vals is where the caller
+ * stores the values it computes now. */
+PetscErrorCode KSRedBegin_Private(const void *owner, const struct _VecOps *ops, void *ctx, PetscInt count, int root, PetscScalar **vals) {
   PetscErrorCode ierr;
-  *batched = PETSC_FALSE;
-  if (!ops || !ops->redopen || !ops->dotpost || !ops->redclose) return 0;
-  if (ks_red.open && (ks_red.ops != ops || ks_red.ctx != ctx)) SETERRQ(PETSC_ERR_ORDER, "A group of split-phase reductions is open on another context");
-  if (!ks_red.open) {
-    ierr = ops->redopen(ctx);CHKERRQ(ierr);
-    ks_red.ops = ops; ks_red.ctx = ctx; ks_red.open = 1; ks_red.n = 0; ks_red.total = 0;
+  const int batched = ops && ops->redopen && ops->dotpost && ops->redclose;
+  if (ks_red.state != 0) SETERRQ(PETSC_ERR_ORDER, "Called before all VecxxxEnd() called");
+  if (ks_red.n >= KS_RED_MAXENTRIES || ks_red.nvals + count > KS_RED_MAXVALUES) SETERRQ(PETSC_ERR_SUP, "Too many reductions in one group");
+  if (batched) {
+    if (ks_red.ops && (ks_red.ops != ops || ks_red.ctx != ctx)) SETERRQ(PETSC_ERR_ARG_INCOMP, "Split-phase reductions of one group must live on one context");
+    if (!ks_red.ops) { ierr = ops->redopen(ctx);CHKERRQ(ierr); ks_red.ops = ops; ks_red.ctx = ctx; }
   }
-  if (ks_red.n >= KS_RED_MAXENTRIES) SETERRQ(PETSC_ERR_SUP, "Too many reductions in one group");
-  *batched = PETSC_TRUE;
+  ks_red.e[ks_red.n].owner = owner; ks_red.e[ks_red.n].count = count; ks_red.e[ks_red.n].off = ks_red.nvals;
+  ks_red.e[ks_red.n].dev_off = -1; ks_red.e[ks_red.n].root = root;
+  *vals = batched ? NULL : ks_red.vals + ks_red.nvals;
+  ks_red.nvals += count;
+  ks_red.n++;
   return 0;
 }
 
-/* records where the `count` values posted at `offset` go (root: deliver the square root) */
-void KSRedRecord_Private(PetscScalar *dst, PetscInt count, PetscInt offset, int root) {
-  ks_red.e[ks_red.n].dst = dst; ks_red.e[ks_red.n].count = count; ks_red.e[ks_red.n].offset = offset; ks_red.e[ks_red.n].root = root;
-  ks_red.n++;
-  if (offset + count > ks_red.total) ks_red.total = offset + count;
+void KSRedPosted_Private(PetscInt dev_off) {
+  ks_red.e[ks_red.n - 1].dev_off = dev_off;
+  if (dev_off + ks_red.e[ks_red.n - 1].count > ks_red.nposted) ks_red.nposted = dev_off + ks_red.e[ks_red.n - 1].count;
 }
 
-/* drops the open group after a failed post, so that the next group starts clean */
-void KSRedAbandon_Private(void) {
-  if (!ks_red.open) return;
-  ks_red.open = 0;
-  (void)ks_red.ops->redclose(ks_red.ctx, NULL, -1);
-}
-
-PetscErrorCode KSRedComplete_Private(void) {
+/* Hands the next entry to its End: `owner` and `count` must be the ones of the matching Begin */
+PetscErrorCode KSRedEnd_Private(const void *owner, PetscInt count, PetscScalar *out) {
   PetscErrorCode ierr;
-  if (!ks_red.open) return 0;
-  ks_red.open = 0;
-  PetscScalar *out = (PetscScalar *)malloc((size_t)PetscMax(ks_red.total, 1) * sizeof(*out));
-  if (!out) SETERRQ(PETSC_ERR_MEM, "Out of memory");
-  ierr = ks_red.ops->redclose(ks_red.ctx, out, ks_red.total);
-  if (!ierr) for (int i = 0; i < ks_red.n; i++)
-    for (PetscInt j = 0; j < ks_red.e[i].count; j++) {
-      const PetscScalar v = out[ks_red.e[i].offset + j];
-      ks_red.e[i].dst[j] = ks_red.e[i].root ? sqrt(v) : v;
+  if (ks_red.state == 0) {                       /* first End of the group: complete it */
+    if (ks_red.ops) {
+      PetscScalar *dev = (PetscScalar *)malloc((size_t)PetscMax(ks_red.nposted, 1) * sizeof(*dev));
+      if (!dev) { KSRedAbandon_Private(); SETERRQ(PETSC_ERR_MEM, "Out of memory"); }
+      ierr = ks_red.ops->redclose(ks_red.ctx, dev, ks_red.nposted);
+      if (ierr) { free(dev); KSRedAbandon_Private();CHKERRQ(ierr); }
+      for (int i = 0; i < ks_red.n; i++)
+        if (ks_red.e[i].dev_off >= 0) memcpy(ks_red.vals + ks_red.e[i].off, dev + ks_red.e[i].dev_off, (size_t)ks_red.e[i].count * sizeof(*dev));
+      free(dev);
+      ks_red.ops = NULL; ks_red.ctx = NULL;
     }
-  free(out);
-  CHKERRQ(ierr);
+    ks_red.state = 1;
+  }
+  if (ks_red.nend >= ks_red.n) { KSRedReset(); SETERRQ(PETSC_ERR_ARG_WRONGSTATE, "Called VecxxxEnd() more times than VecxxxBegin()"); }
+  if (ks_red.e[ks_red.nend].owner != owner || ks_red.e[ks_red.nend].count != count) {
+    KSRedReset();
+    SETERRQ(PETSC_ERR_ARG_WRONGSTATE, "Called xxxEnd() in a different order or with a different object than xxxBegin()");
+  }
+  for (PetscInt j = 0; j < count; j++) {
+    const PetscScalar v = ks_red.vals[ks_red.e[ks_red.nend].off + j];
+    out[j] = ks_red.e[ks_red.nend].root ? sqrt(v) : v;
+  }
+  if (++ks_red.nend == ks_red.n) KSRedReset();    /* all handed out: no outstanding requests */
+  return 0;
+}
+
+static PetscErrorCode VecDotBegin_Private(Vec x, Vec y, int root) {
+  PetscErrorCode ierr;
+  PetscScalar *vals;
+  PetscInt off;
+  ierr = KSRedBegin_Private(x, x->ops, x->ctx, 1, root, &vals);CHKERRQ(ierr);
+  if (vals) ierr = VecDot(x, y, vals);
+  else {
+    ierr = x->ops->dotpost(x, y, &off);
+    if (!ierr) KSRedPosted_Private(off);
+  }
+  if (ierr) { KSRedAbandon_Private();CHKERRQ(ierr); }
   return 0;
 }
 
 PetscErrorCode VecDotBegin(Vec x, Vec y, PetscScalar *r) {
-  PetscErrorCode ierr;
-  PetscBool batched;
-  PetscInt off;
-  if (!x || !y || !r) SETERRQ(PETSC_ERR_ARG_NULL, "Null argument");
+  (void)r;
+  if (!x || !y) SETERRQ(PETSC_ERR_ARG_NULL, "Null argument");
   if (x->n != y->n) SETERRQ(PETSC_ERR_ARG_INCOMP, "Incompatible vector local lengths");
-  ierr = KSRedJoin_Private(x->ops, x->ctx, &batched);CHKERRQ(ierr);
-  if (!batched) return VecDot(x, y, r);
-  ierr = x->ops->dotpost(x, y, &off);
-  if (ierr) { KSRedAbandon_Private();CHKERRQ(ierr); }
-  KSRedRecord_Private(r, 1, off, 0);
-  return 0;
+  return VecDotBegin_Private(x, y, 0);
 }
-PetscErrorCode VecDotEnd(Vec x, Vec y, PetscScalar *r) { (void)x; (void)y; (void)r; return KSRedComplete_Private(); }
-
-PetscErrorCode VecNormBegin(Vec x, NormType type, PetscReal *r) {
-  PetscErrorCode ierr;
-  PetscBool batched;
-  PetscInt off;
+PetscErrorCode VecDotEnd(Vec x, Vec y, PetscScalar *r) {
+  (void)y;
   if (!x || !r) SETERRQ(PETSC_ERR_ARG_NULL, "Null argument");
-  if (type != NORM_2 && type != NORM_FROBENIUS) SETERRQ(PETSC_ERR_SUP, "Only the 2-norm is available in split phase");
-  ierr = KSRedJoin_Private(x->ops, x->ctx, &batched);CHKERRQ(ierr);
-  if (!batched) return VecNorm(x, NORM_2, r);
-  ierr = x->ops->dotpost(x, x, &off);
-  if (ierr) { KSRedAbandon_Private();CHKERRQ(ierr); }
-  KSRedRecord_Private(r, 1, off, 1);
-  return 0;
+  return KSRedEnd_Private(x, 1, r);
 }
-PetscErrorCode VecNormEnd(Vec x, NormType type, PetscReal *r) { (void)x; (void)type; (void)r; return KSRedComplete_Private(); }
+
+/* the sum of squares travels with the group; the root is taken when the value is handed out */
+PetscErrorCode VecNormBegin(Vec x, NormType type, PetscReal *r) {
+  (void)r;
+  if (!x) SETERRQ(PETSC_ERR_ARG_NULL, "Null argument");
+  if (type != NORM_2 && type != NORM_FROBENIUS) SETERRQ(PETSC_ERR_SUP, "Only the 2-norm is available in split phase");
+  return VecDotBegin_Private(x, x, 1);
+}
+PetscErrorCode VecNormEnd(Vec x, NormType type, PetscReal *r) {
+  (void)type;
+  if (!x || !r) SETERRQ(PETSC_ERR_ARG_NULL, "Null argument");
+  return KSRedEnd_Private(x, 1, r);
+}

@@ -255,12 +255,24 @@ def run_split_phase(be, n=1000, m=7):
         K.check(lib.VecDotBegin(y.p, y.p, C.byref(d)))
         K.check(lib.VecNormBegin(y.p, K.NORM_2, C.byref(nn)))
         K.check(lib.BVDotColumnBegin(X, 4, dp(dc)))
-        K.check(lib.VecNormEnd(y.p, K.NORM_2, C.byref(nn)))
+        assert lib.BVNormColumnEnd(X, 2, K.NORM_2, C.byref(nc)) != 0      # not the next in order
+        if rep == 0:        # the failed End dropped the group: post it again
+            K.check(lib.BVDotVecBegin(X, y.p, dp(dv)))
+            K.check(lib.BVNormColumnBegin(X, 2, K.NORM_2, C.byref(nc)))
+            K.check(lib.BVNormVecBegin(X, y.p, K.NORM_2, C.byref(nv)))
+            K.check(lib.VecDotBegin(y.p, y.p, C.byref(d)))
+            K.check(lib.VecNormBegin(y.p, K.NORM_2, C.byref(nn)))
+            K.check(lib.BVDotColumnBegin(X, 4, dp(dc)))
+        else:
+            continue
         K.check(lib.BVDotVecEnd(X, y.p, dp(dv)))
+        assert lib.BVDotVecBegin(X, y.p, dp(dv)) != 0                     # Begin after an End of an unfinished group
         K.check(lib.BVNormColumnEnd(X, 2, K.NORM_2, C.byref(nc)))
         K.check(lib.BVNormVecEnd(X, y.p, K.NORM_2, C.byref(nv)))
         K.check(lib.VecDotEnd(y.p, y.p, C.byref(d)))
+        K.check(lib.VecNormEnd(y.p, K.NORM_2, C.byref(nn)))
         K.check(lib.BVDotColumnEnd(X, 4, dp(dc)))
+        assert lib.VecDotEnd(y.p, y.p, C.byref(d)) != 0                   # more Ends than Begins
         assert np.array_equal(dv, ref_dv) and np.array_equal(dc, ref_dc)
         assert d.value == ref_d.value
         for got, ref in ((nc, ref_nc), (nv, ref_nv), (nn, ref_n)):
