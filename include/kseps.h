@@ -94,6 +94,7 @@ struct _p_Vec {
   PetscScalar *own;         /* storage owned by the vector (NULL for pure views) */
   PetscInt64 state;         /* bumped on every modification */
   void *ctx;                /* back-end context (ksg_ctx for "hip") */
+  PetscInt64 id;            /* unique per object (PetscObjectId): with state, the key of the B*x cache of a BV */
 };
 PetscErrorCode VecCreateHIP(ksg_ctx ctx, PetscInt64 n, PetscInt64 N, PetscInt64 row0, Vec *v);
 PetscErrorCode VecCreateWithOps(const struct _VecOps *ops, void *ctx, PetscInt64 n, PetscInt64 N,
@@ -229,6 +230,14 @@ struct _p_BV {
   void *data;                   /* type-specific (ksg_bv for "hip") */
   void *ctx;
   BVOrthogBlockType orthog_block;   /* method of BVOrthogonalize */
+  /* non-standard inner product <x,y> = y^T B x (bvimpl.h:80-88) */
+  Mat matrix;                   /* B, borrowed: it must outlive the BV (NULL: standard inner product) */
+  PetscBool indef;              /* B is indefinite: signed norms, signature omega */
+  Vec Bx;                       /* B*x of the vector whose id/state are xid/xstate (BV_IPMatMult, bvimpl.h:140-151) */
+  PetscInt64 xid, xstate;
+  BV cached;                    /* B*X of the active columns at state bvstate (BV_IPMatMultBV, bvimpl.h:157-173) */
+  PetscInt64 bvstate;
+  PetscReal *omega;             /* signature, nc+m entries (indefinite case) */
 };
 
 PetscErrorCode BVCreate(void *ctx, BV *bv);
@@ -240,6 +249,27 @@ PetscErrorCode BVSetType(BV bv, const char *type);
 PetscErrorCode BVSetSizesFromVec(BV bv, Vec t, PetscInt m);
 PetscErrorCode BVGetSizes(BV bv, PetscInt64 *n, PetscInt64 *N, PetscInt *m);
 PetscErrorCode BVResize(BV bv, PetscInt m, PetscBool copy);
+/* Constraints (bvfunc.c:414-442, bvbasic.c:262-321): vectors every orthogonalisation also
+ * deflates; stored in front of the columns, reached as columns -nc..-1.  C holds *nc vectors;
+ * linearly dependent ones are dropped and *nc is lowered.  Destroys the contents of V. */
+PetscErrorCode BVInsertConstraints(BV V, PetscInt *nc, Vec *C);
+PetscErrorCode BVSetNumConstraints(BV V, PetscInt nc);
+PetscErrorCode BVGetNumConstraints(BV bv, PetscInt *nc);
+/* Inner product <x,y> = y^T B x (bvbasic.c:481-646).  B is borrowed, not reference counted:
+ * it must outlive the BV.  BVDot, BVDotVec/Column, BVNormVec/Column and every
+ * orthogonalisation then work in that inner product; with indef the norms carry the sign of
+ * x^T B x and the orthogonalisations maintain the signature (bvorthog.c:255-258,352). */
+PetscErrorCode BVSetMatrix(BV bv, Mat B, PetscBool indef);
+PetscErrorCode BVGetMatrix(BV bv, Mat *B, PetscBool *indef);
+PetscErrorCode BVApplyMatrix(BV bv, Vec x, Vec y);
+PetscErrorCode BVApplyMatrixBV(BV X, BV Y);                  /* Y may be NULL: result in the cached BV */
+PetscErrorCode BVGetCachedBV(BV bv, BV *cached);
+/* signature of the active columns 0..k-1 as a host array of k entries (a sequential Vec in
+ * the reference, bvbasic.c:664-729) */
+PetscErrorCode BVSetSignature(BV bv, const PetscReal *omega);
+PetscErrorCode BVGetSignature(BV bv, PetscReal *omega);
+PetscErrorCode BVDuplicate(BV V, BV *W);                     /* bvbasic.c:1432-1485: type, sizes, matrix, orthogonalisation */
+PetscErrorCode BVDuplicateResize(BV V, PetscInt m, BV *W);
 PetscErrorCode BVSetActiveColumns(BV bv, PetscInt l, PetscInt k);
 PetscErrorCode BVGetActiveColumns(BV bv, PetscInt *l, PetscInt *k);
 /* bvorthog.c: eta 0 stands for PETSC_DEFAULT (0.7071) */

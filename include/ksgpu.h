@@ -117,6 +117,10 @@ int ksg_bv_create(ksg_ctx ctx, int64_t n_local, int64_t N, int m, ksg_bv *bv);  
 int ksg_bv_destroy(ksg_bv bv);                                                  /* BVDestroy_Svec svec.c:404 */
 int ksg_bv_resize(ksg_bv bv, int m, int copy);                                  /* BVResize_Svec svec.c:280 */
 int ksg_bv_set_active(ksg_bv bv, int l, int k);
+/* The first nc of the nc+m columns held become constraints with the indices -nc..-1
+ * (BVInsertConstraints bvfunc.c:433-439, BVSetNumConstraints bvbasic.c:276-294, storage
+ * svec.c:41,322: constraints first); m becomes nc_old+m_old-nc.  No data moves. */
+int ksg_bv_set_num_constraints(ksg_bv bv, int nc);
 int ksg_bv_sizes(ksg_bv bv, int64_t *n_local, int64_t *N, int *m, int64_t *ld);
 /* Device address of column j (BVGetColumn_Svec, svec.c:312-324: pv+(nc+j)*n).  Every
  * entry point of this library sees the column up to date; code of the caller that reads

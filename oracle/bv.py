@@ -49,6 +49,13 @@ class BV:
         self.orthog_ref = REFINE_IFNEEDED
         self.orthog_eta = 0.7071
         self.buffer = None
+        # non-standard inner product <x,y> = y^T B x (bvimpl.h:80-88): matvec(x) -> B x on the
+        # local rows, indef = B indefinite, omega = signature (nc+m entries), cached = B*X
+        self.matrix = None
+        self.indef = False
+        self.omega = None
+        self.Bx = None
+        self.cached = None
         # counters used by the byte/flop model of the benchmark
         self.npasses = 0
         self.bytes = 0.0     # algorithmic bytes moved by the op table (same model as the device library)
@@ -70,6 +77,98 @@ class BV:
         if self.buffer is None:
             self.buffer = np.zeros((self.nc + self.m) * self.m)
         return self.buffer
+
+    # ---- inner product matrix, constraints (bvbasic.c:262-321,481-729; bvfunc.c:414-442) ----
+    def set_matrix(self, matvec, indef=False):
+        """``BVSetMatrix`` (bvbasic.c:481-504): ``matvec(x)`` returns B x for the local rows."""
+        self.matrix = matvec
+        self.indef = bool(indef)
+
+    def _safe_sqrt(self, alpha):
+        """``BV_SafeSqrt`` (bvimpl.h:113-134)."""
+        if self.indef:
+            return -np.sqrt(-alpha) if alpha < 0.0 else np.sqrt(alpha)
+        if alpha < 0.0:
+            raise ArithmeticError("The inner product is not well defined: indefinite matrix")
+        return np.sqrt(alpha)
+
+    def _ipmatmult(self, x):
+        """``BV_IPMatMult`` (bvimpl.h:140-151), without the cache (same values)."""
+        self.Bx = np.array(self.matrix(x), dtype=np.float64)
+        return self.Bx
+
+    def _allocate_signature(self):
+        """``BV_AllocateSignature`` (bvimpl.h:193-205)."""
+        if self.indef and self.omega is None:
+            self.omega = np.ones(self.nc + self.m)
+
+    def get_signature(self):
+        """``BVGetSignature`` (bvbasic.c:707-729)."""
+        if self.indef and self.omega is not None:
+            return self.omega[self.nc:self.nc + self.k].copy()
+        return np.ones(self.k)
+
+    def set_signature(self, omega):
+        """``BVSetSignature`` (bvbasic.c:664-687)."""
+        self._allocate_signature()
+        if self.indef:
+            self.omega[self.nc:self.nc + self.k] = omega[:self.k]
+
+    def apply_matrix(self, x):
+        """``BVApplyMatrix`` (bvbasic.c:551-566)."""
+        return self._ipmatmult(x).copy() if self.matrix is not None else np.array(x, dtype=np.float64)
+
+    def _ipmatmult_bv(self):
+        """``BV_IPMatMultBV`` (bvimpl.h:157-173): cached = B*X on the active columns."""
+        if self.cached is None:
+            self.cached = BV(self.n, self.m, N=self.N, comm=self.comm)
+        self.cached.set_active_columns(self.l, self.k)
+        for j in range(self.l, self.k):
+            self.cached.col(j)[:] = self.matrix(self.col(j)) if self.matrix is not None else self.col(j)
+        return self.cached
+
+    def dot(self, Y, M):
+        """``BVDot`` (bvglobal.c:92-137): M = Y^T B X through the cached B X."""
+        if self.matrix is not None:
+            return self._ipmatmult_bv().op_dot(Y, M)
+        return self.op_dot(Y, M)
+
+    def norm_vec(self, v):
+        """``BVNormVec`` / ``BVNorm_Private`` (bvglobal.c:470-480,570-597)."""
+        if self.matrix is not None:
+            p = float(self.comm.allreduce_sum(np.array([self._ipmatmult(v) @ v]))[0])
+            return float(self._safe_sqrt(p))
+        return float(np.sqrt(self.comm.allreduce_sum(np.array([v @ v]))[0]))
+
+    def insert_constraints(self, C):
+        """``BVInsertConstraints`` (bvfunc.c:414-442): the vectors of C, orthonormalised, become
+        the constraints; linearly dependent ones are dropped.  Returns the number kept.
+        Destroys the contents of the columns."""
+        if self.nc:
+            raise ValueError("Constraints already present in this BV object")
+        nc, msave = len(C), self.m
+        if not nc:
+            return 0
+        self.m = nc + msave                                  # BVResize(V, nc+m, FALSE)
+        self.array = np.zeros((self.n, self.m), order="F")
+        self.l, self.k = 0, self.m
+        self.buffer = None
+        self.omega = None
+        ndep = 0                                             # BVInsertVecs(V,0,&nc,C,TRUE), bvfunc.c:331-377
+        for i in range(nc):
+            j = i - ndep
+            self.col(j)[:] = C[i]
+            norm, lindep = self.orthogonalize_column(j)
+            if norm == 0.0 or lindep:
+                ndep += 1
+            else:
+                self.scale_column(j, 1.0 / norm)
+        self.nc = nc - ndep
+        self.m = msave
+        self.l, self.k = 0, msave
+        self.buffer = None
+        self.omega = None
+        return self.nc
 
     # ---- op table (svec.c) -------------------------------------------
     def op_dotvec(self, y, q=None):
@@ -169,8 +268,8 @@ class BV:
 
     # ---- interface wrappers ------------------------------------------
     def dotvec(self, y, q=None):
-        """``BVDotVec`` (bvglobal.c:168-188)."""
-        return self.op_dotvec(y, q)
+        """``BVDotVec`` (bvglobal.c:168-188); with a matrix the type works on B y (svec.c:131-134)."""
+        return self.op_dotvec(self._ipmatmult(y) if self.matrix is not None else y, q)
 
     def multvec(self, alpha, beta, y, q=None):
         """``BVMultVec`` (bvops.c:125-149)."""
@@ -180,7 +279,7 @@ class BV:
         """``BVDotColumn`` (bvglobal.c:324-349): k is set to j for the call."""
         ksave = self.k
         self.k = j
-        r = self.op_dotvec(self.col(j), q)
+        r = self.dotvec(self.col(j), q)
         self.k = ksave
         return r
 
@@ -188,7 +287,7 @@ class BV:
         """``BVDotColumnInc`` (bvorthog.c:176-192): also column j itself."""
         ksave = self.k
         self.k = j + 1
-        r = self.op_dotvec(self.col(j), q)
+        r = self.dotvec(self.col(j), q)
         self.k = ksave
         return r
 
@@ -206,7 +305,9 @@ class BV:
         self.op_multinplace(Q, s, e, False)
 
     def norm_column(self, j, ntype=NORM_2):
-        """``BVNormColumn`` (bvglobal.c:704-730)."""
+        """``BVNormColumn`` (bvglobal.c:704-730): sqrt(z^T B z) with a matrix, whatever the type."""
+        if self.matrix is not None:
+            return self.norm_vec(self.col(j))
         return self.op_norm(j, ntype)
 
     def norm(self, ntype=NORM_FROBENIUS):
@@ -252,23 +353,27 @@ class BV:
         onorm = norm = None
         if want_norms:
             self._dot_column_inc(j, None)               # :243
-            alpha = buf[nc + j]                         # BV_SquareRoot :126-136
-            if alpha < 0.0:
-                raise ArithmeticError("The inner product is not well defined: indefinite matrix")
-            beta = np.sqrt(alpha)
+            beta = self._safe_sqrt(buf[nc + j])         # BV_SquareRoot :126-136
         else:
             self.dot_column(j, None)                    # :250
+        if self.indef:                                  # BV_ApplySignature :108-120, :255
+            buf[:nc + j] /= self.omega[:nc + j]
         self.mult_column(-1.0, 1.0, j, None)            # :256
+        if self.indef:                                  # :258
+            buf[:nc + j] *= self.omega[:nc + j]
         if want_norms:
             onorm = beta
-            ssum = 0.0                                  # BV_SquareSum :89-101
-            for i in range(nc + j):
-                ssum += buf[i] * buf[i]
-            norm = beta * beta - ssum                   # :269
-            if norm <= 0.0:
-                norm = self.norm_column(j, NORM_2)      # :270-271
+            if self.indef:                              # :264-265
+                norm = self.norm_column(j, NORM_2)
             else:
-                norm = np.sqrt(norm)
+                ssum = 0.0                              # BV_SquareSum :89-101
+                for i in range(nc + j):
+                    ssum += buf[i] * buf[i]
+                norm = beta * beta - ssum               # :269
+                if norm <= 0.0:
+                    norm = self.norm_column(j, NORM_2)  # :270-271
+                else:
+                    norm = np.sqrt(norm)
         h = self._hcol(j)                               # BV_AddCoefficients :50-64
         for i in range(nc + j):
             h[i] += buf[i]
@@ -283,28 +388,36 @@ class BV:
         which = getattr(self, "_which", None)
         onrm = nrm = None
         if want_onorm:
-            onrm = float(np.sqrt(self.comm.allreduce_sum(np.array([w @ w]))[0]))
+            onrm = self.norm_vec(w)
         if which is not None:
             buf[:nc + j] = 0.0
         for i in range(-nc, j):
             if which is not None and i >= 0 and not which[i]:
                 continue
             vi = self.col(i)
-            dot = float(self.comm.allreduce_sum(np.array([w @ vi]))[0])
+            z = self._ipmatmult(w) if self.matrix is not None else w     # :212-215
+            dot = float(self.comm.allreduce_sum(np.array([z @ vi]))[0])
             buf[nc + i] = dot
+            if self.indef:                                               # :219
+                dot /= self.omega[nc + i]
             w -= dot * vi
         if want_norm:
-            nrm = float(np.sqrt(self.comm.allreduce_sum(np.array([w @ w]))[0]))
+            nrm = self.norm_vec(w)
         h = self._hcol(j)
         for i in range(nc + j):
             h[i] += buf[i]
         return onrm, nrm
 
     def _gs(self, j, want_norm=True, want_lindep=True):
-        """``BVOrthogonalizeGS`` (bvorthog.c:290-361), column variant, definite
-        inner product.  Returns (norm, lindep)."""
+        """``BVOrthogonalizeGS`` (bvorthog.c:290-361), column variant.  Returns (norm, lindep);
+        with an indefinite inner product lindep is not computed, the norm always is, and its
+        sign goes to the signature (:311-316,352)."""
         nc = self.nc
         mgs = self.orthog_type == MGS
+        self._allocate_signature()
+        signature = self.indef
+        if self.indef:
+            want_lindep = False
         k = j
         h = self._hcol(k)
         for i in range(nc + k):                          # BV_CleanCoefficients :30-44
@@ -331,19 +444,21 @@ class BV:
                 self._mgs1(k, False, False)
             else:
                 self._cgs1(k, False)
-            if want_norm or want_lindep:
+            if want_norm or want_lindep or signature:
                 nrm = self.norm_column(k, NORM_2)
             if want_lindep:
                 lindep = not nrm
         else:                                            # REFINE_ALWAYS :345-350
             if mgs:
                 self._mgs1(k, False, False)
-                onrm, nrm = self._mgs1(k, want_lindep, want_norm or want_lindep)
+                onrm, nrm = self._mgs1(k, want_lindep, want_norm or want_lindep or signature)
             else:
                 self._cgs1(k, False)
-                onrm, nrm = self._cgs1(k, want_norm or want_lindep)
+                onrm, nrm = self._cgs1(k, want_norm or want_lindep or signature)
             if want_lindep:
                 lindep = not (nrm and nrm >= self.orthog_eta * onrm)
+        if signature:                                    # :352
+            self.omega[nc + k] = -1.0 if nrm < 0.0 else 1.0
         if want_norm:                                    # :353-358
             h[nc + k] = 0.0 if (want_lindep and lindep) else nrm
         return nrm, lindep

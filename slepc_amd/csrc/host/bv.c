@@ -104,8 +104,9 @@ PetscErrorCode BVResize(BV bv, PetscInt m, PetscBool copy) {
   if (bv->m == m) return 0;
   ierr = bv->ops.resize(bv, m, copy);CHKERRQ(ierr);
   free(bv->buffer); bv->buffer = NULL;
-  free(bv->h); bv->h = NULL;
-  free(bv->c); bv->c = NULL;
+  free(bv->h); bv->h = NULL; bv->c = NULL;            /* c points into the allocation of h */
+  free(bv->omega); bv->omega = NULL;
+  if (bv->cached) { ierr = BVDestroy(&bv->cached);CHKERRQ(ierr); }
   bv->m = m;
   bv->k = PetscMin(bv->k, m);
   bv->l = PetscMin(bv->l, m);
@@ -137,6 +138,212 @@ PetscErrorCode BVSetOrthogonalization(BV bv, BVOrthogType type, BVOrthogRefineTy
     if (eta <= 0.0 || eta > 1.0) SETERRQ(PETSC_ERR_ARG_OUTOFRANGE, "Invalid eta value");
     bv->orthog_eta = eta;
   }
+  return 0;
+}
+
+/* ---- non-standard inner product (bvimpl.h:107-205, bvbasic.c:481-729) ------------------------ */
+/* bvimpl.h:113-134: the square root of z^T B z, signed when B is indefinite */
+static PetscErrorCode BV_SafeSqrt(BV bv, PetscScalar alpha, PetscReal *res) {
+  if (bv->indef) *res = (alpha < 0.0) ? -sqrt(-alpha) : sqrt(alpha);
+  else {
+    if (alpha < 0.0) SETERRQ(1, "The inner product is not well defined: indefinite matrix");
+    *res = sqrt(alpha);
+  }
+  return 0;
+}
+
+/* bvimpl.h:140-151: Bx = B*x unless it already holds the product of this very vector */
+static PetscErrorCode BV_IPMatMult(BV bv, Vec x) {
+  PetscErrorCode ierr;
+  if (x->id != bv->xid || x->state != bv->xstate) {
+    ierr = MatMult(bv->matrix, x, bv->Bx);CHKERRQ(ierr);
+    bv->xid = x->id;
+    bv->xstate = x->state;
+  }
+  return 0;
+}
+
+/* bvimpl.h:193-205 */
+static PetscErrorCode BV_AllocateSignature(BV bv) {
+  if (bv->indef && !bv->omega) {
+    bv->omega = (PetscReal *)malloc((size_t)(bv->nc + bv->m) * sizeof(PetscReal));
+    if (!bv->omega) SETERRQ(PETSC_ERR_MEM, "Out of memory");
+    for (PetscInt i = 0; i < bv->nc + bv->m; i++) bv->omega[i] = 1.0;
+  }
+  return 0;
+}
+
+/* ops->dotvec in the inner product of the BV: the type sees B*y (svec.c:131-134) */
+static PetscErrorCode BV_DotVecOp(BV X, Vec y, PetscScalar *q) {
+  PetscErrorCode ierr;
+  Vec z = y;
+  if (X->matrix) { ierr = BV_IPMatMult(X, y);CHKERRQ(ierr); z = X->Bx; }
+  ierr = X->ops.dotvec(X, z, q);CHKERRQ(ierr);
+  return 0;
+}
+
+PetscErrorCode BVSetMatrix(BV bv, Mat B, PetscBool indef) {
+  PetscErrorCode ierr;
+  if (!bv) SETERRQ(PETSC_ERR_ARG_NULL, "Null BV");
+  if (B) {
+    if (B->n != B->cn) SETERRQ(PETSC_ERR_ARG_SIZ, "Matrix must be square");
+    if (bv->m && bv->n != B->cn) SETERRQ(PETSC_ERR_ARG_INCOMP, "Mismatching local dimension BV %lld, Mat %lld", (long long)bv->n, (long long)B->cn);
+  }
+  bv->matrix = B;
+  bv->indef = indef;
+  bv->xid = 0; bv->xstate = 0;
+  bv->bvstate = -1;
+  if (B && !bv->Bx) { ierr = MatCreateVecs(B, &bv->Bx, NULL);CHKERRQ(ierr); }
+  return 0;
+}
+
+PetscErrorCode BVGetMatrix(BV bv, Mat *B, PetscBool *indef) {
+  if (!bv) SETERRQ(PETSC_ERR_ARG_NULL, "Null BV");
+  if (B) *B = bv->matrix;
+  if (indef) *indef = bv->indef;
+  return 0;
+}
+
+PetscErrorCode BVApplyMatrix(BV bv, Vec x, Vec y) {
+  PetscErrorCode ierr;
+  if (!bv || !x || !y) SETERRQ(PETSC_ERR_ARG_NULL, "Null argument");
+  if (bv->matrix) {
+    ierr = BV_IPMatMult(bv, x);CHKERRQ(ierr);
+    ierr = VecCopy(bv->Bx, y);CHKERRQ(ierr);
+  } else { ierr = VecCopy(x, y);CHKERRQ(ierr); }
+  return 0;
+}
+
+PetscErrorCode BVGetCachedBV(BV bv, BV *cached) {
+  PetscErrorCode ierr;
+  BVCheckSizes(bv);
+  if (!cached) SETERRQ(PETSC_ERR_ARG_NULL, "Null argument");
+  if (!bv->cached) {
+    ierr = BVCreate(bv->ctx, &bv->cached);CHKERRQ(ierr);
+    ierr = BVSetSizesFromVec(bv->cached, bv->t, bv->m);CHKERRQ(ierr);
+    ierr = BVSetType(bv->cached, bv->type_name);CHKERRQ(ierr);
+    ierr = BVSetOrthogonalization(bv->cached, bv->orthog_type, bv->orthog_ref, bv->orthog_eta, bv->orthog_block);CHKERRQ(ierr);
+    bv->bvstate = -1;
+  }
+  *cached = bv->cached;
+  return 0;
+}
+
+/* bvimpl.h:157-173: cached = B*X on the active columns, recomputed when X has changed */
+static PetscErrorCode BV_IPMatMultBV(BV bv) {
+  PetscErrorCode ierr;
+  ierr = BVGetCachedBV(bv, &bv->cached);CHKERRQ(ierr);
+  ierr = BVSetActiveColumns(bv->cached, bv->l, bv->k);CHKERRQ(ierr);
+  if (bv->state != bv->bvstate) {
+    if (bv->matrix) { ierr = BVMatMult(bv, bv->matrix, bv->cached);CHKERRQ(ierr); }
+    else { ierr = BVCopy(bv, bv->cached);CHKERRQ(ierr); }
+    bv->bvstate = bv->state;
+  }
+  return 0;
+}
+
+PetscErrorCode BVApplyMatrixBV(BV X, BV Y) {
+  PetscErrorCode ierr;
+  BVCheckSizes(X);
+  if (Y) {
+    if (X->matrix) { ierr = BVMatMult(X, X->matrix, Y);CHKERRQ(ierr); }
+    else { ierr = BVCopy(X, Y);CHKERRQ(ierr); }
+  } else { ierr = BV_IPMatMultBV(X);CHKERRQ(ierr); }
+  return 0;
+}
+
+PetscErrorCode BVSetSignature(BV bv, const PetscReal *omega) {
+  PetscErrorCode ierr;
+  BVCheckSizes(bv);
+  if (!omega) SETERRQ(PETSC_ERR_ARG_NULL, "Null array");
+  ierr = BV_AllocateSignature(bv);CHKERRQ(ierr);
+  if (bv->indef) for (PetscInt i = 0; i < bv->k; i++) bv->omega[bv->nc + i] = omega[i];
+  return 0;
+}
+
+PetscErrorCode BVGetSignature(BV bv, PetscReal *omega) {
+  BVCheckSizes(bv);
+  if (!omega) SETERRQ(PETSC_ERR_ARG_NULL, "Null array");
+  for (PetscInt i = 0; i < bv->k; i++) omega[i] = (bv->indef && bv->omega) ? bv->omega[bv->nc + i] : 1.0;
+  return 0;
+}
+
+PetscErrorCode BVDuplicateResize(BV V, PetscInt m, BV *W) {
+  PetscErrorCode ierr;
+  BVCheckSizes(V);
+  if (!W) SETERRQ(PETSC_ERR_ARG_NULL, "Null argument");
+  ierr = BVCreate(V->ctx, W);CHKERRQ(ierr);
+  ierr = BVSetSizesFromVec(*W, V->t, m);CHKERRQ(ierr);
+  ierr = BVSetType(*W, V->type_name);CHKERRQ(ierr);
+  ierr = BVSetMatrix(*W, V->matrix, V->indef);CHKERRQ(ierr);
+  ierr = BVSetOrthogonalization(*W, V->orthog_type, V->orthog_ref, V->orthog_eta, V->orthog_block);CHKERRQ(ierr);
+  (*W)->state++;
+  return 0;
+}
+PetscErrorCode BVDuplicate(BV V, BV *W) { BVCheckSizes(V); return BVDuplicateResize(V, V->m, W); }
+
+/* ---- constraints (bvbasic.c:262-321, bvfunc.c:414-442) ---------------------------------------- */
+PetscErrorCode BVGetNumConstraints(BV bv, PetscInt *nc) {
+  if (!bv || !nc) SETERRQ(PETSC_ERR_ARG_NULL, "Null argument");
+  *nc = bv->nc;
+  return 0;
+}
+
+static void BVFreeCoefficients(BV bv) {
+  free(bv->buffer); bv->buffer = NULL;
+  free(bv->h); bv->h = NULL; bv->c = NULL;
+  free(bv->omega); bv->omega = NULL;
+}
+
+PetscErrorCode BVSetNumConstraints(BV V, PetscInt nc) {
+  PetscErrorCode ierr;
+  PetscInt total, diff, i;
+  Vec x, y;
+  BVCheckSizes(V);
+  if (nc < 0) SETERRQ(PETSC_ERR_ARG_OUTOFRANGE, "Number of constraints (given %d) cannot be negative", nc);
+  if (V->ci[0] != -V->nc - 1 || V->ci[1] != -V->nc - 1) SETERRQ(PETSC_ERR_SUP, "Cannot call BVSetNumConstraints after BVGetColumn");
+  diff = nc - V->nc;
+  if (!diff) return 0;
+  total = V->nc + V->m;
+  if (total - nc <= 0) SETERRQ(PETSC_ERR_ARG_OUTOFRANGE, "Not enough columns for the given nc value");
+  if (diff < 0) {             /* lessen constraints, shift contents of BV */
+    for (i = 0; i < V->m; i++) {
+      ierr = BVGetColumn(V, i, &x);CHKERRQ(ierr);
+      ierr = BVGetColumn(V, i + diff, &y);CHKERRQ(ierr);
+      ierr = VecCopy(x, y);CHKERRQ(ierr);
+      ierr = BVRestoreColumn(V, i, &x);CHKERRQ(ierr);
+      ierr = BVRestoreColumn(V, i + diff, &y);CHKERRQ(ierr);
+    }
+  }
+  V->nc = nc;
+  V->ci[0] = V->ci[1] = -V->nc - 1;
+  V->l = 0;
+  V->m = total - nc;
+  V->k = V->m;
+  BVFreeCoefficients(V);
+  V->state++;
+  return 0;
+}
+
+PetscErrorCode BVInsertConstraints(BV V, PetscInt *nc, Vec *C) {
+  PetscErrorCode ierr;
+  PetscInt msave;
+  BVCheckSizes(V);
+  if (!nc) SETERRQ(PETSC_ERR_ARG_NULL, "Null argument");
+  if (!*nc) return 0;
+  if (*nc < 0) SETERRQ(PETSC_ERR_ARG_OUTOFRANGE, "Number of constraints (given %d) cannot be negative", *nc);
+  if (!C || !*C) SETERRQ(PETSC_ERR_ARG_NULL, "Null argument");
+  if (V->nc) SETERRQ(PETSC_ERR_ARG_WRONGSTATE, "Constraints already present in this BV object");
+  if (V->ci[0] != -1 || V->ci[1] != -1) SETERRQ(PETSC_ERR_SUP, "Cannot call BVInsertConstraints after BVGetColumn");
+  msave = V->m;
+  ierr = BVResize(V, *nc + V->m, PETSC_FALSE);CHKERRQ(ierr);
+  ierr = BVInsertVecs(V, 0, nc, C, PETSC_TRUE);CHKERRQ(ierr);
+  V->nc = *nc;
+  V->m = msave;
+  V->l = 0; V->k = msave;
+  V->ci[0] = V->ci[1] = -V->nc - 1;
+  BVFreeCoefficients(V);          /* sized for the columns as they were counted during the insertion */
+  V->state++;
   return 0;
 }
 
@@ -250,6 +457,10 @@ PetscErrorCode BVCopy(BV V, BV W) {
   if (V->k - V->l > W->m - W->l) SETERRQ(PETSC_ERR_ARG_SIZ, "W has %d non-leading columns, not enough to store %d columns", W->m - W->l, V->k - V->l);
   if (!V->n) return 0;
   W->k = W->l + V->k - V->l;
+  if (V->indef && V->matrix && V->indef == W->indef && V->matrix == W->matrix && V->omega) {      /* copy signature */
+    ierr = BV_AllocateSignature(W);CHKERRQ(ierr);
+    memcpy(W->omega + W->nc + W->l, V->omega + V->nc + V->l, (size_t)(V->k - V->l) * sizeof(PetscReal));
+  }
   ierr = V->ops.copy(V, W);CHKERRQ(ierr);
   W->state++;
   return 0;
@@ -362,7 +573,12 @@ PetscErrorCode BVDot(BV X, BV Y, PetscScalar *M, PetscInt ldm) {
   if (!M) SETERRQ(PETSC_ERR_ARG_NULL, "Null matrix");
   if (ldm < Y->k) SETERRQ(PETSC_ERR_ARG_SIZ, "Mat argument has %d rows, should have at least %d", ldm, Y->k);
   if (X->n != Y->n) SETERRQ(PETSC_ERR_ARG_INCOMP, "Mismatching local dimension X %lld, Y %lld", (long long)X->n, (long long)Y->n);
-  ierr = X->ops.dot(X, Y, M, ldm);CHKERRQ(ierr);
+  if (X->matrix != Y->matrix) SETERRQ(PETSC_ERR_ARG_WRONGSTATE, "X and Y must have the same inner product matrix");
+  if (X->l == X->k || Y->l == Y->k) return 0;
+  if (X->matrix) {            /* M = Y^T (B X): B X first, in the cached BV (bvglobal.c:125-130) */
+    ierr = BV_IPMatMultBV(X);CHKERRQ(ierr);
+    ierr = X->ops.dot(X->cached, Y, M, ldm);CHKERRQ(ierr);
+  } else { ierr = X->ops.dot(X, Y, M, ldm);CHKERRQ(ierr); }
   return 0;
 }
 
@@ -372,7 +588,7 @@ PetscErrorCode BVDotVec(BV X, Vec y, PetscScalar *q) {
   if (!y) SETERRQ(PETSC_ERR_ARG_NULL, "Null vector");
   if (X->n != y->n) SETERRQ(PETSC_ERR_ARG_INCOMP, "Mismatching local dimension X %lld, y %lld", (long long)X->n, (long long)y->n);
   if (!q) { ierr = BVGetBuffer(X, &q, NULL);CHKERRQ(ierr); }
-  ierr = X->ops.dotvec(X, y, q);CHKERRQ(ierr);
+  ierr = BV_DotVecOp(X, y, q);CHKERRQ(ierr);
   return 0;
 }
 
@@ -385,6 +601,7 @@ PetscErrorCode BVDotVecBegin(BV X, Vec y, PetscScalar *m) {
   BVCheckSizes(X);
   if (!y) SETERRQ(PETSC_ERR_ARG_NULL, "Null vector");
   if (X->n != y->n) SETERRQ(PETSC_ERR_ARG_INCOMP, "Mismatching local dimension X %lld, y %lld", (long long)X->n, (long long)y->n);
+  if (X->matrix) { ierr = BV_IPMatMult(X, y);CHKERRQ(ierr); y = X->Bx; }
   ierr = KSRedBegin_Private(X, X->ops.dotvec_post ? y->ops : NULL, y->ctx, X->k - X->l, 0, &vals);CHKERRQ(ierr);
   if (vals) ierr = X->ops.dotvec(X, y, vals);
   else {
@@ -436,18 +653,35 @@ PetscErrorCode BVDotColumnEnd(BV X, PetscInt j, PetscScalar *m) {
   return 0;
 }
 
-/* bvglobal.c:732-830; the entries belong to the vector, as in VecNormBegin/End */
-PetscErrorCode BVNormVecBegin(BV bv, Vec v, NormType type, PetscReal *val) { (void)bv; return VecNormBegin(v, type, val); }
-PetscErrorCode BVNormVecEnd(BV bv, Vec v, NormType type, PetscReal *val) { (void)bv; return VecNormEnd(v, type, val); }
+/* bvglobal.c:482-502,615-700: with a matrix the value posted is z^T B z (the entry belongs to
+ * the vector B*z), otherwise the sum of squares as in VecNormBegin/End */
+static PetscErrorCode BVNorm_Begin_Private(BV bv, Vec z, NormType type, PetscReal *val) {
+  PetscErrorCode ierr;
+  if (!bv->matrix) return VecNormBegin(z, type, val);
+  if (bv->n != z->n) SETERRQ(PETSC_ERR_ARG_INCOMP, "Mismatching local dimension bv %lld, v %lld", (long long)bv->n, (long long)z->n);
+  ierr = BV_IPMatMult(bv, z);CHKERRQ(ierr);
+  ierr = VecDotBegin(bv->Bx, z, val);CHKERRQ(ierr);
+  return 0;
+}
+static PetscErrorCode BVNorm_End_Private(BV bv, Vec z, NormType type, PetscReal *val) {
+  PetscErrorCode ierr;
+  PetscScalar p;
+  if (!bv->matrix) return VecNormEnd(z, type, val);
+  ierr = VecDotEnd(bv->Bx, z, &p);CHKERRQ(ierr);
+  ierr = BV_SafeSqrt(bv, p, val);CHKERRQ(ierr);
+  return 0;
+}
+PetscErrorCode BVNormVecBegin(BV bv, Vec v, NormType type, PetscReal *val) { BVCheckSizes(bv); if (!v) SETERRQ(PETSC_ERR_ARG_NULL, "Null vector"); return BVNorm_Begin_Private(bv, v, type, val); }
+PetscErrorCode BVNormVecEnd(BV bv, Vec v, NormType type, PetscReal *val) { BVCheckSizes(bv); if (!v || !val) SETERRQ(PETSC_ERR_ARG_NULL, "Null argument"); return BVNorm_End_Private(bv, v, type, val); }
 
-/* the entry is keyed by the storage of column j: a column view is the same Vec object for
- * different columns */
+/* a column view is the same Vec object for different columns, so Begin and End of one
+ * column meet on the same entry */
 PetscErrorCode BVNormColumnBegin(BV bv, PetscInt j, NormType type, PetscReal *val) {
   PetscErrorCode ierr;
   Vec v;
   BVCheckSizes(bv);
   ierr = BVGetColumn(bv, j, &v);CHKERRQ(ierr);
-  ierr = VecNormBegin(v, type, val);
+  ierr = BVNorm_Begin_Private(bv, v, type, val);
   { const PetscErrorCode ierr2 = BVRestoreColumn(bv, j, &v); if (!ierr) ierr = ierr2; }
   CHKERRQ(ierr);
   return 0;
@@ -456,8 +690,9 @@ PetscErrorCode BVNormColumnEnd(BV bv, PetscInt j, NormType type, PetscReal *val)
   PetscErrorCode ierr;
   Vec v;
   BVCheckSizes(bv);
+  if (!val) SETERRQ(PETSC_ERR_ARG_NULL, "Null argument");
   ierr = BVGetColumn(bv, j, &v);CHKERRQ(ierr);
-  ierr = VecNormEnd(v, type, val);
+  ierr = BVNorm_End_Private(bv, v, type, val);
   { const PetscErrorCode ierr2 = BVRestoreColumn(bv, j, &v); if (!ierr) ierr = ierr2; }
   CHKERRQ(ierr);
   return 0;
@@ -474,7 +709,7 @@ PetscErrorCode BVDotColumn(BV X, PetscInt j, PetscScalar *q) {
   X->k = j;
   if (!q) { ierr = BVGetBuffer(X, &q, NULL);CHKERRQ(ierr); }
   ierr = BVGetColumn(X, j, &y);CHKERRQ(ierr);
-  ierr = X->ops.dotvec(X, y, q);
+  ierr = BV_DotVecOp(X, y, q);
   X->k = ksave;
   CHKERRQ(ierr);
   ierr = BVRestoreColumn(X, j, &y);CHKERRQ(ierr);
@@ -489,7 +724,7 @@ static PetscErrorCode BVDotColumnInc(BV X, PetscInt j, PetscScalar *q) {
   ksave = X->k;
   X->k = j + 1;
   ierr = BVGetColumn(X, j, &y);CHKERRQ(ierr);
-  ierr = X->ops.dotvec(X, y, q);
+  ierr = BV_DotVecOp(X, y, q);
   X->k = ksave;
   CHKERRQ(ierr);
   ierr = BVRestoreColumn(X, j, &y);CHKERRQ(ierr);
@@ -515,11 +750,22 @@ PetscErrorCode BVScaleColumn(BV bv, PetscInt j, PetscScalar alpha) {
   return 0;
 }
 
+/* bvglobal.c:470-480 */
+static PetscErrorCode BVNorm_Private(BV bv, Vec z, PetscReal *val) {
+  PetscErrorCode ierr;
+  PetscScalar p;
+  ierr = BV_IPMatMult(bv, z);CHKERRQ(ierr);
+  ierr = VecDot(bv->Bx, z, &p);CHKERRQ(ierr);
+  ierr = BV_SafeSqrt(bv, p, val);CHKERRQ(ierr);
+  return 0;
+}
+
 PetscErrorCode BVNorm(BV bv, NormType type, PetscReal *val) {
   PetscErrorCode ierr;
   BVCheckSizes(bv);
   if (!val) SETERRQ(PETSC_ERR_ARG_NULL, "Null argument");
   if (type == NORM_2) SETERRQ(PETSC_ERR_SUP, "Requested norm not available");
+  if (bv->matrix) SETERRQ(PETSC_ERR_SUP, "Matrix norm not available for non-standard inner product");
   ierr = bv->ops.norm(bv, -1, type, val);CHKERRQ(ierr);
   return 0;
 }
@@ -529,7 +775,13 @@ PetscErrorCode BVNormColumn(BV bv, PetscInt j, NormType type, PetscReal *val) {
   BVCheckSizes(bv);
   if (!val) SETERRQ(PETSC_ERR_ARG_NULL, "Null argument");
   if (j < 0 || j >= bv->m) SETERRQ(PETSC_ERR_ARG_OUTOFRANGE, "Argument j has wrong value %d, the number of columns is %d", j, bv->m);
-  ierr = bv->ops.norm(bv, j, type, val);CHKERRQ(ierr);
+  if (bv->matrix) {           /* sqrt(z^T B z), the type argument is ignored (bvglobal.c:722-725) */
+    Vec z;
+    ierr = BVGetColumn(bv, j, &z);CHKERRQ(ierr);
+    ierr = BVNorm_Private(bv, z, val);
+    { const PetscErrorCode ierr2 = BVRestoreColumn(bv, j, &z); if (!ierr) ierr = ierr2; }
+    CHKERRQ(ierr);
+  } else { ierr = bv->ops.norm(bv, j, type, val);CHKERRQ(ierr); }
   return 0;
 }
 
@@ -538,7 +790,8 @@ PetscErrorCode BVNormVec(BV bv, Vec v, NormType type, PetscReal *val) {
   BVCheckSizes(bv);
   if (!v || !val) SETERRQ(PETSC_ERR_ARG_NULL, "Null argument");
   if (bv->n != v->n) SETERRQ(PETSC_ERR_ARG_INCOMP, "Mismatching local dimension bv %lld, v %lld", (long long)bv->n, (long long)v->n);
-  ierr = VecNorm(v, type, val);CHKERRQ(ierr);
+  if (bv->matrix) { ierr = BVNorm_Private(bv, v, val);CHKERRQ(ierr); }
+  else { ierr = VecNorm(v, type, val);CHKERRQ(ierr); }
   return 0;
 }
 
@@ -561,12 +814,6 @@ PetscErrorCode BVMatMult(BV V, Mat A, BV W) {
 static PetscScalar *HH(BV bv, PetscInt j, PetscScalar *h) { return h ? h : bv->buffer + (size_t)j * (bv->nc + bv->m); }
 static PetscScalar *CC(BV bv, PetscScalar *c) { return c ? c : bv->buffer; }
 
-static PetscErrorCode BV_SafeSqrt(PetscScalar alpha, PetscReal *res) {     /* bvimpl.h:113-134, definite case */
-  if (alpha < 0.0) SETERRQ(1, "The inner product is not well defined: indefinite matrix");
-  *res = sqrt(alpha);
-  return 0;
-}
-
 static PetscErrorCode BV_NormVecOrColumn(BV bv, PetscInt j, Vec v, PetscReal *nrm) {
   PetscErrorCode ierr;
   if (v) { ierr = BVNormVec(bv, v, NORM_2, nrm);CHKERRQ(ierr); }
@@ -579,15 +826,18 @@ static PetscErrorCode BVOrthogonalizeMGS1(BV bv, PetscInt j, Vec v, const PetscB
   PetscErrorCode ierr;
   PetscInt i;
   PetscScalar dot, *cc = CC(bv, c), *hh = HH(bv, j, h);
-  Vec vi, w = v;
+  Vec vi, z, w = v;
   if (!v) { ierr = BVGetColumn(bv, j, &w);CHKERRQ(ierr); }
   if (onrm) { ierr = BVNormVec(bv, w, NORM_2, onrm);CHKERRQ(ierr); }
   if (which) for (i = 0; i < bv->nc + j; i++) cc[i] = 0.0;       /* columns left out contribute nothing */
   for (i = -bv->nc; i < j; i++) {
     if (which && i >= 0 && !which[i]) continue;
     ierr = BVGetColumn(bv, i, &vi);CHKERRQ(ierr);
-    ierr = VecDot(w, vi, &dot);CHKERRQ(ierr);
+    z = w;
+    if (bv->matrix) { ierr = BV_IPMatMult(bv, w);CHKERRQ(ierr); z = bv->Bx; }
+    ierr = VecDot(z, vi, &dot);CHKERRQ(ierr);
     cc[bv->nc + i] = dot;
+    if (bv->indef) dot /= bv->omega[bv->nc + i];
     ierr = VecAXPY(w, -dot, vi);CHKERRQ(ierr);
     ierr = BVRestoreColumn(bv, i, &vi);CHKERRQ(ierr);
   }
@@ -608,7 +858,7 @@ static PetscErrorCode BVOrthogonalizeCGS1(BV bv, PetscInt j, Vec v, PetscScalar 
   if (onorm || norm) {
     if (!v) {
       ierr = BVDotColumnInc(bv, j, c ? c : bv->buffer);CHKERRQ(ierr);
-      ierr = BV_SafeSqrt(cc[bv->nc + j], &beta);CHKERRQ(ierr);
+      ierr = BV_SafeSqrt(bv, cc[bv->nc + j], &beta);CHKERRQ(ierr);
     } else {
       ierr = BVDotVec(bv, v, cc);CHKERRQ(ierr);
       ierr = BVNormVec(bv, v, NORM_2, &beta);CHKERRQ(ierr);
@@ -617,16 +867,21 @@ static PetscErrorCode BVOrthogonalizeCGS1(BV bv, PetscInt j, Vec v, PetscScalar 
     if (!v) { ierr = BVDotColumn(bv, j, cc);CHKERRQ(ierr); }
     else { ierr = BVDotVec(bv, v, cc);CHKERRQ(ierr); }
   }
-  /* q = v - V h */
+  /* q = v - V h (h/omega with a signature: BV_ApplySignature, bvorthog.c:108-120) */
+  if (bv->indef) for (i = 0; i < bv->nc + j; i++) cc[i] /= bv->omega[i];
   if (!v) { ierr = BVMultColumn(bv, -1.0, 1.0, j, cc);CHKERRQ(ierr); }
   else { ierr = BVMultVec(bv, -1.0, 1.0, v, cc);CHKERRQ(ierr); }
+  if (bv->indef) for (i = 0; i < bv->nc + j; i++) cc[i] *= bv->omega[i];
   if (onorm) *onorm = beta;
   if (norm) {
-    sum = 0.0;
-    for (i = 0; i < bv->nc + j; i++) sum += cc[i] * cc[i];      /* BV_SquareSum */
-    *norm = beta * beta - sum;
-    if (*norm <= 0.0) { ierr = BV_NormVecOrColumn(bv, j, v, norm);CHKERRQ(ierr); }
-    else *norm = sqrt(*norm);
+    if (bv->indef) { ierr = BV_NormVecOrColumn(bv, j, v, norm);CHKERRQ(ierr); }
+    else {
+      sum = 0.0;
+      for (i = 0; i < bv->nc + j; i++) sum += cc[i] * cc[i];      /* BV_SquareSum */
+      *norm = beta * beta - sum;
+      if (*norm <= 0.0) { ierr = BV_NormVecOrColumn(bv, j, v, norm);CHKERRQ(ierr); }
+      else *norm = sqrt(*norm);
+    }
   }
   for (i = 0; i < bv->nc + j; i++) hh[i] += cc[i];               /* BV_AddCoefficients */
   ks_gs_passes++;
@@ -640,7 +895,10 @@ static PetscErrorCode BVOrthogonalizeGS(BV bv, PetscInt j, Vec v, const PetscBoo
   PetscReal onrm = 0.0, nrm = 0.0;
   PetscInt k, l, i;
   const PetscBool mgs = (bv->orthog_type == BV_ORTHOG_MGS);
-  const PetscBool dolindep = lindep ? PETSC_TRUE : PETSC_FALSE;
+  /* with an indefinite inner product lindep is not computed, and the norm of a column always is */
+  const PetscBool dolindep = (!bv->indef && lindep) ? PETSC_TRUE : PETSC_FALSE;
+  const PetscBool signature = (bv->indef && !v) ? PETSC_TRUE : PETSC_FALSE;
+  if (bv->indef && lindep) *lindep = PETSC_FALSE;
   if (v) { k = bv->k; h = bv->h; c = bv->c; }
   else { k = j; h = NULL; c = NULL; }
 #define GS1(on, nr) (mgs ? BVOrthogonalizeMGS1(bv, k, v, which, h, c, on, nr) : BVOrthogonalizeCGS1(bv, k, v, h, c, on, nr))
@@ -659,16 +917,17 @@ static PetscErrorCode BVOrthogonalizeGS(BV bv, PetscInt j, Vec v, const PetscBoo
       break;
     case BV_ORTHOG_REFINE_NEVER:
       ierr = GS1(NULL, NULL);CHKERRQ(ierr);
-      if (norm || dolindep) { ierr = BV_NormVecOrColumn(bv, k, v, &nrm);CHKERRQ(ierr); }
+      if (norm || dolindep || signature) { ierr = BV_NormVecOrColumn(bv, k, v, &nrm);CHKERRQ(ierr); }
       if (dolindep) *lindep = !nrm;
       break;
     case BV_ORTHOG_REFINE_ALWAYS:
       ierr = GS1(NULL, NULL);CHKERRQ(ierr);
-      ierr = GS1(dolindep ? &onrm : NULL, (norm || dolindep) ? &nrm : NULL);CHKERRQ(ierr);
+      ierr = GS1(dolindep ? &onrm : NULL, (norm || dolindep || signature) ? &nrm : NULL);CHKERRQ(ierr);
       if (dolindep) *lindep = !(nrm && nrm >= bv->orthog_eta * onrm);
       break;
   }
 #undef GS1
+  if (signature) bv->omega[bv->nc + k] = (nrm < 0.0) ? -1.0 : 1.0;
   if (norm) {
     *norm = nrm;
     if (!v) hh[bv->nc + k] = (dolindep && *lindep) ? 0.0 : nrm;    /* store the norm next to the coefficients */
@@ -695,7 +954,8 @@ PetscErrorCode BVOrthogonalizeVec(BV bv, Vec v, PetscScalar *H, PetscReal *norm,
   bv->l = -bv->nc;
   ierr = BV_AllocateCoeffs(bv);CHKERRQ(ierr);
   ierr = BVGetBuffer(bv, NULL, NULL);CHKERRQ(ierr);
-  ierr = BVOrthogonalizeGS(bv, 0, v, NULL, norm, lindep);
+  ierr = BV_AllocateSignature(bv);
+  if (!ierr) ierr = BVOrthogonalizeGS(bv, 0, v, NULL, norm, lindep);
   bv->k = ksave; bv->l = lsave;
   CHKERRQ(ierr);
   if (H) for (i = bv->l; i < bv->k; i++) H[i - bv->l] = bv->h[bv->nc + i];     /* BV_StoreCoefficients */
@@ -712,7 +972,8 @@ PetscErrorCode BVOrthogonalizeColumn(BV bv, PetscInt j, PetscScalar *H, PetscRea
   ksave = bv->k; lsave = bv->l;
   bv->l = -bv->nc;
   ierr = BVGetBuffer(bv, NULL, NULL);CHKERRQ(ierr);
-  ierr = BVOrthogonalizeGS(bv, j, NULL, NULL, norm, lindep);
+  ierr = BV_AllocateSignature(bv);
+  if (!ierr) ierr = BVOrthogonalizeGS(bv, j, NULL, NULL, norm, lindep);
   bv->k = ksave; bv->l = lsave;
   CHKERRQ(ierr);
   if (H) { PetscScalar *hh = HH(bv, j, NULL); for (i = bv->l; i < j; i++) H[i - bv->l] = hh[bv->nc + i]; }
@@ -732,7 +993,8 @@ PetscErrorCode BVOrthogonalizeSomeColumn(BV bv, PetscInt j, const PetscBool *whi
   ksave = bv->k; lsave = bv->l;
   bv->l = -bv->nc;
   ierr = BVGetBuffer(bv, NULL, NULL);CHKERRQ(ierr);
-  ierr = BVOrthogonalizeGS(bv, j, NULL, which, norm, lindep);
+  ierr = BV_AllocateSignature(bv);
+  if (!ierr) ierr = BVOrthogonalizeGS(bv, j, NULL, which, norm, lindep);
   bv->k = ksave; bv->l = lsave;
   CHKERRQ(ierr);
   if (H) { PetscScalar *hh = HH(bv, j, NULL); for (i = bv->l; i < j; i++) H[i - bv->l] = hh[bv->nc + i]; }
@@ -752,7 +1014,8 @@ PetscErrorCode BVOrthonormalizeColumn(BV bv, PetscInt j, PetscBool replace, Pets
   ksave = bv->k; lsave = bv->l;
   bv->l = -bv->nc;
   ierr = BVGetBuffer(bv, NULL, NULL);CHKERRQ(ierr);
-  ierr = BVOrthogonalizeGS(bv, j, NULL, NULL, &nrm, &lndep);
+  ierr = BV_AllocateSignature(bv);
+  if (!ierr) ierr = BVOrthogonalizeGS(bv, j, NULL, NULL, &nrm, &lndep);
   if (!ierr && replace && (nrm == 0.0 || lndep)) {
     ierr = BVSetRandomColumn(bv, j);
     if (!ierr) ierr = BVOrthogonalizeGS(bv, j, NULL, NULL, &nrm, &lndep);
@@ -778,24 +1041,44 @@ PetscErrorCode BVDestroy(BV *bv) {
   ierr = VecDestroy(&b->t);CHKERRQ(ierr);
   ierr = VecDestroy(&b->cv[0]);CHKERRQ(ierr);
   ierr = VecDestroy(&b->cv[1]);CHKERRQ(ierr);
+  ierr = VecDestroy(&b->Bx);CHKERRQ(ierr);
+  ierr = BVDestroy(&b->cached);CHKERRQ(ierr);
   free(b->buffer);
   free(b->h);
+  free(b->omega);
   free(b);
   *bv = NULL;
   return 0;
 }
 
 /* ---- block orthogonalisation (bvorthog.c:635-859) ------------------------------------------- */
-/* bvorthog.c:635-680, standard inner product */
+/* bvorthog.c:635-680 */
 static PetscErrorCode BVOrthogonalize_GS(BV V, PetscScalar *r, PetscInt ldr) {
   PetscErrorCode ierr;
   PetscReal norm;
+  Vec v, w;
+  if (V->matrix) {
+    ierr = BVGetCachedBV(V, &V->cached);CHKERRQ(ierr);
+    ierr = BVSetActiveColumns(V->cached, V->l, V->k);CHKERRQ(ierr);
+  }
   for (PetscInt j = V->l; j < V->k; j++) {
+    if (V->matrix && V->orthog_type == BV_ORTHOG_MGS) {      /* fill cached BV */
+      ierr = BVGetColumn(V->cached, j, &v);CHKERRQ(ierr);
+      ierr = BVGetColumn(V, j, &w);CHKERRQ(ierr);
+      ierr = MatMult(V->matrix, w, v);CHKERRQ(ierr);
+      ierr = BVRestoreColumn(V, j, &w);CHKERRQ(ierr);
+      ierr = BVRestoreColumn(V->cached, j, &v);CHKERRQ(ierr);
+    }
     if (r) {
       ierr = BVOrthogonalizeColumn(V, j, r + (size_t)j * ldr + V->l, &norm, NULL);CHKERRQ(ierr);
       r[j + (size_t)j * ldr] = norm;
     } else { ierr = BVOrthogonalizeColumn(V, j, NULL, &norm, NULL);CHKERRQ(ierr); }
     if (!norm) SETERRQ(1, "Breakdown in BVOrthogonalize due to a linearly dependent column");
+    if (V->matrix && V->orthog_type == BV_ORTHOG_CGS) {      /* fill cached BV with the product the last pass left */
+      ierr = BVGetColumn(V->cached, j, &v);CHKERRQ(ierr);
+      ierr = VecCopy(V->Bx, v);CHKERRQ(ierr);
+      ierr = BVRestoreColumn(V->cached, j, &v);CHKERRQ(ierr);
+    }
     ierr = BVScaleColumn(V, j, 1.0 / norm);CHKERRQ(ierr);
   }
   return 0;
@@ -849,7 +1132,9 @@ PetscErrorCode BVOrthogonalize(BV V, PetscScalar *R, PetscInt ldr) {
   switch (V->orthog_block) {
     case BV_ORTHOG_BLOCK_GS: ierr = BVOrthogonalize_GS(V, R, ldr);CHKERRQ(ierr); break;
     case BV_ORTHOG_BLOCK_CHOL: ierr = BVOrthogonalize_Chol(V, R, ldr);CHKERRQ(ierr); break;
-    default: SETERRQ(PETSC_ERR_SUP, "The tall-skinny QR block orthogonalization is not available");
+    default:
+      if (V->matrix) SETERRQ(PETSC_ERR_SUP, "Orthogonalization method not available for non-standard inner product");
+      SETERRQ(PETSC_ERR_SUP, "The tall-skinny QR block orthogonalization is not available");
   }
   V->state++;
   return 0;

@@ -6,7 +6,12 @@
 
 #define GBV(bv) ((ksg_bv)(bv)->data)
 
-static PetscErrorCode Sync(BV bv) { CHKKSG(ksg_bv_set_active(GBV(bv), bv->l, bv->k)); return 0; }
+/* the interface layer owns nc, l, k (svec reads them from the BV at every op): hand them on */
+static PetscErrorCode Sync(BV bv) {
+  CHKKSG(ksg_bv_set_num_constraints(GBV(bv), bv->nc));
+  CHKKSG(ksg_bv_set_active(GBV(bv), bv->l, bv->k));
+  return 0;
+}
 
 static PetscErrorCode BVMult_HIP(BV Y, PetscScalar alpha, PetscScalar beta, BV X, const PetscScalar *Q, PetscInt ldq) {
   PetscErrorCode ierr;
@@ -80,8 +85,15 @@ static PetscErrorCode BVMatMult_HIP(BV V, Mat A, BV W) {
   PetscErrorCode ierr;
   PetscInt j;
   Vec v, w;
-  if (A->ops.mult && A->ctx == V->ctx && A->ops.createvecs && A->data && V->data && W->data) {
-    /* device operator: column by column on the device (svec.c:250-256) */
+  if (A->ctx == V->ctx && MatGetDeviceHandle_Private(A) && A->n == A->cn) {
+    /* device CSR operator: all active columns in one pass over the matrix */
+    ierr = Sync(V);CHKERRQ(ierr);
+    ierr = Sync(W);CHKERRQ(ierr);
+    CHKKSG(ksg_bv_matmult(GBV(V), (ksg_mat)MatGetDeviceHandle_Private(A), GBV(W)));
+    return 0;
+  }
+  if (A->ops.mult && A->ctx == V->ctx && V->data && W->data) {
+    /* any other operator on the same context: column by column (svec.c:250-256) */
     for (j = 0; j < V->k - V->l; j++) {
       ierr = BVGetColumn(V, V->l + j, &v);CHKERRQ(ierr);
       ierr = BVGetColumn(W, W->l + j, &w);CHKERRQ(ierr);
@@ -104,6 +116,7 @@ static PetscErrorCode BVResize_HIP(BV bv, PetscInt m, PetscBool copy) { CHKKSG(k
 static PetscErrorCode BVGetColumn_HIP(BV bv, PetscInt j, Vec *v) {
   PetscErrorCode ierr;
   const int l = (bv->ci[0] == -bv->nc - 1) ? 0 : 1;            /* BVAvailableVec */
+  CHKKSG(ksg_bv_set_num_constraints(GBV(bv), bv->nc));
   double *p = ksg_bv_column(GBV(bv), j);
   if (!p) SETERRQ(PETSC_ERR_LIB, "libksgpu: %s", ksg_last_error());
   ierr = VecPlaceArray(bv->cv[l], p);CHKERRQ(ierr);             /* svec.c:322 */

@@ -17,6 +17,8 @@ void KSErrorTrace(const char *func, int line);
 /* a libksgpu call: its message becomes ours */
 #define CHKKSG(call) do { int rc_ = (call); if (rc_) return KSError(__func__, __LINE__, PETSC_ERR_LIB, "libksgpu: %s", ksg_last_error()); } while (0)
 
+void *MatGetDeviceHandle_Private(Mat A);          /* mat.c */
+
 /* split-phase reductions (vec.c) */
 PetscErrorCode KSRedBegin_Private(const void *owner, const struct _VecOps *ops, void *ctx, PetscInt count, int root, PetscScalar **vals);
 void KSRedPosted_Private(PetscInt dev_off);

@@ -97,6 +97,9 @@ PetscErrorCode MatShellSetTranspose(Mat A, PetscErrorCode (*transpose)(Mat, Mat 
   return 0;
 }
 
+/* the libksgpu matrix behind an "aijhip" operator, NULL for any other type */
+void *MatGetDeviceHandle_Private(Mat A) { return (A && A->ops.mult == MatMult_AIJHIP) ? A->data : NULL; }
+
 PetscErrorCode MatShellGetContext(Mat A, void **user) { if (!A || !user) SETERRQ(PETSC_ERR_ARG_NULL, "Null argument"); *user = A->data; return 0; }
 
 PetscErrorCode MatMult(Mat A, Vec x, Vec y) {

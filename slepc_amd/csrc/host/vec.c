@@ -39,7 +39,8 @@ PetscErrorCode VecCreateWithOps(const struct _VecOps *ops, void *ctx, PetscInt64
   if (n < 0 || N < n) SETERRQ(PETSC_ERR_ARG_OUTOFRANGE, "Invalid sizes: local %lld, global %lld", (long long)n, (long long)N);
   Vec x = (Vec)calloc(1, sizeof(*x));
   if (!x) SETERRQ(PETSC_ERR_MEM, "Out of memory");
-  x->ops = ops; x->ctx = ctx; x->n = n; x->N = N; x->row0 = row0;
+  static PetscInt64 next_id = 0;
+  x->ops = ops; x->ctx = ctx; x->n = n; x->N = N; x->row0 = row0; x->id = ++next_id;
   if (allocate) { ierr = ops->alloc(x); if (ierr) { free(x); CHKERRQ(ierr); } }
   *v = x;
   return 0;

@@ -779,6 +779,22 @@ extern "C" int ksg_bv_resize(ksg_bv bv, int m, int copy) {
   return KSG_OK;
 }
 
+/* The first nc of the nc+m columns held become constraints (BVInsertConstraints,
+ * bvfunc.c:433-439; BVSetNumConstraints, bvbasic.c:276-294): columns are then counted from
+ * the first regular one, constraints have the indices -nc..-1.  No data moves. */
+extern "C" int ksg_bv_set_num_constraints(ksg_bv bv, int nc) {
+  BV_CHECK(bv, "ksg_bv_set_num_constraints");
+  const int total = bv->nc + bv->m;
+  if (nc < 0 || nc >= total) KSG_FAIL(KSG_ERR_ARG, "ksg_bv_set_num_constraints: nc=%d with %d columns in all", nc, total);
+  if (nc == bv->nc) return KSG_OK;
+  KSG_HIP(hipSetDevice(bv->ctx->device));
+  KSG_CHK(ksg_flush_pending(bv->ctx));
+  bv->ctx->gen++;
+  bv->nc = nc; bv->m = total - nc;
+  bv->l = 0; bv->k = bv->m;
+  return KSG_OK;
+}
+
 extern "C" int ksg_bv_set_active(ksg_bv bv, int l, int k) {
   BV_CHECK(bv, "ksg_bv_set_active");
   if (l < -bv->nc || k > bv->m || l > k) KSG_FAIL(KSG_ERR_ARG, "ksg_bv_set_active: [%d,%d) invalid for m=%d", l, k, bv->m);

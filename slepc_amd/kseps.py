@@ -70,7 +70,7 @@ class VecOps(C.Structure):
 
 VecStruct._fields_ = [("ops", C.POINTER(VecOps)), ("n", c_i64), ("N", c_i64), ("row0", c_i64),
                       ("array", C.c_void_p), ("own", C.c_void_p), ("state", c_i64),
-                      ("ctx", C.c_void_p)]
+                      ("ctx", C.c_void_p), ("id", c_i64)]
 
 
 class MatStruct(C.Structure):
@@ -127,7 +127,9 @@ BVStruct._fields_ = [("ops", BVOps), ("type_name", C.c_char * 32), ("t", VecP), 
                      ("buffer", c_dp), ("h", c_dp), ("c", c_dp), ("cv", VecP * 2),
                      ("ci", C.c_int * 2), ("st", c_i64 * 2), ("state", c_i64),
                      ("rand_seed", C.c_uint64), ("data", C.c_void_p), ("ctx", C.c_void_p),
-                     ("orthog_block", C.c_int)]
+                     ("orthog_block", C.c_int), ("matrix", MatP), ("indef", C.c_int), ("Bx", VecP),
+                     ("xid", c_i64), ("xstate", c_i64), ("cached", BVP), ("bvstate", c_i64),
+                     ("omega", c_dp)]
 
 BVCREATE_FN = C.CFUNCTYPE(Err, BVP)
 COMPARE_FN = C.CFUNCTYPE(Err, C.c_double, C.c_double, C.c_double, C.c_double, C.POINTER(C.c_int),
@@ -177,6 +179,18 @@ SIGNATURES = {
     "BVGetSizes": (Err, [BVP, C.POINTER(c_i64), C.POINTER(c_i64), C.POINTER(C.c_int)]),
     "BVResize": (Err, [BVP, C.c_int, C.c_int]),
     "BVSetActiveColumns": (Err, [BVP, C.c_int, C.c_int]),
+    "BVInsertConstraints": (Err, [BVP, C.POINTER(C.c_int), C.POINTER(VecP)]),
+    "BVSetNumConstraints": (Err, [BVP, C.c_int]),
+    "BVGetNumConstraints": (Err, [BVP, C.POINTER(C.c_int)]),
+    "BVSetMatrix": (Err, [BVP, MatP, C.c_int]),
+    "BVGetMatrix": (Err, [BVP, C.POINTER(MatP), C.POINTER(C.c_int)]),
+    "BVApplyMatrix": (Err, [BVP, VecP, VecP]),
+    "BVApplyMatrixBV": (Err, [BVP, BVP]),
+    "BVGetCachedBV": (Err, [BVP, C.POINTER(BVP)]),
+    "BVSetSignature": (Err, [BVP, c_dp]),
+    "BVGetSignature": (Err, [BVP, c_dp]),
+    "BVDuplicate": (Err, [BVP, C.POINTER(BVP)]),
+    "BVDuplicateResize": (Err, [BVP, C.c_int, C.POINTER(BVP)]),
     "BVGetActiveColumns": (Err, [BVP, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "BVSetOrthogonalization": (Err, [BVP, C.c_int, C.c_int, C.c_double, C.c_int]),
     "BVOrthogonalize": (Err, [BVP, c_dp, C.c_int]),

@@ -83,6 +83,7 @@ SIGNATURES = {
     "ksg_bv_copy_column": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "ksg_bv_mult": (C.c_int, [C.c_void_p, C.c_double, C.c_double, C.c_void_p, c_dp, C.c_int]),
     "ksg_bv_dot": (C.c_int, [C.c_void_p, C.c_void_p, c_dp, C.c_int]),
+    "ksg_bv_set_num_constraints": (C.c_int, [C.c_void_p, C.c_int]),
     "ksg_bv_matmult": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "ksg_mat_create_csr": (C.c_int, [C.c_void_p, c_i64, c_i64, c_i64, C.c_void_p, C.c_void_p,
                                      C.c_void_p, C.POINTER(C.c_void_p)]),

@@ -349,6 +349,234 @@ def solve_eps(be, csr, hermitian=True, nev=1, ncv=0, mpd=0, tol=0.0, max_it=0, w
     return res
 
 
+def petsc_g(x):
+    """%g as PetscPrintf prints it: a value without fractional part gets a trailing dot."""
+    t = "%g" % x
+    return t if ("." in t or "e" in t or "n" in t) else t + "."
+
+
+def tridiag_csr(n):
+    """B = tridiag(-1, 2, -1) (bv tests test3.c:51-56, test11.c:119-124)."""
+    rp, ci, va = [0], [], []
+    for i in range(n):
+        for j, v in ((i - 1, -1.0), (i, 2.0), (i + 1, -1.0)):
+            if 0 <= j < n:
+                ci.append(j)
+                va.append(v)
+        rp.append(len(ci))
+    return np.array(rp, dtype=np.int64), np.array(ci, dtype=np.int32), np.array(va)
+
+
+def _level_of_orthogonality(M, target):
+    nrm = np.abs(M - target).sum(axis=0).max()          # MatNorm(M,NORM_1)
+    return "Level of orthogonality < 100*eps" if nrm < 100 * np.finfo(float).eps else "Level of orthogonality: %g" % nrm
+
+
+def run_bv_test3(be, otype=K.BV_ORTHOG_CGS):
+    """bv/examples/tests/test3.c (non-standard inner product) against output/test3_1.out."""
+    g = golden("bv_misc.json")["test3_lines"]
+    lib = be.lib
+    n, k = 10, 5
+    B = be.mat_csr(*tridiag_csr(n))
+    X = be.bv(n, k)
+    K.check(lib.BVSetOrthogonalization(X, otype, K.BV_ORTHOG_REFINE_IFNEEDED, 0.0, K.BV_ORTHOG_BLOCK_GS))
+    K.check(lib.BVSetMatrix(X, B.p, 0))
+    fill_test1(be, X, n, k)
+    out = []
+    nrm = C.c_double()
+    K.check(lib.BVNormColumn(X, 0, K.NORM_2, C.byref(nrm)))
+    out.append("B-Norm of X[0] = " + petsc_g(nrm.value))
+    for j in range(k):
+        K.check(lib.BVOrthogonalizeColumn(X, j, None, C.byref(nrm), None))
+        K.check(lib.BVScaleColumn(X, j, 1.0 / nrm.value))
+    M = np.zeros((k, k), order="F")
+    K.check(lib.BVDot(X, X, dp(M), k))
+    out.append(_level_of_orthogonality(M, np.eye(k)))
+    v = K.VecP()
+    K.check(lib.BVGetColumn(X, 0, C.byref(v)))
+    K.check(lib.BVNormVecBegin(X, v, K.NORM_1, C.byref(nrm)))
+    K.check(lib.BVNormVecEnd(X, v, K.NORM_1, C.byref(nrm)))
+    K.check(lib.BVRestoreColumn(X, 0, C.byref(v)))
+    out.append("B-Norm of X[0] = " + petsc_g(float("%.12g" % nrm.value)))
+    assert out == g, out
+    # the product really is the B-inner one
+    Q = be.to_numpy(X)
+    Bd = 2 * np.eye(n) - np.eye(n, k=1) - np.eye(n, k=-1)
+    assert np.abs(Q.T @ Bd @ Q - np.eye(k)).max() < 1e-13
+    be.destroy_bv(X)
+    B.destroy()
+
+
+def run_bv_test5(be):
+    """bv/examples/tests/test5.c (indefinite inner product, -bv_orthog_refine always) against
+    output/test5_1.out; the checks the program makes itself (BVApplyMatrix twice = identity for
+    the involutory permutation, BVApplyMatrixBV) are made too."""
+    g = golden("bv_misc.json")["test5_lines"]
+    lib = be.lib
+    n, k = 10, 5
+    rp = np.arange(n + 1, dtype=np.int64)
+    ci = np.arange(n - 1, -1, -1, dtype=np.int32)
+    B = be.mat_csr(rp, ci, np.ones(n))
+    X = be.bv(n, k)
+    K.check(lib.BVSetOrthogonalization(X, K.BV_ORTHOG_CGS, K.BV_ORTHOG_REFINE_ALWAYS, 0.0, K.BV_ORTHOG_BLOCK_GS))
+    K.check(lib.BVSetMatrix(X, B.p, 1))
+    for j in range(k):
+        col = -np.ones(n)
+        for i in range(4):
+            if i + j < n:
+                col[i + j] = 3 * i + j - 2
+        be.set_col(X, j, col)
+    X0 = be.to_numpy(X)
+    out = []
+    nrm = C.c_double()
+    K.check(lib.BVNormColumn(X, 0, K.NORM_2, C.byref(nrm)))
+    out.append("B-Norm of X[0] = " + petsc_g(nrm.value))
+    for j in range(k):
+        K.check(lib.BVOrthogonalizeColumn(X, j, None, C.byref(nrm), None))
+        K.check(lib.BVScaleColumn(X, j, 1.0 / nrm.value))
+    Y = K.BVP()
+    K.check(lib.BVDuplicate(X, C.byref(Y)))
+    K.check(lib.BVCopy(X, Y))
+    M = np.zeros((k, k), order="F")
+    K.check(lib.BVDot(Y, Y, dp(M), k))
+    omega = np.zeros(k)
+    K.check(lib.BVGetSignature(Y, dp(omega)))
+    assert set(omega) <= {-1.0, 1.0} and (omega < 0).any()
+    out.append(_level_of_orthogonality(M, np.diag(omega)))
+    assert out == g, out
+    K.check(lib.BVSetSignature(Y, dp(omega)))
+    om2 = np.zeros(k)
+    K.check(lib.BVGetSignature(Y, dp(om2)))
+    assert np.array_equal(om2, omega)
+    # BVApplyMatrix twice gives the vector back; BVApplyMatrixBV gives B*X
+    t, w = be.vec(n), be.vec(n)
+    v = K.VecP()
+    K.check(lib.BVGetColumn(X, 0, C.byref(v)))
+    K.check(lib.BVApplyMatrix(X, v, w.p))
+    K.check(lib.BVApplyMatrix(X, w.p, t.p))
+    K.check(lib.VecAXPY(t.p, -1.0, v))
+    K.check(lib.BVRestoreColumn(X, 0, C.byref(v)))
+    K.check(lib.VecNorm(t.p, K.NORM_2, C.byref(nrm)))
+    assert abs(nrm.value) <= 10 * np.finfo(float).eps
+    K.check(lib.BVApplyMatrixBV(X, Y))
+    Q = be.to_numpy(X)
+    assert np.array_equal(be.to_numpy(Y), Q[::-1, :])
+    # against the CPU restatement, column for column
+    from oracle import bv as obv
+    O = obv.BV(n, k)
+    O.array[:, :] = X0
+    O.orthog_ref = obv.REFINE_ALWAYS
+    O.set_matrix(lambda x: x[::-1].copy(), True)
+    for j in range(k):
+        onrm, _ = O.orthogonalize_column(j)
+        O.scale_column(j, 1.0 / onrm)
+    assert np.abs(Q - O.array).max() < 1e-13 and np.array_equal(O.get_signature(), omega)
+    t.destroy()
+    w.destroy()
+    be.destroy_bv(Y)
+    be.destroy_bv(X)
+    B.destroy()
+
+
+def run_bv_test6(be, otype=K.BV_ORTHOG_CGS, n=20, k=8, nc=2, dependent=False):
+    """bv/examples/tests/test6.c (orthogonalisation with constraints) against
+    output/test6_1.out; with ``dependent`` a repeated constraint must be dropped."""
+    g = golden("bv_misc.json")["test6_lines"]
+    lib = be.lib
+    X = be.bv(n, k)
+    K.check(lib.BVSetOrthogonalization(X, otype, K.BV_ORTHOG_REFINE_IFNEEDED, 0.0, K.BV_ORTHOG_BLOCK_GS))
+    cvecs, Cm = [], []
+    for j in range(nc):
+        c = np.zeros(n)
+        c[:(j if (dependent and j == nc - 1) else j + 1)] = 1.0
+        Cm.append(c)
+        v = be.vec(n)
+        K.check(lib.VecSetValuesHost(v.p, dp(c)))
+        cvecs.append(v)
+    arr = (K.VecP * nc)(*[v.p for v in cvecs])
+    ncio = C.c_int(nc)
+    K.check(lib.BVInsertConstraints(X, C.byref(ncio), arr))
+    assert ncio.value == (nc - 1 if dependent else nc)
+    got = C.c_int()
+    K.check(lib.BVGetNumConstraints(X, C.byref(got)))
+    assert got.value == ncio.value
+    assert lib.BVInsertConstraints(X, C.byref(ncio), arr) != 0          # only once
+    for v in cvecs:
+        v.destroy()
+    X0 = np.zeros((n, k))
+    for j in range(k):
+        for i in range(n // 2 + 1):
+            if i + j < n:
+                X0[i + j, j] = (3.0 * i + j - 2) / (2 * (i + j + 1))
+        be.set_col(X, j, X0[:, j])
+    nrm = C.c_double()
+    for j in range(k):
+        K.check(lib.BVOrthogonalizeColumn(X, j, None, C.byref(nrm), None))
+        K.check(lib.BVScaleColumn(X, j, 1.0 / nrm.value))
+    M = np.zeros((k, k), order="F")
+    K.check(lib.BVDot(X, X, dp(M), k))
+    assert [_level_of_orthogonality(M, np.eye(k))] == g
+    Q = be.to_numpy(X)
+    # the constraints are deflated, and reachable as columns -nc..-1
+    cons = np.stack([be.get_col(X, -1 - i) for i in range(ncio.value)], axis=1)
+    assert np.abs(cons.T @ Q).max() < 1e-14 and np.abs(cons.T @ cons - np.eye(ncio.value)).max() < 1e-14
+    assert np.abs(np.array(Cm).dot(Q)).max() < 1e-13
+    from oracle import bv as obv
+    O = obv.BV(n, k)
+    O.orthog_type = obv.MGS if otype == K.BV_ORTHOG_MGS else obv.CGS
+    assert O.insert_constraints(Cm) == ncio.value
+    O.array[:, O.nc:O.nc + k] = X0
+    for j in range(k):
+        onrm, _ = O.orthogonalize_column(j)
+        O.scale_column(j, 1.0 / onrm)
+    assert np.abs(Q - O.array[:, O.nc:O.nc + k]).max() < 1e-13
+    be.destroy_bv(X)
+
+
+def run_bv_test11_matrix(be, block, n=20, l=2, k=8):
+    """The second half of bv/examples/tests/test11.c: block orthogonalisation in the inner
+    product of B = tridiag(-1,2,-1), the cached B*X, against the last two lines of
+    output/test11_1.out."""
+    g = golden("bv_misc.json")["test11_lines"][1:]
+    lib = be.lib
+    B = be.mat_csr(*tridiag_csr(n))
+    X, Y = be.bv(n, k), be.bv(n, k)
+    for bv in (X, Y):
+        K.check(lib.BVSetOrthogonalization(bv, K.BV_ORTHOG_CGS, K.BV_ORTHOG_REFINE_IFNEEDED, 0.0, block))
+        for j in range(k):
+            col = np.zeros(n)
+            for i in range(n // 2 + 1):
+                if i + j < n:
+                    col[i + j] = (3.0 * i + j - 2) / (2 * (i + j + 1))
+            be.set_col(bv, j, col)
+        K.check(lib.BVSetActiveColumns(bv, l, k))
+    Z = K.BVP()
+    K.check(lib.BVDuplicate(X, C.byref(Z)))
+    K.check(lib.BVSetActiveColumns(Z, l, k))
+    K.check(lib.BVSetMatrix(X, B.p, 0))
+    K.check(lib.BVSetMatrix(Y, B.p, 0))
+    if block == K.BV_ORTHOG_BLOCK_GS:
+        for j in range(l):
+            K.check(lib.BVOrthonormalizeColumn(Y, j, 0, None, None))
+    K.check(lib.BVOrthogonalize(Y, None, 0))
+    cached = K.BVP()
+    K.check(lib.BVGetCachedBV(Y, C.byref(cached)))
+    K.check(lib.BVMatMult(X, B.p, Z))
+    K.check(lib.BVMult(Z, -1.0, 1.0, cached, None, 0))
+    nrm = C.c_double()
+    K.check(lib.BVNorm(Z, K.NORM_FROBENIUS, C.byref(nrm)))
+    out = ["Residual ||cached-BX|| < 100*eps" if nrm.value < 100 * np.finfo(float).eps else "Residual ||cached-BX||: %g" % nrm.value]
+    M = np.asfortranarray(np.eye(k))
+    K.check(lib.BVDot(Y, Y, dp(M), k))
+    out.append(_level_of_orthogonality(M, np.eye(k)))
+    assert out == g, out
+    assert lib.BVNorm(Y, K.NORM_FROBENIUS, C.byref(nrm)) != 0        # no matrix norm in a B-inner product
+    be.destroy_bv(Z)
+    be.destroy_bv(X)
+    be.destroy_bv(Y)
+    B.destroy()
+
+
 def run_bv_test11(be, block, n=20, l=2, k=8):
     """src/sys/classes/bv/examples/tests/test11.c with the standard inner product (golden
     output test11_1.out: "Level of orthogonality < 100*eps" for -bv_orthog_block gs and chol),

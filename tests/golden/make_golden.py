@@ -83,7 +83,9 @@ def bv_misc():
     g["test7_errors"] = re.findall(r"Norm of error: (\S+)", t)
     t = read("src/sys/classes/bv/examples/tests/output/test10_1.out")
     g["test10_lines"] = t.strip().splitlines()[1:]
-    dump("bv_misc.json", g, "src/sys/classes/bv/examples/tests/output/test{2,4,6,7,10,13}_1.out")
+    for t3 in ("test3", "test5", "test11"):
+        g[t3 + "_lines"] = read("src/sys/classes/bv/examples/tests/output/%s_1.out" % t3).strip().splitlines()[1:]
+    dump("bv_misc.json", g, "src/sys/classes/bv/examples/tests/output/test{2,3,4,5,6,7,10,11,13}_1.out")
 
 
 def ds_tests():

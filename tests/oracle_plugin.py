@@ -138,6 +138,9 @@ def vec_create(n, N=None, row0=0):
 def _obv(bvp):
     b = bvp.contents
     o = _bvs[b.data]
+    if o.nc != b.nc:                      # the interface layer owns nc (svec reads bv->nc at every op)
+        total = o.nc + o.m
+        o.nc, o.m = b.nc, total - b.nc
     o.l, o.k = b.l, b.k
     return o
 
@@ -237,7 +240,7 @@ def _b_resize(bv, m, copy):
 def _b_getcolumn(bv, j, v):
     b = bv.contents
     l = 0 if b.ci[0] == -b.nc - 1 else 1
-    col = _bvs[b.data].col(j)
+    col = _obv(bv).col(j)
     K.check(_lib.VecPlaceArray(b.cv[l], col.ctypes.data))
 
 

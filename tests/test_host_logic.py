@@ -188,6 +188,26 @@ def test_bv_test13(be):
     common.run_bv_test13(be)
 
 
+@pytest.mark.parametrize("otype", [K.BV_ORTHOG_CGS, K.BV_ORTHOG_MGS])
+def test_bv_test3_inner_product(be, otype):
+    common.run_bv_test3(be, otype)
+
+
+def test_bv_test5_indefinite(be):
+    common.run_bv_test5(be)
+
+
+@pytest.mark.parametrize("otype", [K.BV_ORTHOG_CGS, K.BV_ORTHOG_MGS])
+def test_bv_test6_constraints(be, otype):
+    common.run_bv_test6(be, otype)
+    common.run_bv_test6(be, otype, n=53, k=6, nc=3, dependent=True)
+
+
+@pytest.mark.parametrize("block", [K.BV_ORTHOG_BLOCK_GS, K.BV_ORTHOG_BLOCK_CHOL])
+def test_bv_test11_inner_product(be, block):
+    common.run_bv_test11_matrix(be, block)
+
+
 def test_split_phase_reductions(be):
     common.run_split_phase(be)
     common.run_split_phase(be, n=37, m=6)

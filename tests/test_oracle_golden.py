@@ -57,6 +57,88 @@ def test_bv_test2(otype):
     assert g["test2_lines"][0] == "Level of orthogonality < 100*eps"
 
 
+def _lvl(M, target):
+    nrm = np.abs(M - target).sum(axis=0).max()
+    return "Level of orthogonality < 100*eps" if nrm < 100 * EPS_MACH else "Level of orthogonality: %g" % nrm
+
+
+@pytest.mark.parametrize("otype", [obv.CGS, obv.MGS])
+def test_bv_test3_inner_product(otype):
+    """bv/examples/tests/test3.c against output/test3_1.out."""
+    from tests.common import petsc_g
+    g = golden("bv_misc.json")["test3_lines"]
+    n, k = 10, 5
+
+    def B(x):
+        y = 2.0 * x
+        y[1:] -= x[:-1]
+        y[:-1] -= x[1:]
+        return y
+    X = obv.BV(n, k)
+    X.orthog_type = otype
+    X.set_matrix(B)
+    for j in range(k):
+        for i in range(4):
+            if i + j < n:
+                X.col(j)[i + j] = 3 * i + j - 2
+    out = ["B-Norm of X[0] = " + petsc_g(X.norm_column(0))]
+    for j in range(k):
+        nrm, _ = X.orthogonalize_column(j)
+        X.scale_column(j, 1.0 / nrm)
+    M = np.zeros((k, k))
+    X.dot(X, M)
+    out.append(_lvl(M, np.eye(k)))
+    out.append("B-Norm of X[0] = " + petsc_g(float("%.12g" % X.norm_vec(X.col(0)))))
+    assert out == g
+
+
+def test_bv_test5_indefinite():
+    """bv/examples/tests/test5.c (-bv_orthog_refine always) against output/test5_1.out."""
+    from tests.common import petsc_g
+    g = golden("bv_misc.json")["test5_lines"]
+    n, k = 10, 5
+    X = obv.BV(n, k)
+    X.orthog_ref = obv.REFINE_ALWAYS
+    X.set_matrix(lambda x: x[::-1].copy(), True)
+    for j in range(k):
+        X.col(j)[:] = -1.0
+        for i in range(4):
+            if i + j < n:
+                X.col(j)[i + j] = 3 * i + j - 2
+    out = ["B-Norm of X[0] = " + petsc_g(X.norm_column(0))]
+    for j in range(k):
+        nrm, _ = X.orthogonalize_column(j)
+        X.scale_column(j, 1.0 / nrm)
+    M = np.zeros((k, k))
+    X.dot(X, M)
+    out.append(_lvl(M, np.diag(X.get_signature())))
+    assert out == g
+    w = X.apply_matrix(X.col(0))
+    assert np.array_equal(X.apply_matrix(w), X.col(0))
+
+
+@pytest.mark.parametrize("otype", [obv.CGS, obv.MGS])
+def test_bv_test6_constraints(otype):
+    """bv/examples/tests/test6.c against output/test6_1.out."""
+    g = golden("bv_misc.json")["test6_lines"]
+    n, k, nc = 20, 8, 2
+    X = obv.BV(n, k)
+    X.orthog_type = otype
+    C = [np.r_[np.ones(j + 1), np.zeros(n - j - 1)] for j in range(nc)]
+    assert X.insert_constraints(C) == nc
+    for j in range(k):
+        for i in range(n // 2 + 1):
+            if i + j < n:
+                X.col(j)[i + j] = (3.0 * i + j - 2) / (2 * (i + j + 1))
+    for j in range(k):
+        nrm, _ = X.orthogonalize_column(j)
+        X.scale_column(j, 1.0 / nrm)
+    M = np.zeros((k, k))
+    X.dot(X, M)
+    assert [_lvl(M, np.eye(k))] == g
+    assert np.abs(np.array(C) @ X.array[:, nc:]).max() < 1e-14
+
+
 def test_bv_test13():
     g = golden("bv_misc.json")
     n, k = 10, 5
