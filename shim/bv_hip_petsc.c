@@ -25,7 +25,9 @@
 typedef struct { ksg_ctx ctx; ksg_bv bv; } BV_HIP;
 
 #define KSG(call) do { if ((call)) SETERRQ1(PETSC_COMM_SELF,PETSC_ERR_LIB,"libksgpu: %s",ksg_last_error()); } while (0)
-#define SYNC(bv) KSG(ksg_bv_set_active(((BV_HIP*)(bv)->data)->bv,(bv)->l,(bv)->k))
+/* SLEPc's interface layer owns nc, l and k (svec reads them from the BV at every op) */
+#define SYNC(bv) do { KSG(ksg_bv_set_num_constraints(((BV_HIP*)(bv)->data)->bv,(int)(bv)->nc)); \
+                      KSG(ksg_bv_set_active(((BV_HIP*)(bv)->data)->bv,(int)(bv)->l,(int)(bv)->k)); } while (0)
 
 static PetscErrorCode BVDotVec_HIP(BV X,Vec y,PetscScalar *q)
 {
@@ -33,13 +35,18 @@ static PetscErrorCode BVDotVec_HIP(BV X,Vec y,PetscScalar *q)
   BV_HIP            *x = (BV_HIP*)X->data;
   const PetscScalar *py;
   PetscScalar       *qq = q;
+  Vec               z = y;
 
   PetscFunctionBegin;
   SYNC(X);
+  if (X->matrix) {                                                   /* svec.c:131-134: B-inner product */
+    ierr = BV_IPMatMult(X,y);CHKERRQ(ierr);
+    z = X->Bx;
+  }
   if (!q) { ierr = VecGetArray(X->buffer,&qq);CHKERRQ(ierr); }      /* svec.c:137 */
-  ierr = VecHIPGetArrayRead(y,&py);CHKERRQ(ierr);
+  ierr = VecHIPGetArrayRead(z,&py);CHKERRQ(ierr);
   KSG(ksg_bv_dotvec(x->bv,py,qq));                                  /* reduction included */
-  ierr = VecHIPRestoreArrayRead(y,&py);CHKERRQ(ierr);
+  ierr = VecHIPRestoreArrayRead(z,&py);CHKERRQ(ierr);
   if (!q) { ierr = VecRestoreArray(X->buffer,&qq);CHKERRQ(ierr); }
   PetscFunctionReturn(0);
 }
@@ -160,12 +167,56 @@ static PetscErrorCode BVDotVec_Local_HIP(BV X,Vec y,PetscScalar *m)
 {
   PetscErrorCode    ierr;
   const PetscScalar *py;
+  Vec               z = y;
 
   PetscFunctionBegin;
   SYNC(X);
-  ierr = VecHIPGetArrayRead(y,&py);CHKERRQ(ierr);
+  if (X->matrix) {                                                   /* svec.c:153-156 */
+    ierr = BV_IPMatMult(X,y);CHKERRQ(ierr);
+    z = X->Bx;
+  }
+  ierr = VecHIPGetArrayRead(z,&py);CHKERRQ(ierr);
   KSG(ksg_bv_dotvec_local(((BV_HIP*)X->data)->bv,py,m));            /* svec.c:145-163: no reduction */
-  ierr = VecHIPRestoreArrayRead(y,&py);CHKERRQ(ierr);
+  ierr = VecHIPRestoreArrayRead(z,&py);CHKERRQ(ierr);
+  PetscFunctionReturn(0);
+}
+
+/* Split phase (ops->dotvec_begin / dotvec_end, bvimpl.h:43-44, called from bvglobal.c:223-224,
+   272-273 in place of PETSc's PetscSplitReduction): the kernel is queued into the batch of
+   the context, which the device Vec type opens on its first VecDotBegin/VecNormBegin or here,
+   and the first ...End of the group closes it with one all-reduce (ksg_red_close); the values
+   are handed out in posting order.  KSGRedPost/KSGRedFetch stand for that bookkeeping, shared
+   with the Vec type (a per-communicator queue of {offset,count} as PetscSplitReduction keeps). */
+PETSC_EXTERN PetscErrorCode KSGRedPost(MPI_Comm,ksg_ctx,PetscInt offset,PetscInt count);
+PETSC_EXTERN PetscErrorCode KSGRedFetch(MPI_Comm,ksg_ctx,PetscInt count,PetscScalar *out);
+
+static PetscErrorCode BVDotVec_Begin_HIP(BV X,Vec y,PetscScalar *m)
+{
+  PetscErrorCode    ierr;
+  BV_HIP            *x = (BV_HIP*)X->data;
+  const PetscScalar *py;
+  Vec               z = y;
+  int               offset;
+
+  PetscFunctionBegin;
+  SYNC(X);
+  if (X->matrix) {
+    ierr = BV_IPMatMult(X,y);CHKERRQ(ierr);
+    z = X->Bx;
+  }
+  ierr = VecHIPGetArrayRead(z,&py);CHKERRQ(ierr);
+  KSG(ksg_red_post_dotvec(x->bv,py,&offset));
+  ierr = VecHIPRestoreArrayRead(z,&py);CHKERRQ(ierr);
+  ierr = KSGRedPost(PetscObjectComm((PetscObject)X),x->ctx,offset,X->k-X->l);CHKERRQ(ierr);
+  PetscFunctionReturn(0);
+}
+
+static PetscErrorCode BVDotVec_End_HIP(BV X,Vec y,PetscScalar *m)
+{
+  PetscErrorCode ierr;
+
+  PetscFunctionBegin;
+  ierr = KSGRedFetch(PetscObjectComm((PetscObject)X),((BV_HIP*)X->data)->ctx,X->k-X->l,m);CHKERRQ(ierr);
   PetscFunctionReturn(0);
 }
 
@@ -305,6 +356,8 @@ PETSC_EXTERN PetscErrorCode BVCreate_HIP(BV bv)
   bv->ops->dot              = BVDot_HIP;
   bv->ops->dotvec           = BVDotVec_HIP;
   bv->ops->dotvec_local     = BVDotVec_Local_HIP;
+  bv->ops->dotvec_begin     = BVDotVec_Begin_HIP;
+  bv->ops->dotvec_end       = BVDotVec_End_HIP;
   bv->ops->scale            = BVScale_HIP;
   bv->ops->norm             = BVNorm_HIP;
   bv->ops->norm_local       = BVNorm_Local_HIP;
