@@ -67,8 +67,15 @@ void *ksg_ctx_stream(ksg_ctx ctx);
  * store of the column.  Any other call that touches device data applies what is pending
  * first.  The stored values are bit for bit those of separate launches.
  * KSG_OPT_DOT_GRID / KSG_OPT_MV_GRID: upper bound on the workgroups along the rows of
- * the reduction (default 256, one per CU) and update (default 1024) kernels. */
-enum { KSG_OPT_FUSE_DOTS = 1, KSG_OPT_DOT_GRID = 2, KSG_OPT_MV_GRID = 3, KSG_OPT_LAZY_UPDATE = 4 };
+ * the reduction (default 256, one per CU) and update (default 1024) kernels.
+ * KSG_OPT_HOT_COLS (default 262144 = 2 MiB of x, half of one XCD's L2; 0 disables): a CSR
+ * operator created afterwards whose local column block has more than four times that many
+ * columns, with columns referenced at least four times as often as the average that together
+ * hold 15 % or more of the entries (power-law graphs), keeps a packed copy of the x entries of
+ * its most referenced columns: each product gathers them into a dense array that stays in L2,
+ * and the matrix entries of those columns index it instead of x.  Same values, same order
+ * of sums: results are bit for bit those without the packing. */
+enum { KSG_OPT_FUSE_DOTS = 1, KSG_OPT_DOT_GRID = 2, KSG_OPT_MV_GRID = 3, KSG_OPT_LAZY_UPDATE = 4, KSG_OPT_HOT_COLS = 5 };
 int ksg_ctx_set_option(ksg_ctx ctx, int option, int value);
 const char *ksg_last_error(void);
 
@@ -217,6 +224,8 @@ int ksg_mat_sizes(ksg_mat A, int64_t *n_local, int64_t *N, int64_t *row0, int64_
  * stream path, the grouped (several lanes per row) path and the long-row path,
  * and the number of ghost entries received per multiply. */
 int ksg_mat_info(ksg_mat A, int64_t info[4]);
+/* number of columns whose x entries the operator keeps packed (KSG_OPT_HOT_COLS), 0 if none */
+int ksg_mat_hot_columns(ksg_mat A, int64_t *nhot);
 
 /* --------------------------------------------------------- statistics */
 /* Events, named after the reference's PetscLog events (bvfunc.c:78-93,

@@ -39,6 +39,7 @@ extern "C" int ksg_ctx_create(int device, ksg_ctx *out) {
   c->gen = 0;
   c->fuse_dots = 1;
   c->lazy_update = 1;
+  c->hot_cols = 262144;
   c->pend.active = false;
   c->dot_grid = KSG_DOT_GRID;
   c->mv_grid = KSG_MV_GRID;
@@ -78,6 +79,10 @@ extern "C" int ksg_ctx_set_option(ksg_ctx c, int option, int value) {
   switch (option) {
     case KSG_OPT_FUSE_DOTS: KSG_CHK(ksg_flush_pending(c)); c->fuse_dots = value ? 1 : 0; c->spec.valid = false; return KSG_OK;
     case KSG_OPT_LAZY_UPDATE: KSG_CHK(ksg_flush_pending(c)); c->lazy_update = value ? 1 : 0; return KSG_OK;
+    case KSG_OPT_HOT_COLS:
+      if (value < 0) KSG_FAIL(KSG_ERR_ARG, "ksg_ctx_set_option: negative size");
+      c->hot_cols = value;
+      return KSG_OK;
     case KSG_OPT_DOT_GRID:
     case KSG_OPT_MV_GRID:
       if (value < 1 || value > 65535) KSG_FAIL(KSG_ERR_ARG, "ksg_ctx_set_option: grid %d out of range", value);

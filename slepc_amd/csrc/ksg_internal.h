@@ -76,6 +76,7 @@ struct ksg_ctx_s {
   int dot_grid, mv_grid;     /* row workgroups of the reduction / update kernels */
   ksg_pending pend;
   int lazy_update;           /* 0: never defer the store of a Gram-Schmidt update */
+  int hot_cols;              /* most x entries a new operator may keep packed (0: none) */
   /* communicator */
   int comm_kind, rank, nranks, cb_on_device;
   void *rccl_comm;
@@ -114,7 +115,12 @@ struct ksg_mat_s {
   int64_t nc, NC, col0;      /* column layout: x has nc local entries, columns [col0,col0+nc) are local */
   std::vector<int64_t> cstarts;  /* first column of every rank, nranks+1 (empty with one rank) */
   std::vector<int32_t> ghosts;   /* global column of every ghost-buffer slot */
-  ksg_csr_dev diag;          /* columns local (col - col0)                     */
+  ksg_csr_dev diag;          /* columns local (col - col0); entries of a packed column: nc + its slot */
+  /* packed copy of the x entries of the most referenced columns (power-law operators) */
+  int64_t nhot;
+  std::vector<int32_t> hot_cols; /* local column of every slot                  */
+  int32_t *d_hot_idx;        /* the same on the device                         */
+  double *d_xhot;            /* nhot doubles, refreshed by every product       */
   /* ghost block: only rows that have ghost entries */
   int64_t no_rows;           /* number of such rows                            */
   int32_t *o_rows;           /* their local row indices                        */

@@ -57,7 +57,19 @@ __device__ __forceinline__ void spmv_emit(double s, int row, const double *__res
   }
 }
 
-template <int RES>
+/* The x entry a matrix entry multiplies: with HOT, column indices from nx on are slots of the
+ * packed array xh (the most referenced columns of a power-law operator, dense so that they
+ * stay in L2) */
+template <int HOT>
+__device__ __forceinline__ double x_entry(const double *__restrict__ x, const double *__restrict__ xh, int32_t nx, int32_t ci) {
+  if (HOT) {
+    const double *b = ci >= nx ? xh : x;
+    return b[ci >= nx ? ci - nx : ci];
+  }
+  return x[ci];
+}
+
+template <int RES, int HOT>
 __global__ __launch_bounds__(KSG_BLOCK) void k_spmv_tiles(const int32_t *__restrict__ tiles,
                                                            const int64_t *__restrict__ tile_p,
                                                            const int64_t *__restrict__ rowptr,
@@ -66,7 +78,8 @@ __global__ __launch_bounds__(KSG_BLOCK) void k_spmv_tiles(const int32_t *__restr
                                                            const double *__restrict__ x,
                                                            double *__restrict__ y, double kr, double ki,
                                                            const double *__restrict__ xi,
-                                                           double *__restrict__ partial) {
+                                                           double *__restrict__ partial,
+                                                           const double *__restrict__ xh, int32_t nx) {
   __shared__ double prod[KSG_TILE_NNZ];
   __shared__ double red[KSG_BLOCK / 64];
   double acc = 0.0;
@@ -93,14 +106,14 @@ __global__ __launch_bounds__(KSG_BLOCK) void k_spmv_tiles(const int32_t *__restr
 #pragma unroll
       for (int i = 0; i < 8; i++) fence_i(ci[i]);
 #pragma unroll
-      for (int i = 0; i < 8; i++) xv[i] = x[ci[i]];
+      for (int i = 0; i < 8; i++) xv[i] = x_entry<HOT>(x, xh, nx, ci[i]);
 #pragma unroll
       for (int i = 0; i < 8; i++) fence_d(xv[i]);
 #pragma unroll
       for (int i = 0; i < 8; i++) a = fma(v[i], xv[i], a);
     }
     for (; p < p1; p += KSG_BLOCK)
-      a = fma(__builtin_nontemporal_load(val + p), x[__builtin_nontemporal_load(colidx + p)], a);
+      a = fma(__builtin_nontemporal_load(val + p), x_entry<HOT>(x, xh, nx, __builtin_nontemporal_load(colidx + p)), a);
     a = wave_sum_width(a, 64);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = a;
     __syncthreads();
@@ -143,7 +156,7 @@ __global__ __launch_bounds__(KSG_BLOCK) void k_spmv_tiles(const int32_t *__restr
     for (int i = 0; i < KSG_TILE_PER_THREAD; i++) {
       const int t = threadIdx.x + i * KSG_BLOCK;
       xv[i] = 0.0;
-      if (t < n_) xv[i] = x[ci[i]];
+      if (t < n_) xv[i] = x_entry<HOT>(x, xh, nx, ci[i]);
     }
 #pragma unroll
     for (int i = 0; i < KSG_TILE_PER_THREAD; i++) fence_d(xv[i]);
@@ -402,6 +415,37 @@ static int upload(T **dst, const T *src, size_t count) {
   return KSG_OK;
 }
 
+/* Chooses the columns whose x entries are kept packed (see KSG_OPT_HOT_COLS): those referenced
+ * at least four times as often as the average, the most referenced first, at most `maxhot`,
+ * and only when they hold 15 % of the entries and x is much larger than the packed array.
+ * On success `hot` lists them and `relabeled` is a copy of colidx in which their entries carry
+ * ncols + slot; both stay empty when nothing is packed. */
+static void choose_hot_columns(int64_t ncols, int64_t nnz, const int32_t *colidx, int64_t maxhot,
+                               std::vector<int32_t> &hot, std::vector<int32_t> &relabeled) {
+  hot.clear(); relabeled.clear();
+  if (maxhot <= 0 || ncols <= 4 * maxhot || nnz == 0 || ncols + maxhot > (int64_t)INT32_MAX) return;
+  std::vector<int32_t> cnt((size_t)ncols, 0);
+  for (int64_t p = 0; p < nnz; p++) cnt[colidx[p]]++;
+  const int64_t thresh = std::max<int64_t>(8, 4 * ((nnz + ncols - 1) / ncols));
+  for (int64_t j = 0; j < ncols; j++) if (cnt[j] >= thresh) hot.push_back((int32_t)j);
+  /* most referenced first; ties by column, so that every run packs alike */
+  std::sort(hot.begin(), hot.end(), [&](int32_t a, int32_t b) { return cnt[a] != cnt[b] ? cnt[a] > cnt[b] : a < b; });
+  if ((int64_t)hot.size() > maxhot) hot.resize((size_t)maxhot);
+  int64_t covered = 0;
+  for (size_t h = 0; h < hot.size(); h++) covered += cnt[hot[h]];
+  if (hot.empty() || covered * 100 < nnz * 15) { hot.clear(); return; }
+  std::vector<int32_t> slot((size_t)ncols, -1);
+  for (size_t h = 0; h < hot.size(); h++) slot[hot[h]] = (int32_t)h;
+  relabeled.resize((size_t)nnz);
+  for (int64_t p = 0; p < nnz; p++) {
+    const int32_t s = slot[colidx[p]];
+    relabeled[p] = s >= 0 ? (int32_t)(ncols + s) : colidx[p];
+  }
+}
+
+/* decides on the packing for the diagonal block of A and uploads it */
+static int diag_to_device(ksg_mat A, int64_t nrows, const int64_t *rowptr, const int32_t *colidx, const double *val);
+
 static int csr_to_device(ksg_csr_dev *D, int64_t nrows, const int64_t *rowptr, const int32_t *colidx,
                          const double *val) {
   D->nrows = nrows;
@@ -417,6 +461,18 @@ static int csr_to_device(ksg_csr_dev *D, int64_t nrows, const int64_t *rowptr, c
   for (size_t i = 0; i < tiles.size(); i++) tile_p[i] = rowptr[tiles[i]];
   KSG_CHK(upload(&D->tile_p, tile_p.data(), tile_p.size()));
   return KSG_OK;
+}
+
+static int diag_to_device(ksg_mat A, int64_t nrows, const int64_t *rowptr, const int32_t *colidx, const double *val) {
+  std::vector<int32_t> relabeled;
+  choose_hot_columns(A->nc, rowptr[nrows], colidx, A->ctx->hot_cols, A->hot_cols, relabeled);
+  A->nhot = (int64_t)A->hot_cols.size();
+  if (A->nhot) {
+    KSG_CHK(upload(&A->d_hot_idx, A->hot_cols.data(), A->hot_cols.size()));
+    hipError_t e = hipMalloc(&A->d_xhot, (size_t)A->nhot * sizeof(double));
+    if (e != hipSuccess) KSG_FAIL(KSG_ERR_MEM, "matrix upload: %zu bytes: %s", (size_t)A->nhot * sizeof(double), hipGetErrorString(e));
+  }
+  return csr_to_device(&A->diag, nrows, rowptr, A->nhot ? relabeled.data() : colidx, val);
 }
 
 static void csr_free(ksg_csr_dev *D) {
@@ -469,13 +525,14 @@ static int mat_create(ksg_ctx c, int64_t n, int64_t N, int64_t row0, int64_t nc,
   A->no_rows = 0; A->o_rows = NULL; A->o_rowptr = NULL; A->o_colidx = NULL; A->o_val = NULL; A->o_nnz = 0;
   A->nghost = A->nsend = 0;
   A->d_ghost = A->d_send = A->h_ghost = A->h_send = NULL; A->d_send_idx = NULL;
+  A->nhot = 0; A->d_hot_idx = NULL; A->d_xhot = NULL;
   const int P = c->nranks;
   int rc = KSG_OK;
 
   if (P == 1) {
     if (row0 != 0 || n != N || col0 != 0 || nc != NC) { delete A; KSG_FAIL(KSG_ERR_ARG, "ksg_mat_create_csr: one rank must own all rows and columns"); }
-    rc = csr_to_device(&A->diag, n, rowptr, colidx, val);
-    if (rc) { csr_free(&A->diag); delete A; return rc; }
+    rc = diag_to_device(A, n, rowptr, colidx, val);
+    if (rc) { ksg_mat_destroy(A); return rc; }
     *out = A;
     return KSG_OK;
   }
@@ -552,7 +609,7 @@ static int mat_create(ksg_ctx c, int64_t n, int64_t N, int64_t row0, int64_t nc,
   }
 
   /* ---- upload ---- */
-  rc = csr_to_device(&A->diag, n, d_rp.data(), d_ci.data(), d_v.data());
+  rc = diag_to_device(A, n, d_rp.data(), d_ci.data(), d_v.data());
   A->no_rows = (int64_t)o_rows.size();
   A->o_nnz = (int64_t)o_ci.size();
   if (!rc) rc = upload(&A->o_rows, o_rows.data(), o_rows.size());
@@ -610,6 +667,7 @@ static int mat_to_host(ksg_mat A, std::vector<int64_t> &rp, std::vector<int32_t>
     KSG_CHK(download(drp, A->diag.rowptr, (size_t)A->n + 1));
     KSG_CHK(download(dci, A->diag.colidx, (size_t)A->diag.nnz));
     KSG_CHK(download(dva, A->diag.val, (size_t)A->diag.nnz));
+    if (A->nhot) for (size_t p = 0; p < dci.size(); p++) if ((int64_t)dci[p] >= A->nc) dci[p] = A->hot_cols[(size_t)((int64_t)dci[p] - A->nc)];
   } else {
     drp.assign((size_t)A->n + 1, 0);
   }
@@ -728,6 +786,8 @@ extern "C" int ksg_mat_destroy(ksg_mat A) {
   if (A->o_colidx) hipFree(A->o_colidx);
   if (A->o_val) hipFree(A->o_val);
   if (A->d_send_idx) hipFree(A->d_send_idx);
+  if (A->d_hot_idx) hipFree(A->d_hot_idx);
+  if (A->d_xhot) hipFree(A->d_xhot);
   if (A->d_ghost) hipFree(A->d_ghost);
   if (A->d_send) hipFree(A->d_send);
   if (A->h_ghost) hipHostFree(A->h_ghost);
@@ -742,6 +802,12 @@ extern "C" int ksg_mat_sizes(ksg_mat A, int64_t *n, int64_t *N, int64_t *row0, i
   if (N) *N = A->N;
   if (row0) *row0 = A->row0;
   if (nnz) *nnz = A->nnz;
+  return KSG_OK;
+}
+
+extern "C" int ksg_mat_hot_columns(ksg_mat A, int64_t *nhot) {
+  if (!A || !nhot) KSG_FAIL(KSG_ERR_ARG, "ksg_mat_hot_columns: NULL argument");
+  *nhot = A->nhot;
   return KSG_OK;
 }
 
@@ -763,10 +829,15 @@ static int mat_mult_raw(ksg_mat A, const double *x, double *y) {
     if (A->nsend)
       hipLaunchKernelGGL(k_gather, dim3(ksg_grid_for(A->nsend)), dim3(KSG_BLOCK), 0, c->comm_stream, x, A->d_send_idx, A->d_send, A->nsend);
   }
-  if (A->diag.ntiles)
-    hipLaunchKernelGGL(k_spmv_tiles<0>, dim3((unsigned)A->diag.ntiles), dim3(KSG_BLOCK), 0, c->stream,
+  if (A->diag.ntiles && A->nhot) {
+    hipLaunchKernelGGL(k_gather, dim3(ksg_grid_for(A->nhot)), dim3(KSG_BLOCK), 0, c->stream, x, A->d_hot_idx, A->d_xhot, A->nhot);
+    hipLaunchKernelGGL((k_spmv_tiles<0, 1>), dim3((unsigned)A->diag.ntiles), dim3(KSG_BLOCK), 0, c->stream,
                        A->diag.tiles, A->diag.tile_p, A->diag.rowptr, A->diag.colidx, A->diag.val, x, y, 0.0, 0.0,
-                       (const double *)NULL, (double *)NULL);
+                       (const double *)NULL, (double *)NULL, (const double *)A->d_xhot, (int32_t)A->nc);
+  } else if (A->diag.ntiles)
+    hipLaunchKernelGGL((k_spmv_tiles<0, 0>), dim3((unsigned)A->diag.ntiles), dim3(KSG_BLOCK), 0, c->stream,
+                       A->diag.tiles, A->diag.tile_p, A->diag.rowptr, A->diag.colidx, A->diag.val, x, y, 0.0, 0.0,
+                       (const double *)NULL, (double *)NULL, (const double *)NULL, (int32_t)0);
   KSG_HIP(hipGetLastError());
   if (halo) {
     KSG_CHK(ksg_comm_exchange(c, A));
@@ -811,8 +882,15 @@ extern "C" int ksg_mat_residual_norm(ksg_mat A, double kr, double ki, const doub
     nb = (int)A->diag.ntiles;
     if (nb) {
       KSG_CHK(ksg_ensure_partial(c, (size_t)nb));
-      hipLaunchKernelGGL(k_spmv_tiles<1>, dim3((unsigned)nb), dim3(KSG_BLOCK), 0, c->stream, A->diag.tiles, A->diag.tile_p,
-                         A->diag.rowptr, A->diag.colidx, A->diag.val, x, (double *)NULL, kr, ki, xi, c->d_partial);
+      if (A->nhot) {
+        hipLaunchKernelGGL(k_gather, dim3(ksg_grid_for(A->nhot)), dim3(KSG_BLOCK), 0, c->stream, x, A->d_hot_idx, A->d_xhot, A->nhot);
+        hipLaunchKernelGGL((k_spmv_tiles<1, 1>), dim3((unsigned)nb), dim3(KSG_BLOCK), 0, c->stream, A->diag.tiles, A->diag.tile_p,
+                           A->diag.rowptr, A->diag.colidx, A->diag.val, x, (double *)NULL, kr, ki, xi, c->d_partial,
+                           (const double *)A->d_xhot, (int32_t)A->nc);
+      } else
+        hipLaunchKernelGGL((k_spmv_tiles<1, 0>), dim3((unsigned)nb), dim3(KSG_BLOCK), 0, c->stream, A->diag.tiles, A->diag.tile_p,
+                           A->diag.rowptr, A->diag.colidx, A->diag.val, x, (double *)NULL, kr, ki, xi, c->d_partial,
+                           (const double *)NULL, (int32_t)0);
     }
   } else {
     KSG_CHK(mat_mult_raw(A, x, work));
@@ -844,7 +922,7 @@ extern "C" int ksg_bv_matmult(ksg_bv V, ksg_mat A, ksg_bv W) {
   KSG_CHK(ksg_op_begin(c, KSG_EV_MATMULT));
   const double *X = V->d + (int64_t)(V->nc + V->l) * V->ld;
   double *Y = W->d + (int64_t)(W->nc + W->l) * W->ld;
-  if (c->nranks == 1 && nc > 1 && A->diag.ntiles) {
+  if (c->nranks == 1 && nc > 1 && A->diag.ntiles && !A->nhot) {
     /* one pass over the matrix for all the columns */
     hipLaunchKernelGGL(k_spmm_tiles<8>, dim3((unsigned)A->diag.ntiles), dim3(KSG_BLOCK), 0, c->stream, A->diag.tiles,
                        A->diag.tile_p, A->diag.rowptr, A->diag.colidx, A->diag.val, X, V->ld, Y, W->ld, nc);
@@ -852,7 +930,7 @@ extern "C" int ksg_bv_matmult(ksg_bv V, ksg_mat A, ksg_bv W) {
     const double bytes = 12.0 * (double)A->nnz + 8.0 * (double)(A->n + 1) + 8.0 * nc * (double)(A->nc + A->n);
     return ksg_op_end(c, KSG_EV_MATMULT, bytes, 2.0 * nc * (double)A->nnz);
   }
-  /* several ranks: column by column, each product with its halo exchange */
+  /* several ranks, or packed x entries: column by column, each product with its halo exchange */
   for (int j = 0; j < nc; j++) KSG_CHK(mat_mult_raw(A, X + (int64_t)j * V->ld, Y + (int64_t)j * W->ld));
   return ksg_op_end(c, KSG_EV_MATMULT, nc * spmv_bytes(A), 2.0 * nc * (double)A->nnz);
 }

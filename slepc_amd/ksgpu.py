@@ -83,6 +83,7 @@ SIGNATURES = {
     "ksg_bv_copy_column": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "ksg_bv_mult": (C.c_int, [C.c_void_p, C.c_double, C.c_double, C.c_void_p, c_dp, C.c_int]),
     "ksg_bv_dot": (C.c_int, [C.c_void_p, C.c_void_p, c_dp, C.c_int]),
+    "ksg_mat_hot_columns": (C.c_int, [C.c_void_p, C.POINTER(c_i64)]),
     "ksg_bv_set_num_constraints": (C.c_int, [C.c_void_p, C.c_int]),
     "ksg_bv_matmult": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "ksg_mat_create_csr": (C.c_int, [C.c_void_p, c_i64, c_i64, c_i64, C.c_void_p, C.c_void_p,
@@ -140,6 +141,7 @@ OPT_FUSE_DOTS = 1
 OPT_DOT_GRID = 2
 OPT_MV_GRID = 3
 OPT_LAZY_UPDATE = 4
+OPT_HOT_COLS = 5
 
 
 class Context:
@@ -415,6 +417,11 @@ class DeviceCSR:
         r = C.c_double()
         check(self.lib.ksg_mat_residual_norm(self.h, kr, ki, x_dev, xi_dev, work_dev, C.byref(r)))
         return r.value
+
+    def hot_columns(self):
+        n = c_i64()
+        check(self.lib.ksg_mat_hot_columns(self.h, C.byref(n)))
+        return n.value
 
     def info(self):
         a = (c_i64 * 4)()

@@ -170,3 +170,62 @@ def test_block_product_equals_column_products(gpu_ctx, gen):
     gpu_ctx.vec_free(yd)
     for o in (A, V, W):
         o.destroy()
+
+
+def test_packed_hot_columns_bit_exact(gpu_ctx):
+    """A power-law operator with the x entries of its most referenced columns packed
+    (KSG_OPT_HOT_COLS): the product, the store-free residual, the block product, the CSR read
+    back and the transpose are bit for bit those of the same operator without the packing."""
+    from slepc_amd import ksgpu, matgen as mg
+    ctx = gpu_ctx
+    rp, ci, va = mg.rmat_laplacian(15, 8, seed=7)
+    n = len(rp) - 1
+    rng = np.random.default_rng(2)
+    x = rng.standard_normal(n)
+    xd, yd, zd = ctx.vec_alloc(n), ctx.vec_alloc(n), ctx.vec_alloc(n)
+    ctx.upload(xd, x)
+    ctx.set_option(ksgpu.OPT_HOT_COLS, 0)
+    A0 = ksgpu.DeviceCSR(ctx, rp, ci, va)
+    assert A0.hot_columns() == 0
+    ctx.set_option(ksgpu.OPT_HOT_COLS, 1024)
+    A1 = ksgpu.DeviceCSR(ctx, rp, ci, va)
+    ctx.set_option(ksgpu.OPT_HOT_COLS, 262144)
+    nhot = A1.hot_columns()
+    assert 0 < nhot <= 1024
+    # a stencil has no hot columns whatever the limit
+    ctx.set_option(ksgpu.OPT_HOT_COLS, 64)
+    L = ksgpu.DeviceCSR(ctx, *mg.laplacian2d(60, 60))
+    ctx.set_option(ksgpu.OPT_HOT_COLS, 262144)
+    assert L.hot_columns() == 0
+    L.destroy()
+    A0.mult(xd, yd)
+    ctx.upload(zd, np.full(n, np.nan))
+    A1.mult(xd, zd)
+    y0, y1 = ctx.download(yd, n), ctx.download(zd, n)
+    assert np.array_equal(y0, y1)
+    from scipy.sparse import csr_matrix
+    ref = csr_matrix((va, ci, rp), shape=(n, n)) @ x
+    assert np.abs(y1 - ref).max() <= 1e-12 * np.abs(ref).max()
+    # a second product after x changed picks the new hot entries up
+    x2 = rng.standard_normal(n)
+    ctx.upload(xd, x2)
+    A0.mult(xd, yd)
+    A1.mult(xd, zd)
+    assert np.array_equal(ctx.download(yd, n), ctx.download(zd, n))
+    assert A0.residual_norm(1.75, 0.0, xd) == A1.residual_norm(1.75, 0.0, xd)
+    r0, c0, v0 = A0.get_csr()
+    r1, c1, v1 = A1.get_csr()
+    assert np.array_equal(r0, r1) and np.array_equal(c0, c1) and np.array_equal(v0, v1) and np.array_equal(c1, ci)
+    T0, T1 = A0.transpose(), A1.transpose()
+    for a, b in zip(T0.get_csr(), T1.get_csr()):
+        assert np.array_equal(a, b)
+    m = 5
+    V, W0, W1 = (ksgpu.DeviceBV(ctx, n, m) for _ in range(3))
+    V.from_numpy(rng.standard_normal((n, m)))
+    V.matmult(A0, W0)
+    V.matmult(A1, W1)
+    assert np.array_equal(W0.to_numpy(), W1.to_numpy())
+    for o in (A0, A1, T0, T1, V, W0, W1):
+        o.destroy()
+    for p in (xd, yd, zd):
+        ctx.vec_free(p)

@@ -1,5 +1,7 @@
 #!/usr/bin/env python3
-"""SpMV rate on an R-MAT graph Laplacian (power-law rows).  Usage: spmv_rmat.py [scale=22]"""
+"""SpMV rate on an R-MAT graph Laplacian (power-law rows and columns) for several limits of
+the packed hot columns (KSG_OPT_HOT_COLS; 0 = no packing).
+Usage: spmv_rmat.py [scale=22] [limits=0,65536,262144,524288]"""
 import os
 import sys
 
@@ -10,6 +12,7 @@ from slepc_amd import ksgpu, matgen
 
 def main():
     scale = int(sys.argv[1]) if len(sys.argv) > 1 else 22
+    limits = [int(v) for v in (sys.argv[2] if len(sys.argv) > 2 else "0,65536,262144,524288").split(",")]
     rp, ci, va = matgen.rmat_laplacian(scale)
     n = len(rp) - 1
     lens = np.diff(rp)
@@ -18,25 +21,25 @@ def main():
     ctx = ksgpu.Context(0)
     x, y = ctx.vec_alloc(n), ctx.vec_alloc(n)
     ctx.vec_fill_hash(x, n, 0, 5)
-    for bal in ("0", "1"):
-        os.environ["KSG_SPMV_BALANCE"] = bal
+    y0 = None
+    for lim in limits:
+        ctx.set_option(ksgpu.OPT_HOT_COLS, lim)
         A = ksgpu.DeviceCSR(ctx, rp, ci, va)
         A.mult(x, y)
         ctx.sync()
         ctx.enable_timing(True)
         ctx.stats_reset()
-        for _ in range(10):
+        for _ in range(20):
             A.mult(x, y)
         ctx.sync()
         s = ctx.stats()["matmult"]
-        print("balance=%s info=%s  %.3f ms  %.1f GB/s  %.1f Gnnz/s" % (
-            bal, A.info(), s["ms"] / s["calls"], s["bytes"] / s["ms"] / 1e6, rp[-1] * s["calls"] / s["ms"] / 1e6), flush=True)
         ctx.enable_timing(False)
         yb = ctx.download(y, n)
-        if bal == "0":
+        if y0 is None:
             y0 = yb
-        else:
-            print("max |y_balanced - y_plain| = %.3e (scale %.3e)" % (np.abs(yb - y0).max(), np.abs(y0).max()))
+        print("hot limit %7d packed %7d  %.3f ms  %.1f GB/s  %.1f Gnnz/s  same bits as the first: %s" % (
+            lim, A.hot_columns(), s["ms"] / s["calls"], s["bytes"] / s["ms"] / 1e6,
+            rp[-1] * s["calls"] / s["ms"] / 1e6, np.array_equal(yb, y0)), flush=True)
         A.destroy()
 
 
