@@ -24,6 +24,8 @@ def main():
 
     if case.startswith("svd_"):
         return svd_main(mode, case, out, rank, size, dist)
+    if case == "bv_ip":
+        return bv_ip_main(mode, out, rank, size, dist)
     if case == "lap2d":
         gx, gy = 61, 47
         N = gx * gy
@@ -138,6 +140,96 @@ def main():
     Am.destroy()
     if ctx:
         ctx.close()
+
+
+def bv_ip_main(mode, out, rank, size, dist):
+    """Rows of a BV and of its inner-product matrix split over the ranks (the reference runs
+    its bv tests test3 and test6 on two processes): constraints, Gram-Schmidt in the B-inner
+    product, the block Gram matrix and a group of split-phase reductions."""
+    import ctypes as C
+    from slepc_amd import kseps as K, ksgpu, matgen as mg, dist as kdist
+    from tests.common import tridiag_csr, dp
+    assert mode == "gpu"
+    N, k, nc = 211, 7, 2
+    row0, row1 = mg.split_rows(N, size, rank)
+    n = row1 - row0
+    rp, ci, va = tridiag_csr(N)
+    lo, hi = rp[row0], rp[row1]
+    ctx = ksgpu.Context(0)
+    if size > 1:
+        kdist.init_comm(ctx, transport=os.environ.get("KS_TRANSPORT", "gloo"))
+    B = K.Mat.create_aij_hip(ctx, rp[row0:row1 + 1] - lo, ci[lo:hi], va[lo:hi], N=N, row0=row0)
+    lib = K.load()
+    t = K.Vec.create_hip(ctx, n, N, row0)
+    t.set_values(np.cos(np.arange(row0, row1) / 3.0))
+    X = K.BVP()
+    K.check(lib.BVCreate(None, C.byref(X)))
+    K.check(lib.BVSetSizesFromVec(X, t.p, k))
+    K.check(lib.BVSetType(X, b"hip"))
+    K.check(lib.BVSetMatrix(X, B.p, 0))
+    g = np.arange(row0, row1, dtype=float)
+    cons = []
+    for j in range(nc):
+        v = K.Vec.create_hip(ctx, n, N, row0)
+        v.set_values(np.cos((j + 1) * g / 7.0))
+        cons.append(v)
+    ncio = C.c_int(nc)
+    K.check(lib.BVInsertConstraints(X, C.byref(ncio), (K.VecP * nc)(*[v.p for v in cons])))
+    col = K.VecP()
+
+    def set_col(j, a):
+        K.check(lib.BVGetColumn(X, j, C.byref(col)))
+        K.check(lib.VecSetValuesHost(col, dp(np.ascontiguousarray(a))))
+        K.check(lib.BVRestoreColumn(X, j, C.byref(col)))
+
+    def get_col(j):
+        a = np.empty(n)
+        K.check(lib.BVGetColumn(X, j, C.byref(col)))
+        K.check(lib.VecGetValuesHost(col, dp(a)))
+        K.check(lib.BVRestoreColumn(X, j, C.byref(col)))
+        return a
+    for j in range(k):
+        set_col(j, np.sin((j + 1) * (g + 1) / 11.0) + (g == 3 * j))
+    nrm = C.c_double()
+    K.check(lib.BVNormColumn(X, 0, K.NORM_2, C.byref(nrm)))
+    res = {"nc": ncio.value, "bnorm0": nrm.value, "norms": []}
+    for j in range(k):
+        K.check(lib.BVOrthogonalizeColumn(X, j, None, C.byref(nrm), None))
+        K.check(lib.BVScaleColumn(X, j, 1.0 / nrm.value))
+        res["norms"].append(nrm.value)
+    M = np.zeros((k, k), order="F")
+    K.check(lib.BVDot(X, X, dp(M), k))
+    res["gram"] = M.tolist()
+    # one group: coefficients against the first columns, a B-norm and a plain dot product
+    dv, d, bn = np.zeros(3), C.c_double(), C.c_double()
+    K.check(lib.BVSetActiveColumns(X, 0, 3))
+    K.check(lib.BVDotVecBegin(X, t.p, dp(dv)))
+    K.check(lib.BVNormColumnBegin(X, 5, K.NORM_2, C.byref(bn)))
+    K.check(lib.VecDotBegin(t.p, t.p, C.byref(d)))
+    K.check(lib.BVDotVecEnd(X, t.p, dp(dv)))
+    K.check(lib.BVNormColumnEnd(X, 5, K.NORM_2, C.byref(bn)))
+    K.check(lib.VecDotEnd(t.p, t.p, C.byref(d)))
+    K.check(lib.BVSetActiveColumns(X, 0, k))
+    res["split"] = dv.tolist() + [bn.value, d.value]
+    cols = [get_col(j) for j in range(-ncio.value, k)]
+    if size > 1:
+        full = []
+        for a in cols:
+            parts = [None] * size
+            dist.all_gather_object(parts, a)
+            full.append(np.concatenate(parts))
+        cols = full
+    res["Q"] = [a.tolist() for a in cols]
+    if rank == 0:
+        with open(out, "w") as f:
+            json.dump(res, f)
+    if dist:
+        dist.barrier()
+    K.check(lib.BVDestroy(C.byref(X)))
+    for v in cons + [t]:
+        v.destroy()
+    B.destroy()
+    ctx.close()
 
 
 def svd_main(mode, case, out, rank, size, dist):

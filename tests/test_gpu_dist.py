@@ -44,6 +44,28 @@ def test_svd_ranks_match_single(case, ranks):
             assert np.abs(s * x2 - x1).max() < 1e-6
 
 
+@pytest.mark.parametrize("ranks", [2, 3])
+def test_bv_inner_product_and_constraints_ranks_match_single(ranks):
+    """Constraints, Gram-Schmidt in the inner product of a distributed matrix, the block Gram
+    matrix and a group of split-phase reductions give the single-rank result on 2 and 3 ranks
+    (the reference runs bv tests test3 and test6 on two processes)."""
+    one = run_ranks("gpu", "bv_ip", 1)
+    many = run_ranks("gpu", "bv_ip", ranks)
+    assert one["nc"] == many["nc"] == 2
+    Q1, Qm = np.array(one["Q"]), np.array(many["Q"])
+    assert np.abs(Q1 - Qm).max() < 1e-12
+    assert abs(one["bnorm0"] - many["bnorm0"]) < 1e-12 * one["bnorm0"]
+    assert np.abs(np.array(one["norms"]) - np.array(many["norms"])).max() < 1e-12
+    assert np.abs(np.array(one["split"]) - np.array(many["split"])).max() < 1e-11
+    G = np.array(many["gram"])
+    assert np.abs(G - np.eye(G.shape[0])).max() < 1e-13
+    # B-orthonormal against the matrix itself, constraints deflated
+    n = Q1.shape[1]
+    B = 2 * np.eye(n) - np.eye(n, k=1) - np.eye(n, k=-1)
+    W = Qm @ B @ Qm.T
+    assert np.abs(W - np.eye(W.shape[0])).max() < 1e-12
+
+
 def test_rccl_single_rank_communicator():
     """dlopen of RCCL, ncclCommInitRank and the all-reduce on the compute stream."""
     from slepc_amd import ksgpu
