@@ -50,6 +50,9 @@ typedef int PetscBool;
 #define PETSC_ERR_FILE_READ      66
 #define PETSC_ERR_FILE_WRITE     67
 #define PETSC_ERR_FILE_UNEXPECTED 79
+#define PETSC_ERR_ARG_IDN         61
+#define PETSC_ERR_MAT_LU_ZRPVT    71
+#define PETSC_ERR_NOT_CONVERGED   82
 
 const char *KSGetLastError(void);
 
@@ -61,6 +64,7 @@ typedef struct _p_BV *BV;
 typedef struct _p_DS *DS;
 typedef struct _p_EPS *EPS;
 typedef struct _p_SVD *SVD;
+typedef struct _p_ST *ST;
 
 /* ------------------------------------------------------------------ Vec */
 /* Op table of a vector type: the PETSc Vec operations the hot-path host code
@@ -364,12 +368,17 @@ PetscErrorCode SlepcCompareSmallestReal(PetscScalar, PetscScalar, PetscScalar, P
 PetscErrorCode SlepcCompareLargestImaginary(PetscScalar, PetscScalar, PetscScalar, PetscScalar, PetscInt *, void *);
 PetscErrorCode SlepcCompareSmallestImaginary(PetscScalar, PetscScalar, PetscScalar, PetscScalar, PetscInt *, void *);
 PetscErrorCode SlepcCompareSmallestPosReal(PetscScalar, PetscScalar, PetscScalar, PetscScalar, PetscInt *, void *);
+/* closest to the target, ctx = PetscScalar *target (slepcsc.c:225-262) */
+PetscErrorCode SlepcCompareTargetMagnitude(PetscScalar, PetscScalar, PetscScalar, PetscScalar, PetscInt *, void *);
+PetscErrorCode SlepcCompareTargetReal(PetscScalar, PetscScalar, PetscScalar, PetscScalar, PetscInt *, void *);
 PetscErrorCode SlepcSortEigenvalues(SlepcCompareFn cmp, void *ctx, PetscInt n, PetscScalar *eigr, PetscScalar *eigi, PetscInt *perm);
 
 /* ------------------------------------------------------------------ EPS */
-typedef enum { EPS_HEP = 1, EPS_NHEP = 3 } EPSProblemType;
+/* epsopts.c:946-989.  EPS_GHIEP (indefinite B) is not available. */
+typedef enum { EPS_HEP = 1, EPS_GHEP = 2, EPS_NHEP = 3, EPS_GNHEP = 4, EPS_PGNHEP = 5 } EPSProblemType;
 typedef enum { EPS_LARGEST_MAGNITUDE = 1, EPS_SMALLEST_MAGNITUDE, EPS_LARGEST_REAL, EPS_SMALLEST_REAL,
-               EPS_LARGEST_IMAGINARY, EPS_SMALLEST_IMAGINARY, EPS_WHICH_USER = 11 } EPSWhich;
+               EPS_LARGEST_IMAGINARY, EPS_SMALLEST_IMAGINARY, EPS_TARGET_MAGNITUDE, EPS_TARGET_REAL,
+               EPS_WHICH_USER = 11 } EPSWhich;
 typedef enum { EPS_ERROR_ABSOLUTE = 0, EPS_ERROR_RELATIVE = 1 } EPSErrorType;
 typedef enum { EPS_CONVERGED_TOL = 1, EPS_CONVERGED_USER = 2, EPS_DIVERGED_ITS = -1, EPS_DIVERGED_BREAKDOWN = -2,
                EPS_DIVERGED_SYMMETRY_LOST = -3, EPS_CONVERGED_ITERATING = 0 } EPSConvergedReason;
@@ -378,13 +387,44 @@ typedef PetscErrorCode (*EPSMonitorFn)(EPS eps, PetscInt its, PetscInt nconv, Pe
                                        PetscReal *errest, PetscInt nest, void *ctx);
 
 PetscErrorCode EPSCreate(void *ctx, EPS *eps);                                   /* epsbasic.c:60-80 */
-PetscErrorCode EPSSetOperators(EPS eps, Mat A, Mat B);                           /* B must be NULL */
+PetscErrorCode EPSSetOperators(EPS eps, Mat A, Mat B);                           /* B == NULL: standard problem */
 /* "krylovschur" (default; krylovschur.c, ks-symm.c), "arnoldi" (explicit restart,
  * src/eps/impls/krylov/arnoldi/arnoldi.c) or "lanczos" (explicit restart, symmetric problems,
  * src/eps/impls/krylov/lanczos/lanczos.c; reorthogonalisation chosen with EPSLanczosSetReorthog) */
 PetscErrorCode EPSSetType(EPS eps, const char *type);                            /* epsbasic.c */
 PetscErrorCode EPSGetType(EPS eps, const char **type);
 PetscErrorCode EPSSetProblemType(EPS eps, EPSProblemType type);                  /* epsopts.c:946-989 */
+PetscErrorCode EPSSetTarget(EPS eps, PetscScalar target);                        /* epsopts.c (EPSSetTarget): also the default shift of sinvert */
+PetscErrorCode EPSGetTarget(EPS eps, PetscScalar *target);
+PetscErrorCode EPSGetST(EPS eps, ST *st);
+PetscErrorCode EPSSetPurify(EPS eps, PetscBool purify);                          /* epsopts.c:1327 */
+/* vectors every basis vector is kept orthogonal to (epssetup.c:264-270; copies are kept) */
+PetscErrorCode EPSSetDeflationSpace(EPS eps, PetscInt n, Vec *v);
+
+/* ---- ST: spectral transformation (src/sys/classes/st) ------------------------------------
+ * "shift" (default): OP = A - sigma I, or B^-1 (A - sigma B); "sinvert": OP = (A - sigma I)^-1,
+ * or (A - sigma B)^-1 B.  The linear systems are solved by "preonly" (dense LU on the host,
+ * one process and at most 4096 rows: the stand-in for the reference's KSPPREONLY + PCLU and
+ * the default when it applies), "cg" or "gmres" (on the device vectors; gmres is the default
+ * otherwise). */
+PetscErrorCode STCreate(void *ctx, ST *st);
+PetscErrorCode STDestroy(ST *st);
+PetscErrorCode STSetType(ST st, const char *type);
+PetscErrorCode STGetType(ST st, const char **type);
+PetscErrorCode STSetOperators(ST st, Mat A, Mat B);
+PetscErrorCode STGetNumMatrices(ST st, PetscInt *n);
+PetscErrorCode STSetShift(ST st, PetscScalar shift);
+PetscErrorCode STGetShift(ST st, PetscScalar *shift);
+PetscErrorCode STSetDefaultShift(ST st, PetscScalar defaultshift);
+PetscErrorCode STSetKSPType(ST st, const char *type);
+PetscErrorCode STGetKSPType(ST st, const char **type);
+PetscErrorCode STSetKSPTolerances(ST st, PetscReal rtol, PetscInt maxit, PetscInt restart);    /* 0 keeps a value */
+PetscErrorCode STGetKSPIterations(ST st, PetscInt64 *its, PetscInt64 *solves);
+PetscErrorCode STGetBilinearForm(ST st, Mat *B);
+PetscErrorCode STSetUp(ST st);
+PetscErrorCode STApply(ST st, Vec x, Vec y);                                     /* stsolve.c:44-72 */
+PetscErrorCode STMatSolve(ST st, Vec b, Vec x);                                  /* stsles.c */
+PetscErrorCode STBackTransform(ST st, PetscInt n, PetscScalar *eigr, PetscScalar *eigi);
 PetscErrorCode EPSSetDimensions(EPS eps, PetscInt nev, PetscInt ncv, PetscInt mpd);
 PetscErrorCode EPSSetTolerances(EPS eps, PetscReal tol, PetscInt maxits);
 PetscErrorCode EPSSetWhichEigenpairs(EPS eps, EPSWhich which);

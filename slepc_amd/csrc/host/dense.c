@@ -784,3 +784,33 @@ int ksd_trtri_upper(int n, double *A, int lda) {
   }
   return 0;
 }
+
+/* ---- LU with partial pivoting (the direct solve behind a spectral transformation of a small
+ * problem; the reference uses PETSc's PCLU there) -------------------------------------------- */
+int ksd_getrf(int n, double *A, int lda, int *piv) {
+  for (int k = 0; k < n; k++) {
+    int p = k;
+    double big = fabs(A[k + (size_t)k * lda]);
+    for (int i = k + 1; i < n; i++) { const double v = fabs(A[i + (size_t)k * lda]); if (v > big) { big = v; p = i; } }
+    piv[k] = p;
+    if (big == 0.0) return k + 1;
+    if (p != k) for (int j = 0; j < n; j++) { const double t = A[k + (size_t)j * lda]; A[k + (size_t)j * lda] = A[p + (size_t)j * lda]; A[p + (size_t)j * lda] = t; }
+    const double inv = 1.0 / A[k + (size_t)k * lda];
+    for (int i = k + 1; i < n; i++) A[i + (size_t)k * lda] *= inv;
+    for (int j = k + 1; j < n; j++) {
+      const double akj = A[k + (size_t)j * lda];
+      if (akj != 0.0) for (int i = k + 1; i < n; i++) A[i + (size_t)j * lda] -= A[i + (size_t)k * lda] * akj;
+    }
+  }
+  return 0;
+}
+
+void ksd_getrs(int n, const double *LU, int lda, const int *piv, double *b) {
+  for (int k = 0; k < n; k++) { const int p = piv[k]; if (p != k) { const double t = b[k]; b[k] = b[p]; b[p] = t; } }
+  for (int k = 0; k < n; k++) { const double bk = b[k]; if (bk != 0.0) for (int i = k + 1; i < n; i++) b[i] -= LU[i + (size_t)k * lda] * bk; }
+  for (int k = n - 1; k >= 0; k--) {
+    b[k] /= LU[k + (size_t)k * lda];
+    const double bk = b[k];
+    if (bk != 0.0) for (int i = 0; i < k; i++) b[i] -= LU[i + (size_t)k * lda] * bk;
+  }
+}

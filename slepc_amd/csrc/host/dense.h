@@ -21,5 +21,10 @@ int ksd_gesvd(int n, const double *A, int lda, double *s, double *U, int ldu, do
 int ksd_potrf_upper(int n, double *A, int lda);
 /* inverse of an upper triangular matrix, in place; returns k > 0 for a zero on the diagonal */
 int ksd_trtri_upper(int n, double *A, int lda);
+/* LU factorisation with partial pivoting of the n x n matrix A (column-major), in place;
+ * piv[k] = row exchanged with row k.  Returns k > 0 when the pivot of step k is exactly zero. */
+int ksd_getrf(int n, double *A, int lda, int *piv);
+/* solves A x = b with the factors of ksd_getrf; b is overwritten by x */
+void ksd_getrs(int n, const double *LU, int lda, const int *piv, double *b);
 
 #endif

@@ -599,6 +599,21 @@ CMP(SlepcCompareLargestImaginary, fabs(ai), fabs(bi), <, >)
 CMP(SlepcCompareSmallestImaginary, fabs(ai), fabs(bi), >, <)
 
 /* slepcsc.c:310-329: positive real parts first, then by increasing magnitude */
+/* slepcsc.c:225-262 */
+PetscErrorCode SlepcCompareTargetMagnitude(PetscScalar ar, PetscScalar ai, PetscScalar br, PetscScalar bi, PetscInt *result, void *ctx) {
+  const PetscScalar t = *(PetscScalar *)ctx;
+  const PetscReal a = SlepcAbsEigenvalue(ar - t, ai), b = SlepcAbsEigenvalue(br - t, bi);
+  *result = a > b ? 1 : (a < b ? -1 : 0);
+  return 0;
+}
+PetscErrorCode SlepcCompareTargetReal(PetscScalar ar, PetscScalar ai, PetscScalar br, PetscScalar bi, PetscInt *result, void *ctx) {
+  const PetscScalar t = *(PetscScalar *)ctx;
+  const PetscReal a = fabs(ar - t), b = fabs(br - t);
+  (void)ai; (void)bi;
+  *result = a > b ? 1 : (a < b ? -1 : 0);
+  return 0;
+}
+
 PetscErrorCode SlepcCompareSmallestPosReal(PetscScalar ar, PetscScalar ai, PetscScalar br, PetscScalar bi, PetscInt *result, void *ctx) {
   const PetscBool aisright = ar > 0.0, bisright = br > 0.0;
   (void)ctx;

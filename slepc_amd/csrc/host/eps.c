@@ -19,6 +19,7 @@ PetscErrorCode EPSCreate(void *ctx, EPS *outeps) {
   eps->tol = 0.0;                 /* PETSC_DEFAULT -> 1e-8 at setup (epssetup.c:184) */
   eps->lock = PETSC_TRUE;
   eps->conv = EPS_CONV_REL;
+  eps->purify = PETSC_TRUE;       /* epsbasic.c:80 */
   eps->problem_type = (EPSProblemType)0;
   ierr = BVCreate(ctx, &eps->V);CHKERRQ(ierr);
   ierr = DSCreate(&eps->ds);CHKERRQ(ierr);
@@ -28,8 +29,54 @@ PetscErrorCode EPSCreate(void *ctx, EPS *outeps) {
 
 PetscErrorCode EPSSetOperators(EPS eps, Mat A, Mat B) {
   if (!eps || !A) SETERRQ(PETSC_ERR_ARG_NULL, "Null argument");
-  if (B) SETERRQ(PETSC_ERR_SUP, "Generalized problems are not available");
+  if (B && (A->n != B->n || A->N != B->N)) SETERRQ(PETSC_ERR_ARG_INCOMP, "Incompatible matrix sizes");
   eps->A = A;
+  eps->B = B;
+  eps->state = 0;
+  return 0;
+}
+
+/* the eigensolver's ST, created on first use (epsbasic.c, EPSGetST) */
+PetscErrorCode EPSGetST(EPS eps, ST *st) {
+  PetscErrorCode ierr;
+  if (!eps || !st) SETERRQ(PETSC_ERR_ARG_NULL, "Null argument");
+  if (!eps->st) { ierr = STCreate(eps->ctx, &eps->st);CHKERRQ(ierr); }
+  *st = eps->st;
+  return 0;
+}
+
+PetscErrorCode EPSSetTarget(EPS eps, PetscScalar target) {
+  PetscErrorCode ierr;
+  ST st;
+  if (!eps) SETERRQ(PETSC_ERR_ARG_NULL, "Null EPS");
+  eps->target = target;
+  ierr = EPSGetST(eps, &st);CHKERRQ(ierr);
+  ierr = STSetDefaultShift(st, target);CHKERRQ(ierr);
+  eps->state = 0;
+  return 0;
+}
+PetscErrorCode EPSGetTarget(EPS eps, PetscScalar *target) { if (!eps || !target) SETERRQ(PETSC_ERR_ARG_NULL, "Null argument"); *target = eps->target; return 0; }
+PetscErrorCode EPSSetPurify(EPS eps, PetscBool purify) { if (!eps) SETERRQ(PETSC_ERR_ARG_NULL, "Null EPS"); eps->purify = purify ? PETSC_TRUE : PETSC_FALSE; eps->state = 0; return 0; }
+
+/* epssetup.c (EPSSetDeflationSpace): copies are kept until the setup turns them into constraints */
+PetscErrorCode EPSSetDeflationSpace(EPS eps, PetscInt n, Vec *v) {
+  PetscErrorCode ierr;
+  if (!eps) SETERRQ(PETSC_ERR_ARG_NULL, "Null EPS");
+  if (n < 0) SETERRQ(PETSC_ERR_ARG_OUTOFRANGE, "Argument n out of range");
+  if (eps->defl) for (PetscInt i = 0; i < -eps->nds; i++) { ierr = VecDestroy(&eps->defl[i]);CHKERRQ(ierr); }
+  free(eps->defl); eps->defl = NULL;
+  if (eps->nds > 0) { ierr = BVSetNumConstraints(eps->V, 0);CHKERRQ(ierr); }
+  eps->nds = 0;
+  if (n > 0) {
+    if (!v) SETERRQ(PETSC_ERR_ARG_NULL, "Null argument");
+    eps->defl = (Vec *)calloc((size_t)n, sizeof(Vec));
+    if (!eps->defl) SETERRQ(PETSC_ERR_MEM, "Out of memory");
+    for (PetscInt i = 0; i < n; i++) {
+      ierr = VecDuplicate(v[i], &eps->defl[i]);CHKERRQ(ierr);
+      ierr = VecCopy(v[i], eps->defl[i]);CHKERRQ(ierr);
+    }
+    eps->nds = -n;           /* pending, as the reference marks them */
+  }
   eps->state = 0;
   return 0;
 }
@@ -37,8 +84,11 @@ PetscErrorCode EPSSetOperators(EPS eps, Mat A, Mat B) {
 PetscErrorCode EPSSetProblemType(EPS eps, EPSProblemType type) {
   if (!eps) SETERRQ(PETSC_ERR_ARG_NULL, "Null EPS");
   switch (type) {
-    case EPS_HEP: eps->ishermitian = PETSC_TRUE; break;
-    case EPS_NHEP: eps->ishermitian = PETSC_FALSE; break;
+    case EPS_HEP: eps->ishermitian = PETSC_TRUE; eps->isgeneralized = PETSC_FALSE; eps->ispositive = PETSC_FALSE; break;
+    case EPS_NHEP: eps->ishermitian = PETSC_FALSE; eps->isgeneralized = PETSC_FALSE; eps->ispositive = PETSC_FALSE; break;
+    case EPS_GHEP: eps->ishermitian = PETSC_TRUE; eps->isgeneralized = PETSC_TRUE; eps->ispositive = PETSC_TRUE; break;
+    case EPS_GNHEP: eps->ishermitian = PETSC_FALSE; eps->isgeneralized = PETSC_TRUE; eps->ispositive = PETSC_FALSE; break;
+    case EPS_PGNHEP: eps->ishermitian = PETSC_FALSE; eps->isgeneralized = PETSC_TRUE; eps->ispositive = PETSC_TRUE; break;
     default: SETERRQ(PETSC_ERR_ARG_WRONG, "Unknown eigenvalue problem type");
   }
   eps->problem_type = type;
@@ -87,7 +137,7 @@ PetscErrorCode EPSSetTolerances(EPS eps, PetscReal tol, PetscInt maxits) {
 
 PetscErrorCode EPSSetWhichEigenpairs(EPS eps, EPSWhich which) {
   if (!eps) SETERRQ(PETSC_ERR_ARG_NULL, "Null EPS");
-  if (which < EPS_LARGEST_MAGNITUDE || which > EPS_SMALLEST_IMAGINARY) SETERRQ(PETSC_ERR_ARG_OUTOFRANGE, "Invalid 'which' value");
+  if (which < EPS_LARGEST_MAGNITUDE || which > EPS_TARGET_REAL) SETERRQ(PETSC_ERR_ARG_OUTOFRANGE, "Invalid 'which' value");
   eps->which = which;
   eps->state = 0;
   return 0;
@@ -151,6 +201,17 @@ PetscErrorCode EPSMonitorSet(EPS eps, EPSMonitorFn monitor, void *ctx) { if (!ep
 PetscErrorCode EPSGetBV(EPS eps, BV *bv) { if (!eps || !bv) SETERRQ(PETSC_ERR_ARG_NULL, "Null argument"); *bv = eps->V; return 0; }
 PetscErrorCode EPSGetDS(EPS eps, DS *ds) { if (!eps || !ds) SETERRQ(PETSC_ERR_ARG_NULL, "Null argument"); *ds = eps->ds; return 0; }
 
+/* The solver orders the eigenvalues of the transformed operator by what they are in the original
+ * problem: both values go through STBackTransform first (SlepcSCCompare with sc->map =
+ * SlepcMap_ST, slepcsc.c:51-81,162-171; epssetup.c:239-248). */
+static PetscErrorCode EPSCompareMapped(PetscScalar ar, PetscScalar ai, PetscScalar br, PetscScalar bi, PetscInt *res, void *ctx) {
+  PetscErrorCode ierr;
+  EPS eps = (EPS)ctx;
+  ierr = STBackTransform(eps->st, 1, &ar, &ai);CHKERRQ(ierr);
+  ierr = STBackTransform(eps->st, 1, &br, &bi);CHKERRQ(ierr);
+  return eps->cmp0(ar, ai, br, bi, res, eps->cmp0ctx);
+}
+
 /* ---- setup (epssetup.c:100-288,466-555; krylovschur.c:73-167) ----------------------------------- */
 static PetscErrorCode EPSSetDimensions_Default(EPS eps, PetscInt nev, PetscInt *ncv, PetscInt *mpd) {
   const PetscInt n = (PetscInt)PetscMin(eps->n, (PetscInt64)2147483647);
@@ -170,11 +231,20 @@ PetscErrorCode EPSSetUp(EPS eps) {
   PetscInt oldm = 0, k;
   Vec t;
   static const SlepcCompareFn cmps[] = { NULL, SlepcCompareLargestMagnitude, SlepcCompareSmallestMagnitude, SlepcCompareLargestReal,
-                                         SlepcCompareSmallestReal, SlepcCompareLargestImaginary, SlepcCompareSmallestImaginary };
+                                         SlepcCompareSmallestReal, SlepcCompareLargestImaginary, SlepcCompareSmallestImaginary,
+                                         SlepcCompareTargetMagnitude, SlepcCompareTargetReal };
+  ST st;
+  const char *sttype;
   if (!eps) SETERRQ(PETSC_ERR_ARG_NULL, "Null EPS");
   if (eps->state) return 0;
   if (!eps->A) SETERRQ(PETSC_ERR_ARG_WRONGSTATE, "EPSSetOperators must be called first");
-  if (!eps->problem_type) { ierr = EPSSetProblemType(eps, EPS_NHEP);CHKERRQ(ierr); }     /* epssetup.c:138-141 */
+  ierr = EPSGetST(eps, &st);CHKERRQ(ierr);
+  ierr = STSetOperators(st, eps->A, eps->B);CHKERRQ(ierr);
+  /* default problem type, consistency (epssetup.c:137-149) */
+  if (!eps->problem_type) { ierr = EPSSetProblemType(eps, eps->B ? EPS_GNHEP : EPS_NHEP);CHKERRQ(ierr); }
+  else if (!eps->B && eps->isgeneralized) { ierr = EPSSetProblemType(eps, eps->ishermitian ? EPS_HEP : EPS_NHEP);CHKERRQ(ierr); }
+  else if (eps->B && !eps->isgeneralized) SETERRQ(PETSC_ERR_ARG_INCOMP, "Inconsistent EPS state");
+  ierr = STGetType(st, &sttype);CHKERRQ(ierr);
   {
     PetscInt64 ncols;
     ierr = MatGetSize(eps->A, &eps->n, &ncols);CHKERRQ(ierr);
@@ -188,12 +258,18 @@ PetscErrorCode EPSSetUp(EPS eps) {
   ierr = EPSSetDimensions_Default(eps, eps->nev, &eps->ncv, &eps->mpd);CHKERRQ(ierr);
   if (eps->ncv > eps->nev + eps->mpd) SETERRQ(1, "The value of ncv must not be larger than nev+mpd");
   if (!eps->max_it) eps->max_it = (PetscInt)PetscMax((PetscInt64)100, 2 * eps->n / eps->ncv);
-  if (!eps->which) eps->which = EPS_LARGEST_MAGNITUDE;                                    /* epsdefault.c:243-253 */
+  if (!eps->which) eps->which = strcmp(sttype, "sinvert") ? EPS_LARGEST_MAGNITUDE : EPS_TARGET_MAGNITUDE;   /* epsdefault.c:243-253 */
   if (!eps->lock && eps->mpd < eps->ncv) SETERRQ(PETSC_ERR_SUP, "Should not use mpd parameter in non-locking variant");
   if (eps->ishermitian && (eps->which == EPS_LARGEST_IMAGINARY || eps->which == EPS_SMALLEST_IMAGINARY)) SETERRQ(1, "Wrong value of eps->which");
   if (!eps->keep) eps->keep = 0.5;
   if (eps->tol == 0.0) eps->tol = 1e-8;                                                   /* SLEPC_DEFAULT_TOL */
-  eps->cmp = eps->which == EPS_WHICH_USER ? eps->usercmp : cmps[eps->which];
+  eps->cmp0 = eps->which == EPS_WHICH_USER ? eps->usercmp : cmps[eps->which];
+  eps->cmp0ctx = (eps->which == EPS_TARGET_MAGNITUDE || eps->which == EPS_TARGET_REAL) ? (void *)&eps->target : NULL;
+  /* purification only where it makes sense (epssetup.c:169-177) */
+  if (eps->purify && (!eps->isgeneralized || (!eps->ishermitian && !eps->ispositive))) eps->purify = PETSC_FALSE;
+  ierr = STSetUp(st);CHKERRQ(ierr);
+  if (STIsTrivial_Private(st)) { eps->cmp = eps->cmp0; eps->cmpctx = eps->cmp0ctx; }
+  else { eps->cmp = EPSCompareMapped; eps->cmpctx = eps; }
 
   /* EPSAllocateSolution(eps,1) */
   ierr = BVGetSizes(eps->V, NULL, NULL, &oldm);CHKERRQ(ierr);
@@ -211,7 +287,16 @@ PetscErrorCode EPSSetUp(EPS eps) {
     ierr = MatCreateVecs(eps->A, &t, NULL);CHKERRQ(ierr);
     ierr = BVSetSizesFromVec(eps->V, t, requested);CHKERRQ(ierr);
     ierr = VecDestroy(&t);CHKERRQ(ierr);
-  } else { ierr = BVResize(eps->V, requested, PETSC_FALSE);CHKERRQ(ierr); }
+  } else {
+    if (eps->nds > 0) { ierr = BVSetNumConstraints(eps->V, 0);CHKERRQ(ierr); eps->nds = 0; }
+    ierr = BVResize(eps->V, requested, PETSC_FALSE);CHKERRQ(ierr);
+  }
+  /* EPS_SetInnerProduct (epsimpl.h:146-161): B-inner product where it makes the operator self-adjoint */
+  if (eps->ispositive || (eps->isgeneralized && eps->ishermitian)) {
+    Mat Bf;
+    ierr = STGetBilinearForm(st, &Bf);CHKERRQ(ierr);
+    ierr = BVSetMatrix(eps->V, Bf, eps->ispositive ? PETSC_FALSE : PETSC_TRUE);CHKERRQ(ierr);
+  } else { ierr = BVSetMatrix(eps->V, NULL, PETSC_FALSE);CHKERRQ(ierr); }
 
   /* dispatch solve method: DS type (EPSSetUp_KrylovSchur krylovschur.c:141-148;
      EPSSetUp_Arnoldi arnoldi.c:58-64: always the non-symmetric projected problem, extra row) */
@@ -248,9 +333,16 @@ PetscErrorCode EPSSetUp(EPS eps) {
     ierr = DSSetExtraRow(eps->ds, PETSC_FALSE);CHKERRQ(ierr);
   }
   ierr = DSAllocate(eps->ds, eps->ncv + 1);CHKERRQ(ierr);
-  ierr = DSSetSlepcSC(eps->ds, eps->cmp, NULL);CHKERRQ(ierr);
+  ierr = DSSetSlepcSC(eps->ds, eps->cmp, eps->cmpctx);CHKERRQ(ierr);
 
-  /* process initial vectors (epssetup.c:277-283) */
+  /* process deflation and initial vectors (epssetup.c:263-283) */
+  if (eps->nds < 0) {
+    k = -eps->nds;
+    ierr = BVInsertConstraints(eps->V, &k, eps->defl);CHKERRQ(ierr);
+    for (PetscInt i = 0; i < -eps->nds; i++) { ierr = VecDestroy(&eps->defl[i]);CHKERRQ(ierr); }
+    free(eps->defl); eps->defl = NULL;
+    eps->nds = k;
+  }
   if (eps->nini > 0) {
     k = eps->nini;
     ierr = BVInsertVecs(eps->V, 0, &k, eps->IS, PETSC_TRUE);CHKERRQ(ierr);
@@ -263,11 +355,10 @@ PetscErrorCode EPSSetUp(EPS eps) {
 }
 
 /* ---- building blocks ------------------------------------------------------------------------------ */
-/* stsolve.c:44-72 + shift.c:27-41 with sigma = 0: y = A x */
-static PetscErrorCode STApply(EPS eps, Vec x, Vec y) {
+/* the operator of the solver: STApply of the eigensolver's ST (stsolve.c:44-72) */
+static PetscErrorCode EPSApplyOperator(EPS eps, Vec x, Vec y) {
   PetscErrorCode ierr;
-  if (x == y) SETERRQ(PETSC_ERR_ARG_WRONG, "x and y must be different vectors");
-  ierr = MatMult(eps->A, x, y);CHKERRQ(ierr);
+  ierr = STApply(eps->st, x, y);CHKERRQ(ierr);
   eps->matvecs++;
   return 0;
 }
@@ -298,7 +389,7 @@ static PetscErrorCode EPSFullLanczos(EPS eps, PetscReal *alpha, PetscReal *beta,
   for (j = k; j < m; j++) {
     ierr = BVGetColumn(eps->V, j, &vj);CHKERRQ(ierr);
     ierr = BVGetColumn(eps->V, j + 1, &vj1);CHKERRQ(ierr);
-    ierr = STApply(eps, vj, vj1);CHKERRQ(ierr);
+    ierr = EPSApplyOperator(eps, vj, vj1);CHKERRQ(ierr);
     ierr = BVRestoreColumn(eps->V, j, &vj);CHKERRQ(ierr);
     ierr = BVRestoreColumn(eps->V, j + 1, &vj1);CHKERRQ(ierr);
     ierr = BVOrthonormalizeColumn(eps->V, j + 1, PETSC_FALSE, beta + j, breakdown);CHKERRQ(ierr);
@@ -320,7 +411,7 @@ static PetscErrorCode EPSBasicArnoldi(EPS eps, PetscScalar *H, PetscInt ldh, Pet
   for (j = k; j < m; j++) {
     ierr = BVGetColumn(eps->V, j, &vj);CHKERRQ(ierr);
     ierr = BVGetColumn(eps->V, j + 1, &vj1);CHKERRQ(ierr);
-    ierr = STApply(eps, vj, vj1);CHKERRQ(ierr);
+    ierr = EPSApplyOperator(eps, vj, vj1);CHKERRQ(ierr);
     ierr = BVRestoreColumn(eps->V, j, &vj);CHKERRQ(ierr);
     ierr = BVRestoreColumn(eps->V, j + 1, &vj1);CHKERRQ(ierr);
     ierr = BVOrthonormalizeColumn(eps->V, j + 1, PETSC_FALSE, beta, breakdown);CHKERRQ(ierr);
@@ -350,7 +441,7 @@ static PetscErrorCode EPSDelayedArnoldi(EPS eps, PetscScalar *H, PetscInt ldh, P
   for (j = k; j < m; j++) {
     DCHK(BVGetColumn(eps->V, j, &vj));
     DCHK(BVGetColumn(eps->V, j + 1, &vj1));
-    DCHK(STApply(eps, vj, vj1));
+    DCHK(EPSApplyOperator(eps, vj, vj1));
     DCHK(BVRestoreColumn(eps->V, j, &vj));
     DCHK(BVRestoreColumn(eps->V, j + 1, &vj1));
 
@@ -420,7 +511,7 @@ static PetscErrorCode EPSDelayedArnoldi1(EPS eps, PetscScalar *H, PetscInt ldh, 
   for (j = k; j < m; j++) {
     ierr = BVGetColumn(eps->V, j, &vj);CHKERRQ(ierr);
     ierr = BVGetColumn(eps->V, j + 1, &vj1);CHKERRQ(ierr);
-    ierr = STApply(eps, vj, vj1);CHKERRQ(ierr);
+    ierr = EPSApplyOperator(eps, vj, vj1);CHKERRQ(ierr);
     ierr = BVRestoreColumn(eps->V, j + 1, &vj1);CHKERRQ(ierr);
     ierr = BVRestoreColumn(eps->V, j, &vj);CHKERRQ(ierr);
     ierr = BVDotColumnBegin(eps->V, j + 1, H + (size_t)ldh * j);CHKERRQ(ierr);
@@ -453,7 +544,8 @@ static PetscErrorCode EPSKrylovConvergence(EPS eps, PetscInt kini, PetscInt nits
   PetscInt k, newk, marker = -1;
   PetscReal resnorm;
   for (k = kini; k < kini + nits; k++) {
-    const PetscScalar re = eps->eigr[k], im = eps->eigi[k];
+    PetscScalar re = eps->eigr[k], im = eps->eigi[k];
+    if (STIsShift_Private(eps->st)) { ierr = STBackTransform(eps->st, 1, &re, &im);CHKERRQ(ierr); }    /* epskrylov.c:285-287 */
     newk = k;
     ierr = DSVectors(eps->ds, DS_MAT_X, &newk, &resnorm);CHKERRQ(ierr);
     resnorm *= beta * corrf;
@@ -657,7 +749,7 @@ static PetscErrorCode LanczosLocalStep(EPS eps, PetscInt j, PetscInt k, PetscBoo
   Vec vj, vj1;
   ierr = BVGetColumn(eps->V, j, &vj);CHKERRQ(ierr);
   ierr = BVGetColumn(eps->V, j + 1, &vj1);CHKERRQ(ierr);
-  ierr = STApply(eps, vj, vj1);CHKERRQ(ierr);
+  ierr = EPSApplyOperator(eps, vj, vj1);CHKERRQ(ierr);
   ierr = BVRestoreColumn(eps->V, j, &vj);CHKERRQ(ierr);
   ierr = BVRestoreColumn(eps->V, j + 1, &vj1);CHKERRQ(ierr);
   which[j] = PETSC_TRUE;
@@ -796,7 +888,7 @@ static PetscErrorCode EPSPartialLanczos(EPS eps, PetscReal *alpha, PetscReal *be
       /* Lanczos step with full reorthogonalisation */
       PCHK(BVGetColumn(eps->V, j, &vj));
       PCHK(BVGetColumn(eps->V, j + 1, &vj1));
-      PCHK(STApply(eps, vj, vj1));
+      PCHK(EPSApplyOperator(eps, vj, vj1));
       PCHK(BVRestoreColumn(eps->V, j, &vj));
       PCHK(BVRestoreColumn(eps->V, j + 1, &vj1));
       PCHK(BVOrthogonalizeColumn(eps->V, j + 1, hwork, &norm, breakdown));
@@ -928,7 +1020,7 @@ static PetscErrorCode EPSSolve_Lanczos(EPS eps) {
       else {
         for (i = restart + 1; i < n; i++) {
           if (conv[i] == 'N') {
-            LCHK(eps->cmp(ritz[restart], 0.0, ritz[i], 0.0, &r, NULL));
+            LCHK(eps->cmp(ritz[restart], 0.0, ritz[i], 0.0, &r, eps->cmpctx));
             if (r > 0) restart = i;
           }
         }
@@ -967,7 +1059,7 @@ static PetscErrorCode EPSSolve_Lanczos(EPS eps) {
         LCHK(BVGetColumn(eps->V, i, &vi));
         LCHK(VecNorm(vi, NORM_2, &norm));
         LCHK(VecScale(vi, 1.0 / norm));
-        LCHK(STApply(eps, vi, w));
+        LCHK(EPSApplyOperator(eps, vi, w));
         LCHK(VecAXPY(w, -ritz[i], vi));
         LCHK(BVRestoreColumn(eps->V, i, &vi));
         LCHK(VecNorm(w, NORM_2, &norm));
@@ -1014,18 +1106,73 @@ static PetscErrorCode EPSSolve_Lanczos(EPS eps) {
   return 0;
 }
 
+/* epsimpl.h:166-183: each of the first k basis vectors through the operator once more */
+static PetscErrorCode EPS_Purify(EPS eps, PetscInt k) {
+  PetscErrorCode ierr;
+  Vec v = NULL, z;
+  ierr = VecDuplicate(eps->V->t, &v);CHKERRQ(ierr);
+  for (PetscInt i = 0; i < k; i++) {
+    ierr = BVCopyVec(eps->V, i, v);
+    if (!ierr) ierr = BVGetColumn(eps->V, i, &z);
+    if (!ierr) {
+      ierr = EPSApplyOperator(eps, v, z);
+      { const PetscErrorCode ierr2 = BVRestoreColumn(eps->V, i, &z); if (!ierr) ierr = ierr2; }
+    }
+    if (ierr) break;
+  }
+  { const PetscErrorCode ierr2 = VecDestroy(&v); if (!ierr) ierr = ierr2; }
+  CHKERRQ(ierr);
+  return 0;
+}
+
 static PetscErrorCode EPSComputeVectors(EPS eps) {
   PetscErrorCode ierr;
   PetscInt n;
   EPSCheckSolved(eps);
   if (eps->state == 3) return 0;
   eps->state = 3;
-  if (eps->ishermitian && eps->type != 1) return 0;   /* Lanczos vectors are the eigenvectors of a standard HEP */
+  if (eps->ishermitian && eps->type != 1) {
+    /* EPSComputeVectors_Hermitian (epsdefault.c:40-74): the Lanczos vectors are the eigenvectors;
+       with purification each one goes through the operator once more and is normalised again */
+    if (eps->purify) {
+      ierr = EPS_Purify(eps, eps->nconv);CHKERRQ(ierr);
+      for (PetscInt i = 0; i < eps->nconv; i++) {
+        PetscReal norm;
+        ierr = BVNormColumn(eps->V, i, NORM_2, &norm);CHKERRQ(ierr);
+        ierr = BVScaleColumn(eps->V, i, 1.0 / norm);CHKERRQ(ierr);
+      }
+    }
+    return 0;
+  }
   ierr = DSGetDimensions(eps->ds, &n, NULL, NULL, NULL, NULL);CHKERRQ(ierr);
   if (!n) return 0;
   ierr = DSVectors(eps->ds, DS_MAT_X, NULL, NULL);CHKERRQ(ierr);        /* right eigenvectors of T */
   ierr = BVSetActiveColumns(eps->V, 0, n);CHKERRQ(ierr);
   ierr = UpdateBasis(eps, DS_MAT_X, 0, n);CHKERRQ(ierr);                /* V = V * Z */
+  if (eps->purify) {                                                    /* epsdefault.c:168-207 */
+    Vec v, v1;
+    PetscReal norm, normi;
+    ierr = EPS_Purify(eps, eps->nconv);CHKERRQ(ierr);
+    for (PetscInt i = 0; i < n; i++) {
+      if (eps->eigi[i] != 0.0 && i + 1 < n) {
+        ierr = BVGetColumn(eps->V, i, &v);CHKERRQ(ierr);
+        ierr = BVGetColumn(eps->V, i + 1, &v1);CHKERRQ(ierr);
+        ierr = VecNorm(v, NORM_2, &norm);CHKERRQ(ierr);
+        ierr = VecNorm(v1, NORM_2, &normi);CHKERRQ(ierr);
+        const PetscScalar tmp = 1.0 / SlepcAbsEigenvalue(norm, normi);
+        ierr = VecScale(v, tmp);CHKERRQ(ierr);
+        ierr = VecScale(v1, tmp);CHKERRQ(ierr);
+        ierr = BVRestoreColumn(eps->V, i, &v);CHKERRQ(ierr);
+        ierr = BVRestoreColumn(eps->V, i + 1, &v1);CHKERRQ(ierr);
+        i++;
+      } else {
+        ierr = BVGetColumn(eps->V, i, &v);CHKERRQ(ierr);
+        ierr = VecNorm(v, NORM_2, &norm);CHKERRQ(ierr);
+        if (norm != 0.0) { ierr = VecScale(v, 1.0 / norm);CHKERRQ(ierr); }
+        ierr = BVRestoreColumn(eps->V, i, &v);CHKERRQ(ierr);
+      }
+    }
+  }
   return 0;
 }
 
@@ -1046,6 +1193,8 @@ PetscErrorCode EPSSolve(EPS eps) {
   else { ierr = EPSSolve_KrylovSchur_Default(eps);CHKERRQ(ierr); }
   eps->state = 2;
   if (!eps->reason) SETERRQ(PETSC_ERR_PLIB, "Internal error, solver returned without setting converged reason");
+  /* map the eigenvalues back to the original problem (EPSBackTransform_Default, epsdefault.c:27-34) */
+  ierr = STBackTransform(eps->st, eps->nconv, eps->eigr, eps->eigi);CHKERRQ(ierr);
   /* reorder conjugate eigenvalues (positive imaginary first) */
   for (i = 0; i < eps->nconv - 1; i++) {
     if (eps->eigi[i] != 0) {
@@ -1061,7 +1210,9 @@ PetscErrorCode EPSSolve(EPS eps) {
   }
   /* sort eigenvalues according to eps->which */
   for (i = 0; i < eps->ncv; i++) eps->perm[i] = i;
-  ierr = SlepcSortEigenvalues(eps->cmp, NULL, eps->nconv, eps->eigr, eps->eigi, eps->perm);CHKERRQ(ierr);
+  ierr = SlepcSortEigenvalues(eps->cmp0, eps->cmp0ctx, eps->nconv, eps->eigr, eps->eigi, eps->perm);CHKERRQ(ierr);
+  /* remove deflation and initial subspaces (epssolve.c:139-144) */
+  if (eps->nds > 0) { ierr = BVSetNumConstraints(eps->V, 0);CHKERRQ(ierr); eps->nds = 0; }
   eps->nini = 0;
   return 0;
 }
@@ -1137,7 +1288,7 @@ static PetscErrorCode EPSComputeResidualNorm_Private(EPS eps, PetscScalar kr, Pe
   PetscErrorCode ierr;
   Vec u = z[0], v = z[1], w = z[2];
   PetscReal ni, nr;
-  if (eps->A->ops.residualnorm) {
+  if (eps->A->ops.residualnorm && !eps->isgeneralized) {
     /* the operator forms the same residuals in one pass each, storing nothing */
     if (ki == 0 || fabs(ki) < fabs(kr * PETSC_MACHINE_EPSILON)) {
       ierr = eps->A->ops.residualnorm(eps->A, fabs(kr) > PETSC_MACHINE_EPSILON ? kr : 0.0, 0.0, xr, NULL, u, norm);CHKERRQ(ierr);
@@ -1152,16 +1303,19 @@ static PetscErrorCode EPSComputeResidualNorm_Private(EPS eps, PetscScalar kr, Pe
   if (ki == 0 || fabs(ki) < fabs(kr * PETSC_MACHINE_EPSILON)) {
     ierr = MatMult(eps->A, xr, u);CHKERRQ(ierr);                       /* u=A*x */
     if (fabs(kr) > PETSC_MACHINE_EPSILON) {
-      ierr = VecCopy(xr, w);CHKERRQ(ierr);                             /* w=B*x */
+      if (eps->isgeneralized) { ierr = MatMult(eps->B, xr, w);CHKERRQ(ierr); }
+      else { ierr = VecCopy(xr, w);CHKERRQ(ierr); }                    /* w=B*x */
       ierr = VecAXPY(u, -kr, w);CHKERRQ(ierr);                         /* u=A*x-k*B*x */
     }
     ierr = VecNorm(u, NORM_2, norm);CHKERRQ(ierr);
   } else {
     ierr = MatMult(eps->A, xr, u);CHKERRQ(ierr);                       /* u=A*xr */
     if (SlepcAbsEigenvalue(kr, ki) > PETSC_MACHINE_EPSILON) {
-      ierr = VecCopy(xr, v);CHKERRQ(ierr);                             /* v=B*xr */
+      if (eps->isgeneralized) { ierr = MatMult(eps->B, xr, v);CHKERRQ(ierr); }
+      else { ierr = VecCopy(xr, v);CHKERRQ(ierr); }                    /* v=B*xr */
       ierr = VecAXPY(u, -kr, v);CHKERRQ(ierr);                         /* u=A*xr-kr*B*xr */
-      ierr = VecCopy(xi, w);CHKERRQ(ierr);                             /* w=B*xi */
+      if (eps->isgeneralized) { ierr = MatMult(eps->B, xi, w);CHKERRQ(ierr); }
+      else { ierr = VecCopy(xi, w);CHKERRQ(ierr); }                    /* w=B*xi */
       ierr = VecAXPY(u, ki, w);CHKERRQ(ierr);                          /* u=A*xr-kr*B*xr+ki*B*xi */
     }
     ierr = VecNorm(u, NORM_2, &nr);CHKERRQ(ierr);
@@ -1215,8 +1369,11 @@ PetscErrorCode EPSDestroy(EPS *peps) {
   for (PetscInt j = 0; j < eps->nwork; j++) { ierr = VecDestroy(&eps->work[j]);CHKERRQ(ierr); }
   for (PetscInt j = 0; j < eps->nini && eps->IS; j++) { ierr = VecDestroy(&eps->IS[j]);CHKERRQ(ierr); }
   free(eps->IS);
+  if (eps->defl) for (PetscInt j = 0; j < -eps->nds; j++) { ierr = VecDestroy(&eps->defl[j]);CHKERRQ(ierr); }
+  free(eps->defl);
   ierr = BVDestroy(&eps->V);CHKERRQ(ierr);
   ierr = BVDestroy(&eps->AV);CHKERRQ(ierr);
+  ierr = STDestroy(&eps->st);CHKERRQ(ierr);
   ierr = DSDestroy(&eps->ds);CHKERRQ(ierr);
   free(eps->eigr); free(eps->eigi); free(eps->errest); free(eps->perm);
   free(eps);

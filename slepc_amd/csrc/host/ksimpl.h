@@ -51,6 +51,13 @@ struct _p_EPS {
   EPSProblemType problem_type;
   int type;                 /* 0 krylovschur (default), 1 arnoldi, 2 lanczos (full reorthogonalisation) */
   PetscBool ishermitian;
+  Mat B;                    /* generalized problem A x = lambda B x (NULL: standard) */
+  PetscBool isgeneralized, ispositive, purify;
+  ST st;
+  PetscScalar target;
+  SlepcCompareFn cmp0; void *cmp0ctx;   /* the ordering asked for, on values of the original problem */
+  void *cmpctx;             /* context of cmp (the ordering the solver uses, on transformed values) */
+  Vec *defl; PetscInt nds;  /* deflation space: pending vectors, or the number of constraints held */
   PetscInt nev, ncv, mpd, max_it;
   PetscInt64 n, nloc;
   PetscReal tol;
@@ -74,6 +81,9 @@ struct _p_EPS {
   Vec work[5]; PetscInt nwork;
   PetscInt64 matvecs, gs_passes;
 };
+
+PetscBool STIsTrivial_Private(ST st);              /* st.c */
+PetscBool STIsShift_Private(ST st);
 
 /* counters shared between bv.c and eps.c */
 extern PetscInt64 ks_gs_passes;

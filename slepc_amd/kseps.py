@@ -22,11 +22,12 @@ c_dp = C.POINTER(C.c_double)
 Err = C.c_int
 
 NORM_1, NORM_2, NORM_FROBENIUS, NORM_INFINITY = 0, 1, 2, 3
-EPS_HEP, EPS_NHEP = 1, 3
+EPS_HEP, EPS_GHEP, EPS_NHEP, EPS_GNHEP, EPS_PGNHEP = 1, 2, 3, 4, 5
+EPS_TARGET_MAGNITUDE, EPS_TARGET_REAL = 7, 8
 EPS_LARGEST_MAGNITUDE, EPS_SMALLEST_MAGNITUDE, EPS_LARGEST_REAL, EPS_SMALLEST_REAL, \
     EPS_LARGEST_IMAGINARY, EPS_SMALLEST_IMAGINARY = 1, 2, 3, 4, 5, 6
 WHICH = {"largest_magnitude": 1, "smallest_magnitude": 2, "largest_real": 3, "smallest_real": 4,
-         "largest_imaginary": 5, "smallest_imaginary": 6}
+         "largest_imaginary": 5, "smallest_imaginary": 6, "target_magnitude": 7, "target_real": 8}
 EPS_ERROR_ABSOLUTE, EPS_ERROR_RELATIVE = 0, 1
 EPS_CONVERGED_TOL, EPS_DIVERGED_ITS, EPS_DIVERGED_BREAKDOWN = 1, -1, -2
 BV_ORTHOG_CGS, BV_ORTHOG_MGS = 0, 1
@@ -260,6 +261,21 @@ SIGNATURES = {
     "EPSCreate": (Err, [vp, C.POINTER(vp)]),
     "EPSSetOperators": (Err, [vp, MatP, MatP]),
     "EPSSetProblemType": (Err, [vp, C.c_int]),
+    "EPSSetTarget": (Err, [vp, C.c_double]), "EPSGetTarget": (Err, [vp, c_dp]),
+    "EPSGetST": (Err, [vp, C.POINTER(vp)]), "EPSSetPurify": (Err, [vp, C.c_int]),
+    "EPSSetDeflationSpace": (Err, [vp, C.c_int, C.POINTER(VecP)]),
+    "STCreate": (Err, [vp, C.POINTER(vp)]), "STDestroy": (Err, [C.POINTER(vp)]),
+    "STSetType": (Err, [vp, C.c_char_p]), "STGetType": (Err, [vp, C.POINTER(C.c_char_p)]),
+    "STSetOperators": (Err, [vp, MatP, MatP]), "STGetNumMatrices": (Err, [vp, C.POINTER(C.c_int)]),
+    "STSetShift": (Err, [vp, C.c_double]), "STGetShift": (Err, [vp, c_dp]), "STSetDefaultShift": (Err, [vp, C.c_double]),
+    "STSetKSPType": (Err, [vp, C.c_char_p]), "STGetKSPType": (Err, [vp, C.POINTER(C.c_char_p)]),
+    "STSetKSPTolerances": (Err, [vp, C.c_double, C.c_int, C.c_int]),
+    "STGetKSPIterations": (Err, [vp, C.POINTER(c_i64), C.POINTER(c_i64)]),
+    "STGetBilinearForm": (Err, [vp, C.POINTER(MatP)]), "STSetUp": (Err, [vp]),
+    "STApply": (Err, [vp, VecP, VecP]), "STMatSolve": (Err, [vp, VecP, VecP]),
+    "STBackTransform": (Err, [vp, C.c_int, c_dp, c_dp]),
+    "SlepcCompareTargetMagnitude": (Err, [C.c_double] * 4 + [C.POINTER(C.c_int), vp]),
+    "SlepcCompareTargetReal": (Err, [C.c_double] * 4 + [C.POINTER(C.c_int), vp]),
     "EPSSetType": (Err, [vp, C.c_char_p]),
     "EPSGetType": (Err, [vp, C.POINTER(C.c_char_p)]),
     "EPSSetDimensions": (Err, [vp, C.c_int, C.c_int, C.c_int]),
@@ -578,6 +594,45 @@ def write_petsc_binary(filename, M, N, rowptr, colidx, val):
     check(lib.KSMatWritePetscBinary(os.fsencode(filename), M, N, rp.ctypes.data, ci.ctypes.data, va.ctypes.data))
 
 
+class ST:
+    """The spectral transformation of an eigensolver (borrowed handle: EPSGetST)."""
+
+    def __init__(self, h, lib):
+        self.h, self.lib = h, lib
+
+    def set_type(self, name):
+        check(self.lib.STSetType(self.h, name.encode()))
+
+    def get_type(self):
+        p = C.c_char_p()
+        check(self.lib.STGetType(self.h, C.byref(p)))
+        return p.value.decode()
+
+    def set_shift(self, sigma):
+        check(self.lib.STSetShift(self.h, float(sigma)))
+
+    def get_shift(self):
+        v = C.c_double()
+        check(self.lib.STGetShift(self.h, C.byref(v)))
+        return v.value
+
+    def set_ksp_type(self, name):
+        check(self.lib.STSetKSPType(self.h, name.encode()))
+
+    def get_ksp_type(self):
+        p = C.c_char_p()
+        check(self.lib.STGetKSPType(self.h, C.byref(p)))
+        return p.value.decode()
+
+    def set_ksp_tolerances(self, rtol=0.0, maxit=0, restart=0):
+        check(self.lib.STSetKSPTolerances(self.h, rtol, maxit, restart))
+
+    def ksp_iterations(self):
+        a, b = c_i64(), c_i64()
+        check(self.lib.STGetKSPIterations(self.h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+
 class EPS:
     """``EPSCreate`` ... ``EPSDestroy`` with the argument meaning of the C interface."""
 
@@ -588,9 +643,24 @@ class EPS:
         self.h = h
         self._keep = []
 
-    def set_operators(self, A):
-        self.A = A
-        check(self.lib.EPSSetOperators(self.h, A.p, None))
+    def set_operators(self, A, B=None):
+        self.A, self.B = A, B
+        check(self.lib.EPSSetOperators(self.h, A.p, B.p if B is not None else None))
+
+    def set_target(self, target):
+        check(self.lib.EPSSetTarget(self.h, float(target)))
+
+    def set_purify(self, flag):
+        check(self.lib.EPSSetPurify(self.h, 1 if flag else 0))
+
+    def set_deflation_space(self, vecs):
+        arr = (VecP * max(len(vecs), 1))(*[v.p for v in vecs])
+        check(self.lib.EPSSetDeflationSpace(self.h, len(vecs), arr))
+
+    def st(self):
+        h = C.c_void_p()
+        check(self.lib.EPSGetST(self.h, C.byref(h)))
+        return ST(h, self.lib)
 
     def set_type(self, name):
         check(self.lib.EPSSetType(self.h, name.encode()))

@@ -300,13 +300,41 @@ def run_bv_test13(be):
 
 
 def solve_eps(be, csr, hermitian=True, nev=1, ncv=0, mpd=0, tol=0.0, max_it=0, which=None, v0=None,
-              keep=None, lock=True, want_vectors=False, solver=None, delayed=False, orthog_refine=None, reorthog=None):
-    """EPSCreate / EPSSetOperators / ... / EPSSolve / EPSGetEigenpair / EPSComputeError."""
+              keep=None, lock=True, want_vectors=False, solver=None, delayed=False, orthog_refine=None, reorthog=None,
+              csr_b=None, problem=None, st_type=None, sigma=None, target=None, ksp=None, deflation=None, purify=None,
+              ksp_restart=0):
+    """EPSCreate / EPSSetOperators / ... / EPSSolve / EPSGetEigenpair / EPSComputeError.
+    csr_b: the matrix B of a generalized problem; problem: EPS_GHEP, ...; st_type, sigma, ksp:
+    the spectral transformation and its linear solver; deflation: vectors of EPSSetDeflationSpace."""
     rp, ci, va = csr
     A = be.mat_csr(rp, ci, va)
+    B = be.mat_csr(*csr_b) if csr_b is not None else None
     eps = K.EPS(be.ctx.h if be.ctx else None)
-    eps.set_operators(A)
-    eps.set_problem_type(K.EPS_HEP if hermitian else K.EPS_NHEP)
+    eps.set_operators(A, B)
+    if problem is not None:
+        eps.set_problem_type(problem)
+    elif B is None:
+        eps.set_problem_type(K.EPS_HEP if hermitian else K.EPS_NHEP)
+    st = eps.st()
+    if st_type:
+        st.set_type(st_type)
+    if sigma is not None:
+        st.set_shift(sigma)
+    if target is not None:
+        eps.set_target(target)
+    if ksp:
+        st.set_ksp_type(ksp)
+    if ksp_restart:
+        st.set_ksp_tolerances(0.0, 0, ksp_restart)
+    if purify is not None:
+        eps.set_purify(purify)
+    dvecs = []
+    for d in (deflation or []):
+        v = A.create_vecs()
+        v.set_values(d)
+        dvecs.append(v)
+    if dvecs:
+        eps.set_deflation_space(dvecs)
     if solver:
         eps.set_type(solver)
     if reorthog:
@@ -331,7 +359,7 @@ def solve_eps(be, csr, hermitian=True, nev=1, ncv=0, mpd=0, tol=0.0, max_it=0, w
         eps.set_initial_space([vs])
     eps.solve()
     res = {"its": eps.its, "nconv": eps.nconv, "reason": eps.reason, "values": [], "errors": [],
-           "vectors": [], "dims": eps.dimensions()}
+           "vectors": [], "dims": eps.dimensions(), "ksp": st.get_ksp_type(), "linear": st.ksp_iterations()}
     xr, xi = A.create_vecs(), A.create_vecs()
     for i in range(eps.nconv):
         re, im = eps.get_eigenpair(i, xr, xi)
@@ -344,8 +372,63 @@ def solve_eps(be, csr, hermitian=True, nev=1, ncv=0, mpd=0, tol=0.0, max_it=0, w
         o.destroy()
     if vs:
         vs.destroy()
+    for v in dvecs:
+        v.destroy()
     eps.destroy()
     A.destroy()
+    if B is not None:
+        B.destroy()
+    return res
+
+
+def golden_matrix(name):
+    """One of the reference's data files kept as a fixture (share/slepc/datafiles/matrices)."""
+    _, _, rp, ci, va = K.read_petsc_binary(os.path.join(GOLDEN, "matrices", name + ".petsc"))
+    return rp, ci, va
+
+
+def diag_csr(d):
+    n = len(d)
+    return np.arange(n + 1, dtype=np.int64), np.arange(n, dtype=np.int32), np.asarray(d, dtype=np.float64)
+
+
+def check_values(got, want, rtol=1e-9):
+    """Eigenvalues (re, im) against printed golden values "re", "re+imi" (5 decimals)."""
+    assert len(got) >= len(want)
+    for (re, im), w in zip(got, want):
+        m = __import__("re").match(r"^(-?[0-9.]+)(?:([+-][0-9.]+)i)?$", w)
+        wr, wi = float(m.group(1)), float(m.group(2) or 0.0)
+        scale = max(abs(complex(wr, wi)), 1e-300)
+        assert abs(re - wr) <= 0.6e-5 + rtol * scale and abs(im - wi) <= 0.6e-5 + rtol * scale, (re, im, w)
+
+
+def run_eps_ex13(be, ksp=None, nulldim=0):
+    """src/eps/examples/tutorials/ex13.c (generalized symmetric problem, shift-and-invert at
+    target 0, -eps_nev 4 -eps_ncv 22) against output/ex13_1.out."""
+    from slepc_amd import matgen as mg
+    g = golden("eps_tests.json")["ex13"]
+    n = 10
+    N = n * n
+    d = np.full(N, 4.0)
+    d[:nulldim] = 0.0
+    res = solve_eps(be, mg.laplacian2d(n, n), nev=4, ncv=22, csr_b=diag_csr(d), problem=K.EPS_GHEP,
+                    st_type="sinvert", target=0.0, which="target_magnitude", ksp=ksp, want_vectors=True)
+    assert res["reason"] == 1 and res["nconv"] >= 4
+    if nulldim == 0:
+        check_values(res["values"][:4], g)
+    assert max(res["errors"][:4]) < 1e-7
+    return res
+
+
+def run_eps_ex7(be, ksp=None):
+    """src/eps/examples/tutorials/ex7.c on the reference's files bfw62a/bfw62b (-eps_nev 4; a
+    generalized non-symmetric problem with the default transformation, B^-1 A) against
+    output/ex7_1.out."""
+    g = golden("eps_tests.json")["ex7"]
+    res = solve_eps(be, golden_matrix("bfw62a"), nev=4, csr_b=golden_matrix("bfw62b"), ksp=ksp)
+    assert res["reason"] == 1 and res["nconv"] >= 4
+    check_values(res["values"][:4], g)
+    assert max(res["errors"][:4]) < 1e-7
     return res
 
 

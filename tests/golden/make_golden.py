@@ -127,6 +127,8 @@ def eps_tests():
                 "values": eigs("src/eps/examples/tutorials/output/ex4_1.out")[0]}
     g["test10_ks"] = {"n": 10, "m": 11, "nev": 4, "which": "largest_magnitude",
                       "values": eigs("src/eps/examples/tests/output/test10_1_ks.out")[0]}
+    g["ex13"] = eigs("src/eps/examples/tutorials/output/ex13_1.out")[0]
+    g["ex7"] = eigs("src/eps/examples/tutorials/output/ex7_1.out")[0]
     t2 = eigs("src/eps/examples/tests/output/test2_1.out")
     g["test2"] = {"n": 30, "nev": 4, "largest": t2[0], "smallest": t2[1]}
     dump("eps_tests.json", g, "src/eps/examples/{tutorials,tests}/output/*.out")

@@ -212,6 +212,70 @@ def test_split_phase_reductions(be):
     common.run_split_phase(be)
     common.run_split_phase(be, n=37, m=6)
 
+# ---- generalized problems and spectral transformations --------------------------------------
+@pytest.mark.parametrize("ksp", ["gmres", "cg"])
+def test_eps_ex13_generalized_sinvert(be, ksp):
+    res = common.run_eps_ex13(be, ksp)
+    assert res["ksp"] == ksp and res["linear"][0] > res["linear"][1] > 0
+
+
+def test_eps_ex13_singular_B(be):
+    """null(B) = 2: shift-and-invert never solves with B (the case ex13.c is written for)."""
+    res = common.run_eps_ex13(be, "gmres", nulldim=2)
+    ref = _dense_generalized(10, 2)
+    for (re, im), w in zip(res["values"][:4], ref[:4]):
+        assert abs(re - w) <= 1e-9 * abs(w) and im == 0.0
+
+
+def _dense_generalized(n, nulldim):
+    from slepc_amd import matgen as mg
+    from scipy.sparse import csr_matrix
+    import scipy.linalg as sl
+    rp, ci, va = mg.laplacian2d(n, n)
+    A = csr_matrix((va, ci, rp)).toarray()
+    d = np.full(n * n, 4.0)
+    d[:nulldim] = 0.0
+    # A x = lambda B x with singular B: the finite eigenvalues are 1/mu, mu eigenvalue of A^-1 B
+    mu = np.linalg.eigvals(np.linalg.solve(A, np.diag(d)))
+    mu = np.sort(mu.real)[::-1]
+    return [1.0 / m for m in mu if abs(m) > 1e-12]
+
+
+def test_eps_ex7_generalized_nonsymmetric(be):
+    common.run_eps_ex7(be, "gmres")
+
+
+def test_eps_shift_and_target(be):
+    """Standard problem through the transformations: a shifted operator finds the same
+    eigenvalues (back-transformed), shift-and-invert the ones closest to the target."""
+    from slepc_amd import matgen as mg
+    csr = mg.laplacian1d(60)
+    lam = np.sort(2 - 2 * np.cos(np.arange(1, 61) * np.pi / 61))
+    plain = common.solve_eps(be, csr, nev=3, tol=1e-10)
+    shifted = common.solve_eps(be, csr, nev=3, tol=1e-10, sigma=-1.5)       # largest |lambda + 1.5|: the same end
+    for a, b in zip(plain["values"][:3], shifted["values"][:3]):
+        assert abs(a[0] - b[0]) < 1e-9
+    target = 1.3
+    si = common.solve_eps(be, csr, nev=4, tol=1e-10, st_type="sinvert", target=target, ksp="gmres")
+    want = lam[np.argsort(np.abs(lam - target))][:4]
+    assert si["nconv"] >= 4
+    for (re, im), w in zip(si["values"][:4], want):
+        assert abs(re - w) < 1e-8 and im == 0.0
+    assert max(si["errors"][:4]) < 1e-8
+
+
+def test_eps_deflation_space(be):
+    """EPSSetDeflationSpace: with the dominant eigenvector deflated the solver returns the next ones."""
+    from slepc_amd import matgen as mg
+    n = 50
+    csr = mg.laplacian1d(n)
+    k = np.arange(1, n + 1)
+    lam = 2 - 2 * np.cos(k * np.pi / (n + 1))
+    top = np.sin(n * np.arange(1, n + 1) * np.pi / (n + 1))
+    res = common.solve_eps(be, csr, nev=2, tol=1e-10, deflation=[top])
+    assert abs(res["values"][0][0] - lam[-2]) < 1e-9 and abs(res["values"][1][0] - lam[-3]) < 1e-9
+
+
 
 def test_bv_column_view_rules(be):
     """bvbasic.c:1152-1224: at most two outstanding columns, same Vec restored."""
@@ -421,7 +485,7 @@ def test_libraries_export_declared_symbols():
     for header, libpath, table in (("ksgpu.h", ksgpu.LIB_PATH, ksgpu.SIGNATURES), ("kseps.h", K.LIB_PATH, K.SIGNATURES)):
         text = open(os.path.join(root, "include", header)).read()
         text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-        names = set(re.findall(r"\b((?:ksg_|KS|Vec|Mat|BV|DS|EPS|SVD|Slepc)\w+)\s*\(", text))
+        names = set(re.findall(r"\b((?:ksg_|KS|Vec|Mat|BV|DS|EPS|SVD|ST|Slepc)\w+)\s*\(", text))
         names = {n for n in names if not n.endswith("Fn") and n not in ("EPSMonitorFn",)}
         dll = C.CDLL(libpath)
         missing = [n for n in sorted(names) if not hasattr(dll, n)]
