@@ -42,8 +42,27 @@ class EPS:
     def __init__(self, matvec, n_local, N=None, hermitian=True, nev=1, ncv=0, mpd=0,
                  tol=1e-8, max_it=0, which=None, keep=0.5, lock=True, comm=None,
                  row0=0, v0=None, monitor=None, solver="krylovschur", delayed=False,
-                 orthog_refine=REFINE_IFNEEDED, reorthog="local"):
+                 orthog_refine=REFINE_IFNEEDED, reorthog="local", Bmatvec=None, positive=True,
+                 st="shift", sigma=None, target=0.0, solve=None, purify=True, deflation=None):
+        """Generalized problem: ``Bmatvec(x, y)`` computes y = B x.  ``st`` is the spectral
+        transformation ("shift", "sinvert"), ``sigma`` its shift (sinvert: the target when not
+        given, sinvert.c:112) and ``solve(b, x)`` solves with the matrix the transformation needs
+        -- B for shift, A - sigma B for sinvert -- the KSPSolve the reference delegates to PETSc
+        (stsles.c).  ``deflation``: vectors of EPSSetDeflationSpace."""
         self.matvec = matvec
+        self.Bmatvec = Bmatvec
+        self.generalized = Bmatvec is not None
+        self.positive = self.generalized and positive and (hermitian or positive == "pgnhep")
+        if st not in ("shift", "sinvert"):
+            raise ValueError("unknown ST type " + st)
+        self.st = st
+        self.sigma = (target if st == "sinvert" else 0.0) if sigma is None else sigma
+        self.target = target
+        self.lin_solve = solve
+        self.purify = purify
+        self.deflation = deflation or []
+        if (self.generalized or st == "sinvert") and solve is None:
+            raise ValueError("a linear solver is needed")
         self.n = int(n_local)
         self.N = int(N if N is not None else n_local)
         self.hermitian = hermitian
@@ -91,8 +110,8 @@ class EPS:
             raise ValueError("The value of ncv must not be larger than nev+mpd")
         if not self.max_it:
             self.max_it = max(100, 2 * self.N // self.ncv)   # krylovschur.c:89
-        if not self.which:
-            self.which = "largest_magnitude"                 # epsdefault.c:243-253
+        if not self.which:                                   # epsdefault.c:243-253
+            self.which = "target_magnitude" if self.st == "sinvert" else "largest_magnitude"
         if not self.keep:
             self.keep = 0.5                                  # krylovschur.c:103
         ncv = self.ncv
@@ -107,16 +126,78 @@ class EPS:
         self.eigi = np.zeros(ncv + 1)
         self.errest = np.zeros(ncv + 1)
         self.perm = np.arange(ncv + 1)
-        cmpf = dsmod.COMPARE[self.which]
+        # purification only where it makes sense (epssetup.c:169-177)
+        if self.purify and (not self.generalized or (not self.hermitian and not self.positive)):
+            self.purify = False
+        # EPS_SetInnerProduct (epsimpl.h:146-161)
+        if self.positive or (self.generalized and self.hermitian):
+            def bmul(x):
+                y = np.zeros(self.n)
+                self.Bmatvec(x, y)
+                return y
+            self.V.set_matrix(bmul, indef=not self.positive)
+        if self.deflation:                                   # epssetup.c:263-270
+            self.V.insert_constraints(self.deflation)
+        self.cmp0 = self._raw_compare()
+        trivial = self.st == "shift" and self.sigma == 0.0 and not self.generalized
+        if trivial:
+            cmpf = self.cmp0
+        else:
+            # eigenvalues of the transformed operator are ordered by what they are in the original
+            # problem (SlepcSCCompare with map = SlepcMap_ST, slepcsc.c:51-81; epssetup.c:239-248)
+            def cmpf(ar, ai, br, bi):
+                ar, ai = self._back_transform(ar, ai)
+                br, bi = self._back_transform(br, bi)
+                return self.cmp0(ar, ai, br, bi)
+        self.cmpf = cmpf
         if self.hermitian and self.solver in ("krylovschur", "lanczos"):
             self.ds = dsmod.DSHEP(ncv + 1, cmpf)
         else:
             self.ds = dsmod.DSNHEP(ncv + 1, cmpf)
 
     # -- helpers --------------------------------------------------------------
+    def _raw_compare(self):
+        if self.which == "target_magnitude":                 # slepcsc.c:261-274
+            t = self.target
+            return lambda ar, ai, br, bi: (lambda a, b: 1 if a > b else (-1 if a < b else 0))(
+                dsmod.abs_eig(ar - t, ai), dsmod.abs_eig(br - t, bi))
+        if self.which == "target_real":                      # slepcsc.c:276-289
+            t = self.target
+            return lambda ar, ai, br, bi: (lambda a, b: 1 if a > b else (-1 if a < b else 0))(abs(ar - t), abs(br - t))
+        return dsmod.COMPARE[self.which]
+
+    def _back_transform(self, re, im):
+        """``STBackTransform_Shift`` (shift.c:60-70) / ``_Sinvert`` (sinvert.c:59-82)."""
+        if self.st == "shift":
+            return re + self.sigma, im
+        if im == 0:
+            return 1.0 / re + self.sigma, im
+        t = re * re + im * im
+        return re / t + self.sigma, -im / t
+
     def _apply(self, x, y):
+        """``STApply``: shift.c:27-41, sinvert.c:26-40."""
         self.nmatvec += 1
-        self.matvec(x, y)
+        if self.st == "shift":
+            if self.generalized:                             # y = B^-1 (A - sigma B) x
+                w = np.zeros(self.n)
+                self.matvec(x, w)
+                if self.sigma != 0.0:
+                    bx = np.zeros(self.n)
+                    self.Bmatvec(x, bx)
+                    w -= self.sigma * bx
+                self.lin_solve(w, y)
+            else:
+                self.matvec(x, y)
+                if self.sigma != 0.0:
+                    y -= self.sigma * x
+        else:
+            if self.generalized:                             # y = (A - sigma B)^-1 B x
+                w = np.zeros(self.n)
+                self.Bmatvec(x, w)
+                self.lin_solve(w, y)
+            else:
+                self.lin_solve(np.array(x), y)
 
     def _random_column(self, j):
         g = np.arange(self.row0, self.row0 + self.n, dtype=np.uint64)
@@ -260,6 +341,8 @@ class EPS:
         k = kini
         while k < kini + nits:
             re, im = self.eigr[k], self.eigi[k]
+            if self.st == "shift":                           # epskrylov.c:285-287
+                re, im = self._back_transform(re, im)
             newk, resnorm = self.ds.vectors_rnorm(k)
             resnorm *= beta
             # EPSConvergedRelative / EPSConvergedAbsolute (epsdefault.c:258-280)
@@ -634,7 +717,7 @@ class EPS:
         bnd = np.zeros(ncv + 1)
         conv = ["N"] * (ncv + 1)
         perm = np.zeros(ncv + 1, dtype=int)
-        cmpf = dsmod.COMPARE[self.which]
+        cmpf = self.cmpf
         macheps = np.finfo(float).eps
         self._get_start_vector(0)
         anorm = -1.0
@@ -762,6 +845,8 @@ class EPS:
         else:
             self._solve_default()
         self._vectors_done = False
+        for i in range(self.nconv):                          # EPSBackTransform_Default (epsdefault.c:27-34)
+            self.eigr[i], self.eigi[i] = self._back_transform(self.eigr[i], self.eigi[i])
         # reorder conjugate eigenvalues, positive imaginary part first (:106-120)
         i = 0
         while i < self.nconv - 1:
@@ -774,8 +859,7 @@ class EPS:
                 i += 1
             i += 1
         self.perm = np.arange(self.ncv + 1)
-        dsmod.sort_eigenvalues(dsmod.COMPARE[self.which], self.nconv, self.eigr, self.eigi,
-                               self.perm)
+        dsmod.sort_eigenvalues(self.cmp0, self.nconv, self.eigr, self.eigi, self.perm)
         return self
 
     # -- post-solve ------------------------------------------------------------------
@@ -787,6 +871,10 @@ class EPS:
             return
         self._vectors_done = True
         if self.hermitian and self.solver in ("krylovschur", "lanczos"):
+            if self.purify:                                  # epsdefault.c:50-56
+                self._purify(self.nconv)
+                for i in range(self.nconv):
+                    self.V.scale_column(i, 1.0 / self.V.norm_column(i))
             return
         n = self.ds.n
         if n == 0:
@@ -795,6 +883,29 @@ class EPS:
         Z = self.ds.get_mat("X")
         self.V.set_active_columns(0, n)
         self.V.mult_in_place(Z, 0, n)
+        if self.purify:                                      # epsdefault.c:168-205
+            self._purify(self.nconv)
+
+            def nrm2(v):
+                return float(np.sqrt(self.comm.allreduce_sum(np.array([v @ v]))[0]))
+            i = 0
+            while i < n:
+                if self.eigi[i] != 0.0 and i + 1 < n:
+                    t = 1.0 / dsmod.abs_eig(nrm2(self.V.col(i)), nrm2(self.V.col(i + 1)))
+                    self.V.col(i)[:] *= t
+                    self.V.col(i + 1)[:] *= t
+                    i += 1
+                else:
+                    nr = nrm2(self.V.col(i))
+                    if nr != 0.0:
+                        self.V.col(i)[:] /= nr
+                i += 1
+
+    def _purify(self, k):
+        """``EPS_Purify`` (epsimpl.h:166-183)."""
+        for i in range(k):
+            v = self.V.col(i).copy()
+            self._apply(v, self.V.col(i))
 
     def get_eigenvalue(self, i):
         """``EPSGetEigenvalue`` (epssolve.c:370-390)."""
@@ -821,21 +932,29 @@ class EPS:
         def nrm2(v):
             return float(np.sqrt(self.comm.allreduce_sum(np.array([v @ v]))[0]))
 
+        def bmul(x):
+            if not self.generalized:
+                return x
+            y = np.zeros(self.n)
+            self.Bmatvec(x, y)
+            return y
+
         if ki == 0 or abs(ki) < abs(kr * EPSILON):
             self.matvec(xr, u)
             if abs(kr) > EPSILON:
-                u -= kr * xr
+                u -= kr * bmul(xr)
             err = nrm2(u)
         else:
             self.matvec(xr, u)
+            bxr, bxi = bmul(xr), bmul(xi)
             if dsmod.abs_eig(kr, ki) > EPSILON:
-                u -= kr * xr
-                u += ki * xi
+                u -= kr * bxr
+                u += ki * bxi
             nr = nrm2(u)
             self.matvec(xi, u)
             if dsmod.abs_eig(kr, ki) > EPSILON:
-                u -= kr * xi
-                u -= ki * xr
+                u -= kr * bxi
+                u -= ki * bxr
             ni = nrm2(u)
             err = dsmod.abs_eig(nr, ni)
         if relative:

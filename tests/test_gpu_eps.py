@@ -85,8 +85,21 @@ def test_eps_ex13_generalized_sinvert(be, ksp):
 
 
 def test_eps_ex7_generalized_nonsymmetric(be):
-    for ksp in (None, "gmres"):
-        common.run_eps_ex7(be, ksp)
+    """ex7 on the reference's files; the product with its direct solver against the CPU
+    restatement with SuperLU solves: same restarts, same eigenvalues."""
+    from tests.test_oracle_golden import _splu_solver
+    results = [common.run_eps_ex7(be, ksp) for ksp in (None, "gmres")]
+    rpa, cia, vaa = common.golden_matrix("bfw62a")
+    rpb, cib, vab = common.golden_matrix("bfw62b")
+    A = csr_matrix((vaa, cia, rpa), shape=(62, 62))
+    B = csr_matrix((vab, cib, rpb), shape=(62, 62))
+    e = oeps.EPS(lambda x, y: y.__setitem__(slice(None), A @ x), 62, hermitian=False, nev=4,
+                 Bmatvec=lambda x, y: y.__setitem__(slice(None), B @ x), solve=_splu_solver(B)).solve()
+    for res in results:
+        assert res["its"] == e.its and res["nconv"] == e.nconv
+        for i in range(e.nconv):
+            kr, ki = e.get_eigenvalue(i)
+            assert abs(complex(*res["values"][i]) - complex(kr, ki)) <= 1e-9 * abs(complex(kr, ki))
 
 
 def test_eps_shift_sinvert_standard(be):
