@@ -52,6 +52,19 @@ static void eps_set_from_options(EPS eps, int argc, char **argv) {
   if (opt_find(argc, argv, "-eps_smallest_magnitude")) CHK(EPSSetWhichEigenpairs(eps, EPS_SMALLEST_MAGNITUDE));
   if (opt_find(argc, argv, "-eps_largest_real")) CHK(EPSSetWhichEigenpairs(eps, EPS_LARGEST_REAL));
   if (opt_find(argc, argv, "-eps_smallest_real")) CHK(EPSSetWhichEigenpairs(eps, EPS_SMALLEST_REAL));
+  if (opt_find(argc, argv, "-eps_target_magnitude")) CHK(EPSSetWhichEigenpairs(eps, EPS_TARGET_MAGNITUDE));
+  if (opt_find(argc, argv, "-eps_target_real")) CHK(EPSSetWhichEigenpairs(eps, EPS_TARGET_REAL));
+  if (opt_find(argc, argv, "-eps_target")) CHK(EPSSetTarget(eps, opt_real(argc, argv, "-eps_target", 0.0)));
+  /* -st_type shift|sinvert  -st_shift s  -st_ksp_type preonly|cg|gmres  -st_ksp_rtol t  -st_ksp_gmres_restart m (STSetFromOptions) */
+  ST st;
+  CHK(EPSGetST(eps, &st));
+  it = opt_find(argc, argv, "-st_type");
+  if (it && it + 1 < argc) CHK(STSetType(st, argv[it + 1]));
+  if (opt_find(argc, argv, "-st_shift")) CHK(STSetShift(st, opt_real(argc, argv, "-st_shift", 0.0)));
+  it = opt_find(argc, argv, "-st_ksp_type");
+  if (it && it + 1 < argc) CHK(STSetKSPType(st, argv[it + 1]));
+  CHK(STSetKSPTolerances(st, opt_real(argc, argv, "-st_ksp_rtol", 0.0), (PetscInt)opt_int(argc, argv, "-st_ksp_max_it", 0),
+                         (PetscInt)opt_int(argc, argv, "-st_ksp_gmres_restart", 0)));
 }
 
 /* -svd_type -svd_nsv -svd_ncv -svd_mpd -svd_tol -svd_max_it -svd_largest -svd_smallest
