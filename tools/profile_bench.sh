@@ -15,6 +15,19 @@ timeout -s KILL 400 rocprofv3 --pmc WRITE_SIZE -d $OUT -o write --output-format 
 cd $R
 python3 tools/prof_summary.py trace $OUT/trace_kernel_trace.csv > $OUT/summary_trace.txt
 python3 tools/prof_summary.py pmc $OUT/fetch_counter_collection.csv $OUT/write_counter_collection.csv $OUT/bench_trace.json > $OUT/summary_pmc.txt
+# the file bench.py reads for roofline.traffic (copy it to profiles/pmc_traffic.json)
+python3 - "$OUT" <<'PY'
+import json, sys
+out = sys.argv[1]
+kern = json.loads(open(out + "/summary_pmc.txt").read().strip().splitlines()[-1])
+line = json.loads(open(out + "/bench_trace.json").read().strip().splitlines()[-1])
+json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) of `python3 bench.py --steps 5 --warmup 2 "
+                     "--no-cpu-baseline`, dispatches between the bench markers; traffic = (2*FETCH_SIZE + WRITE_SIZE)*1024 bytes "
+                     "(FETCH_SIZE reads half of a wide coalesced stream on gfx950; calibrated on k_scale_cols, 8n read + 8n written "
+                     "per launch: profiles/r01c_bench_pmc_summary.txt)",
+           "workload": line["config"]["workload"], "steps": line["steps"], "warmup": line["warmup"], "kernels": kern},
+          open(out + "/pmc_traffic.json", "w"), indent=1)
+PY
 rm -f $OUT/fetch_counter_collection.csv $OUT/write_counter_collection.csv
 tail -3 $OUT/bench_trace.json | cut -c1-600
 cat $OUT/summary_trace.txt | head -20
