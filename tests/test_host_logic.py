@@ -491,3 +491,15 @@ def test_libraries_export_declared_symbols():
         missing = [n for n in sorted(names) if not hasattr(dll, n)]
         assert not missing, missing
         assert names <= set(table) | {"SlepcCompareFn"}, sorted(names - set(table))
+
+
+def test_pmc_traffic_file_layout():
+    """bench.py takes roofline.traffic from profiles/pmc_traffic.json: the layout it reads."""
+    import json
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with open(os.path.join(root, "profiles", "pmc_traffic.json")) as f:
+        pmc = json.load(f)
+    assert pmc["workload"].startswith("ex2 2-D 5-point Laplacian 4096x4096")
+    for k in ("k_multvec_dot", "k_dotw", "k_spmv_tiles"):
+        assert 0.9 < pmc["kernels"][k]["traffic_over_algorithmic"] < 1.2 and pmc["kernels"][k]["launches"] > 0
