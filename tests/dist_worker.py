@@ -26,6 +26,8 @@ def main():
         return svd_main(mode, case, out, rank, size, dist)
     if case == "bv_ip":
         return bv_ip_main(mode, out, rank, size, dist)
+    if case.startswith("gen_"):
+        return generalized_main(mode, case, out, rank, size, dist)
     if case == "lap2d":
         gx, gy = 61, 47
         N = gx * gy
@@ -228,6 +230,61 @@ def bv_ip_main(mode, out, rank, size, dist):
     K.check(lib.BVDestroy(C.byref(X)))
     for v in cons + [t]:
         v.destroy()
+    B.destroy()
+    ctx.close()
+
+
+def generalized_main(mode, case, out, rank, size, dist):
+    """ex13-like generalized symmetric problem (B diagonal, varying) on row-distributed operators:
+    gen_sinvert -- shift-and-invert at a target inside the spectrum's lower end, A - sigma B merged
+    on every rank from its rows, CG/GMRES with the halo exchange in every product;
+    gen_shift   -- the default transformation, systems with B."""
+    from slepc_amd import kseps as K, ksgpu, matgen as mg, dist as kdist
+    assert mode == "gpu"
+    gx, gy = 19, 14
+    N = gx * gy
+    row0, row1 = mg.split_rows(N, size, rank)
+    n = row1 - row0
+    rp, ci, va = mg.laplacian2d(gx, gy, row0, row1)
+    d = 2.0 + np.sin(np.arange(row0, row1))
+    ctx = ksgpu.Context(0)
+    if size > 1:
+        kdist.init_comm(ctx, transport=os.environ.get("KS_TRANSPORT", "gloo"))
+    A = K.Mat.create_aij_hip(ctx, rp, ci, va, N=N, row0=row0)
+    B = K.Mat.create_aij_hip(ctx, np.arange(n + 1, dtype=np.int64), np.arange(row0, row1, dtype=np.int32), d, N=N, row0=row0)
+    eps = K.EPS(ctx.h)
+    eps.set_operators(A, B)
+    eps.set_problem_type(K.EPS_GHEP)
+    eps.set_dimensions(4)
+    eps.set_tolerances(1e-10)
+    st = eps.st()
+    if case == "gen_sinvert":
+        st.set_type("sinvert")
+        eps.set_target(0.0)
+        eps.set_which("target_magnitude")
+        st.set_ksp_type("cg")
+    else:
+        st.set_ksp_type("gmres")
+    eps.solve()
+    res = {"its": eps.its, "nconv": eps.nconv, "reason": eps.reason, "ksp": st.get_ksp_type(),
+           "values": [eps.get_eigenvalue(i) for i in range(min(eps.nconv, 4))],
+           "errors": [eps.compute_error(i) for i in range(min(eps.nconv, 4))]}
+    xr = A.create_vecs()
+    eps.get_eigenpair(0, xr)
+    local = xr.get_values()
+    if size > 1:
+        gathered = [None] * size
+        dist.all_gather_object(gathered, local)
+        local = np.concatenate(gathered)
+    res["x0"] = local.tolist()
+    if rank == 0:
+        with open(out, "w") as f:
+            json.dump(res, f)
+    if dist:
+        dist.barrier()
+    xr.destroy()
+    eps.destroy()
+    A.destroy()
     B.destroy()
     ctx.close()
 

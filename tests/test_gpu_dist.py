@@ -66,6 +66,30 @@ def test_bv_inner_product_and_constraints_ranks_match_single(ranks):
     assert np.abs(W - np.eye(W.shape[0])).max() < 1e-12
 
 
+@pytest.mark.parametrize("case,ranks", [("gen_sinvert", 2), ("gen_shift", 3)])
+def test_generalized_problem_ranks_match_single(case, ranks):
+    """A generalized symmetric problem through shift-and-invert (CG) and through the default
+    transformation (GMRES) with the operators split by rows: the single-rank result, and the
+    dense solution of the pencil."""
+    import scipy.linalg as sl
+    from scipy.sparse import csr_matrix
+    from slepc_amd import matgen as mg
+    one = run_ranks("gpu", case, 1)
+    many = run_ranks("gpu", case, ranks)
+    rp, ci, va = mg.laplacian2d(19, 14)
+    A = csr_matrix((va, ci, rp)).toarray()
+    d = 2.0 + np.sin(np.arange(19 * 14))
+    lam = sl.eigh(A, np.diag(d), eigvals_only=True)
+    want = lam[:4] if case == "gen_sinvert" else lam[::-1][:4]
+    for res in (one, many):
+        assert res["reason"] == 1 and res["nconv"] >= 4 and res["ksp"] == ("cg" if case == "gen_sinvert" else "gmres")
+        assert np.abs(np.array([v[0] for v in res["values"]]) - want).max() < 1e-8
+        assert max(res["errors"]) < 1e-8
+    x1, xm = np.array(one["x0"]), np.array(many["x0"])
+    assert np.abs(np.sign(x1 @ xm) * xm - x1).max() < 1e-6
+    assert abs((x1 * d) @ x1 - 1.0) < 1e-8                       # B-normalised
+
+
 def test_rccl_single_rank_communicator():
     """dlopen of RCCL, ncclCommInitRank and the all-reduce on the compute stream."""
     from slepc_amd import ksgpu
