@@ -683,9 +683,144 @@ __global__ __launch_bounds__(256) void k_gram(const double *__restrict__ Y, int6
     }
 }
 
+/* The same block product on the matrix cores.  Accumulators of v_mfma_f64_16x16x4_f64 are
+ * spread over the wave (4 results per lane and 16 x 16 tile), so one wave holds a whole
+ * 64 x 64 block of results and every element of Y and X is fetched once per wave and row --
+ * the register-tiled kernel above fetches each column once per 8 x 8 tile and is bound by the
+ * L2 -> L1 path at 64 columns.  A lane supplies one entry of A = Y^T (row i = lane & 15 of the
+ * tile, k = lane >> 4) and one of B = X (column j = lane & 15, k = lane >> 4) per instruction;
+ * since the order of the rows in the sum is free, k stands for the four consecutive rows
+ * r0 + 4k .. r0 + 4k + 3 of a group of 16, one per instruction, so that a lane reads 32
+ * contiguous bytes of a column and the four lanes of a column one whole cache line.  D holds
+ * row (lane >> 4) + 4 v, column lane & 15 in element v.
+ * sym: X and Y are the same panel (M is symmetric): blocks and tiles below the diagonal are
+ * left out and filled in by the caller. */
+typedef double ksg_d4 __attribute__((ext_vector_type(4)));
+
+/* M(i,j) = M(j,i) for i > j, M k x k column-major */
+__global__ __launch_bounds__(KSG_BLOCK) void k_mirror_upper(double *__restrict__ M, int k) {
+  const int e = blockIdx.x * KSG_BLOCK + threadIdx.x;
+  if (e >= k * k) return;
+  const int i = e % k, j = e / k;
+  if (i > j) M[(int64_t)j * k + i] = M[(int64_t)i * k + j];
+}
+
+template <int T>
+__global__ __launch_bounds__(256, 2) void k_gram_mfma(const double *__restrict__ Y, int64_t ldy, int ky,
+                                                   const double *__restrict__ X, int64_t ldx, int kx, int64_t n,
+                                                   double *__restrict__ partial, int nrb, int nby, int nbx, int sym) {
+  const int lane = threadIdx.x & 63;
+  const int gw = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int nob = nby * nbx;
+  const int ob = gw % nob, rb = gw / nob;
+  if (rb >= nrb) return;                               /* no barriers in this kernel */
+  const int by = ob % nby, bx = ob / nby;
+  if (sym && bx < by) return;
+  const bool diag = sym && bx == by;
+  const int c = lane & 15, k = lane >> 4;
+  const int i0 = by * (16 * T), j0 = bx * (16 * T);
+  const double *yc[T], *xc[T];
+#pragma unroll
+  for (int t = 0; t < T; t++) {
+    yc[t] = Y + (int64_t)min(i0 + 16 * t + c, ky - 1) * ldy + 4 * k;
+    xc[t] = X + (int64_t)min(j0 + 16 * t + c, kx - 1) * ldx + 4 * k;
+  }
+  ksg_d4 acc[T][T];
+#pragma unroll
+  for (int a = 0; a < T; a++)
+#pragma unroll
+    for (int b = 0; b < T; b++) acc[a][b] = (ksg_d4){0.0, 0.0, 0.0, 0.0};
+  const int64_t ngroups = n >> 4;                      /* whole groups of 16 rows */
+  double yn[T][4], xn[T][4];
+  int64_t g = rb;
+  auto load = [&](int64_t gg) {
+    const int64_t r0 = gg << 4;
+#pragma unroll
+    for (int t = 0; t < T; t++) {
+      const double2 a0 = *reinterpret_cast<const double2 *>(yc[t] + r0), a1 = *reinterpret_cast<const double2 *>(yc[t] + r0 + 2);
+      yn[t][0] = a0.x; yn[t][1] = a0.y; yn[t][2] = a1.x; yn[t][3] = a1.y;
+    }
+    if (!diag) {
+#pragma unroll
+      for (int t = 0; t < T; t++) {
+        const double2 b0 = *reinterpret_cast<const double2 *>(xc[t] + r0), b1 = *reinterpret_cast<const double2 *>(xc[t] + r0 + 2);
+        xn[t][0] = b0.x; xn[t][1] = b0.y; xn[t][2] = b1.x; xn[t][3] = b1.y;
+      }
+    }
+  };
+  auto multiply = [&](double (&yv)[T][4], double (&xv)[T][4]) {
+#pragma unroll
+    for (int s = 0; s < 4; s++)
+#pragma unroll
+      for (int a = 0; a < T; a++)
+#pragma unroll
+        for (int b = 0; b < T; b++) {
+          if (diag && b < a) continue;
+          acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(yv[a][s], diag ? yv[b][s] : xv[b][s], acc[a][b], 0, 0, 0);
+        }
+  };
+  /* two or more waves per SIMD hide each other's loads (a register-level prefetch costs the
+   * second wave and measured slower) */
+  for (; g < ngroups; g += nrb) {
+    load(g);
+    multiply(yn, xn);
+  }
+  if ((n & 15) && rb == 0) {
+    /* the last, partial group: rows past the end count as zeros */
+    const int64_t r0 = ngroups << 4;
+    double yv[T][4], xv[T][4];
+#pragma unroll
+    for (int t = 0; t < T; t++)
+#pragma unroll
+      for (int s = 0; s < 4; s++) {
+        const bool in = r0 + 4 * k + s < n;
+        yv[t][s] = in ? yc[t][r0 + s] : 0.0;
+        xv[t][s] = in ? xc[t][r0 + s] : 0.0;
+      }
+    multiply(yv, xv);
+  }
+#pragma unroll
+  for (int a = 0; a < T; a++)
+#pragma unroll
+    for (int b = 0; b < T; b++) {
+      if (diag && b < a) continue;
+#pragma unroll
+      for (int v = 0; v < 4; v++) {
+        const int i = i0 + 16 * a + k + 4 * v, j = j0 + 16 * b + c;
+        if (i < ky && j < kx) partial[((int64_t)j * ky + i) * nrb + rb] = acc[a][b][v];
+      }
+    }
+}
+
 /* d_out[j*ky + i] = Y(:,i)^T X(:,j) over the local rows; needs 16-byte aligned columns */
 static int launch_gram(ksg_ctx c, const double *Y, int64_t ldy, int ky, const double *X, int64_t ldx, int kx,
                        int64_t n, double *d_out) {
+  const int gram_sym = (Y == X && ldy == ldx && ky == kx) ? 1 : 0;
+  if ((ky > 16 || kx > 16 || (gram_sym && ky > KSG_GT)) && ldy % 4 == 0 && ldx % 4 == 0 && ((uintptr_t)Y & 31) == 0 && ((uintptr_t)X & 31) == 0 && !getenv("KSG_GRAM_VALU")) {
+    /* more than one register tile: the matrix-core kernel */
+    const int kmax = ky > kx ? ky : kx;
+    const int T = kmax <= 16 ? 1 : (kmax <= 32 ? 2 : 4);
+    const int nby = (ky + 16 * T - 1) / (16 * T), nbx = (kx + 16 * T - 1) / (16 * T);
+    const int sym = gram_sym;
+    const int64_t groups = n >> 4;
+    int nrb = 4096 / (nby * nbx);                  /* 4 waves per SIMD in flight or queued */
+    if (nrb < 8) nrb = 8;
+    if ((int64_t)nrb > groups) nrb = groups > 0 ? (int)groups : 1;
+    const int nwaves = nrb * nby * nbx;
+    KSG_CHK(ksg_ensure_partial(c, (size_t)kx * ky * nrb));
+    const dim3 grid((unsigned)((nwaves + 3) / 4)), block(256);
+    if (T == 1) hipLaunchKernelGGL((k_gram_mfma<1>), grid, block, 0, c->stream, Y, ldy, ky, X, ldx, kx, n, c->d_partial, nrb, nby, nbx, sym);
+    else if (T == 2) hipLaunchKernelGGL((k_gram_mfma<2>), grid, block, 0, c->stream, Y, ldy, ky, X, ldx, kx, n, c->d_partial, nrb, nby, nbx, sym);
+    else hipLaunchKernelGGL((k_gram_mfma<4>), grid, block, 0, c->stream, Y, ldy, ky, X, ldx, kx, n, c->d_partial, nrb, nby, nbx, sym);
+    hipLaunchKernelGGL((k_reduce_partials<0>), dim3(kx * ky), dim3(KSG_BLOCK), 0, c->stream, c->d_partial, nrb, d_out);
+    KSG_HIP(hipGetLastError());
+    if (sym) {
+      /* results below the diagonal were left out: mirror them on the device */
+      hipLaunchKernelGGL(k_mirror_upper, dim3((unsigned)((kx * ky + KSG_BLOCK - 1) / KSG_BLOCK)), dim3(KSG_BLOCK), 0, c->stream, d_out, ky);
+      KSG_HIP(hipGetLastError());
+    }
+    return KSG_OK;
+  }
   const int ngy = (ky + KSG_GT - 1) / KSG_GT, ngx = (kx + KSG_GT - 1) / KSG_GT;
   int WY = ngy < 4 ? ngy : 4;
   int WX = 4 / WY; if (WX > ngx) WX = ngx;

@@ -464,3 +464,39 @@ def test_posted_reductions(gpu_ctx):
     assert off[0].value == 0 and out[0] == ref2
     gpu_ctx.vec_free(yd)
     G.destroy()
+
+
+@pytest.mark.parametrize("n,mx,my,lx,kx,ly,ky", [(4096, 20, 13, 0, 20, 0, 13), (10007, 40, 33, 3, 37, 1, 33),
+                                                  (50021, 70, 66, 0, 70, 2, 66), (17, 65, 65, 0, 65, 0, 65),
+                                                  (3, 9, 12, 0, 9, 0, 12), (100003, 64, 64, 0, 64, 0, 64)])
+def test_dot_matrix_core_kernel(gpu_ctx, n, mx, my, lx, kx, ly, ky):
+    """BVDot with more than one register tile of results runs on the matrix cores
+    (16/32/64-wide blocks, several blocks, row counts that are not multiples of 16):
+    M(ly+i, lx+j) = Y_i^T X_j against the host, integer data exact; X with itself
+    (only the upper blocks are computed, the rest mirrored) symmetric to the bit."""
+    from slepc_amd import ksgpu
+    rng = np.random.default_rng(n + mx)
+    Xa, Ya = rng.standard_normal((n, mx)), rng.standard_normal((n, my))
+    X, Y = ksgpu.DeviceBV(gpu_ctx, n, mx), ksgpu.DeviceBV(gpu_ctx, n, my)
+    X.from_numpy(Xa)
+    Y.from_numpy(Ya)
+    X.set_active(lx, kx)
+    Y.set_active(ly, ky)
+    M = np.full((my, mx), np.nan, order="F")
+    X.dot(Y, M)
+    ref = Ya[:, ly:ky].T @ Xa[:, lx:kx]
+    assert np.abs(M[ly:ky, lx:kx] - ref).max() <= 1e-12 * np.sqrt(n) * 10
+    assert np.isnan(M[:ly, :]).all() and np.isnan(M[:, :lx]).all() and np.isnan(M[ky:, :]).all() and np.isnan(M[:, kx:]).all()
+    S = np.zeros((mx, mx), order="F")
+    X.dot(X, S)
+    G = S[lx:kx, lx:kx]
+    assert np.array_equal(G, G.T)
+    assert np.abs(G - Xa[:, lx:kx].T @ Xa[:, lx:kx]).max() <= 1e-12 * np.sqrt(n) * 10
+    # small integers: every product and sum is exact whatever the order
+    Xi, Yi = rng.integers(-3, 4, (n, mx)).astype(float), rng.integers(-3, 4, (n, my)).astype(float)
+    X.from_numpy(Xi)
+    Y.from_numpy(Yi)
+    X.dot(Y, M)
+    assert np.array_equal(M[ly:ky, lx:kx], Yi[:, ly:ky].T @ Xi[:, lx:kx])
+    X.destroy()
+    Y.destroy()

@@ -59,6 +59,7 @@ def main():
         W.set_active(0, kk)
         M = np.zeros((64, m), order="F")
         run("dot %dx%d" % (kk, kk), "dot", lambda: V.dot(W, M))
+        run("dot %dx%d, V with itself" % (kk, kk), "dot", lambda: V.dot(V, M))
         Qm = np.asfortranarray(np.eye(m, 64) * 0.5 + 1e-3)
         run("mult %dx%d" % (kk, kk), "mult", lambda: W.mult(1.0, 0.0, V, Qm))
     # block product W = A V: one pass over the matrix for all the columns
