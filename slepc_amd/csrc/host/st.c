@@ -191,7 +191,13 @@ PetscErrorCode STSetShift(ST st, PetscScalar shift) {
 }
 PetscErrorCode STGetShift(ST st, PetscScalar *shift) { if (!st || !shift) SETERRQ(PETSC_ERR_ARG_NULL, "Null argument"); *shift = st->sigma; return 0; }
 /* the value sinvert takes when no shift was given: the target of the eigensolver (stfunc.c) */
-PetscErrorCode STSetDefaultShift(ST st, PetscScalar defaultshift) { if (!st) SETERRQ(PETSC_ERR_ARG_NULL, "Null ST"); st->defsigma = defaultshift; return 0; }
+PetscErrorCode STSetDefaultShift(ST st, PetscScalar defaultshift) {
+  PetscErrorCode ierr;
+  if (!st) SETERRQ(PETSC_ERR_ARG_NULL, "Null ST");
+  if (st->state && st->type == 1 && !st->sigma_set && st->defsigma != defaultshift) { ierr = STReset(st);CHKERRQ(ierr); }   /* the operator was built for the old value */
+  st->defsigma = defaultshift;
+  return 0;
+}
 
 PetscErrorCode STSetKSPType(ST st, const char *type) {
   PetscErrorCode ierr;

@@ -503,3 +503,29 @@ def test_pmc_traffic_file_layout():
     assert pmc["workload"].startswith("ex2 2-D 5-point Laplacian 4096x4096")
     for k in ("k_multvec_dot", "k_dotw", "k_spmv_tiles"):
         assert 0.9 < pmc["kernels"][k]["traffic_over_algorithmic"] < 1.2 and pmc["kernels"][k]["launches"] > 0
+
+
+def test_eps_target_changed_between_solves(be):
+    """A second solve with another target rebuilds the shifted operator (the transformation is
+    set up once per shift)."""
+    from slepc_amd import matgen as mg
+    n = 40
+    lam = np.sort(2 - 2 * np.cos(np.arange(1, n + 1) * np.pi / (n + 1)))
+    A = be.mat_csr(*mg.laplacian1d(n))
+    eps = K.EPS(None)
+    eps.set_operators(A)
+    eps.set_problem_type(K.EPS_HEP)
+    eps.set_bv_type("oracle")
+    eps.set_dimensions(2)
+    eps.set_tolerances(1e-10)
+    st = eps.st()
+    st.set_type("sinvert")
+    for target in (0.7, 3.1):
+        eps.set_target(target)
+        eps.solve()
+        want = lam[np.argsort(np.abs(lam - target))][:2]
+        got = [eps.get_eigenvalue(i)[0] for i in range(2)]
+        assert np.abs(np.array(got) - want).max() < 1e-8, (target, got, want)
+        assert abs(st.get_shift() - target) < 1e-15
+    eps.destroy()
+    A.destroy()
