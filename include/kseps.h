@@ -212,6 +212,10 @@ struct _BVOps {
    * bvimpl.h:35-64) -- queues X(:,l:k)^T y in the batch opened on the context of the template
    * vector and returns the index of its first value */
   PetscErrorCode (*dotvec_post)(BV X, Vec y, PetscInt *offset);
+  /* optional (may be NULL): QR factorisation of columns [0,k) by a method that forms no Gram
+   * matrix, V <- Q, R (ldr x k, may be NULL) -- what BVOrthogonalize_TSQR (bvorthog.c:770-782)
+   * does on the host array of the basis */
+  PetscErrorCode (*orthogonalize_tsqr)(BV V, PetscScalar *R, PetscInt ldr);
 };
 
 /* struct _p_BV of bvimpl.h:66-105 (the fields this path uses). */

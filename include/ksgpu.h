@@ -178,6 +178,13 @@ int ksg_bv_mult(ksg_bv Y, double alpha, double beta, ksg_bv X, const double *Q_h
 /* M(ly:ky, lx:kx) = Y^T X, M host array with leading dimension ldm; collective
  * (BVDot_Svec svec.c:102). */
 int ksg_bv_dot(ksg_bv X, ksg_bv Y, double *M_host, int ldm);
+/* Tall-skinny QR of columns [0,k): V = Q R with Q^T Q = I left in V and R (upper triangular,
+ * positive diagonal, host array ldr x k, may be NULL); collective.  At most 64 columns, no
+ * constraints; numerically dependent columns are an error.  (BVOrthogonalize_TSQR
+ * bvorthog.c:770 -> BVOrthogonalize_LAPACK_Private bvblas.c:345: geqrf/orgqr on the local
+ * rows plus a QR of the stacked triangles, two processes at most; here a Householder
+ * reduction tree on the device for R, any number of ranks, and Q = V R^-1 in two sweeps.) */
+int ksg_bv_tsqr(ksg_bv V, double *R_host, int ldr);
 /* W(:,lw+j) = A*V(:,lv+j), column by column (BVMatMult_Svec svec.c:216,250-256). */
 int ksg_bv_matmult(ksg_bv V, ksg_mat A, ksg_bv W);
 

@@ -1132,9 +1132,12 @@ PetscErrorCode BVOrthogonalize(BV V, PetscScalar *R, PetscInt ldr) {
   switch (V->orthog_block) {
     case BV_ORTHOG_BLOCK_GS: ierr = BVOrthogonalize_GS(V, R, ldr);CHKERRQ(ierr); break;
     case BV_ORTHOG_BLOCK_CHOL: ierr = BVOrthogonalize_Chol(V, R, ldr);CHKERRQ(ierr); break;
-    default:
+    default:                                       /* bvorthog.c:851-854, 770-782 */
       if (V->matrix) SETERRQ(PETSC_ERR_SUP, "Orthogonalization method not available for non-standard inner product");
-      SETERRQ(PETSC_ERR_SUP, "The tall-skinny QR block orthogonalization is not available");
+      if (!V->ops.orthogonalize_tsqr) SETERRQ(PETSC_ERR_SUP, "The tall-skinny QR block orthogonalization is not available for BV type %s", V->type_name);
+      if (R) for (PetscInt j = 0; j < V->k; j++) memset(R + (size_t)j * ldr, 0, (size_t)V->k * sizeof(PetscScalar));
+      ierr = V->ops.orthogonalize_tsqr(V, R, ldr);CHKERRQ(ierr);
+      break;
   }
   V->state++;
   return 0;

@@ -105,6 +105,12 @@ static PetscErrorCode BVMatMult_HIP(BV V, Mat A, BV W) {
   }
   SETERRQ(PETSC_ERR_SUP, "BVMatMult needs an operator created on the same context");
 }
+static PetscErrorCode BVOrthogonalizeTSQR_HIP(BV V, PetscScalar *R, PetscInt ldr) {
+  PetscErrorCode ierr;
+  ierr = Sync(V);CHKERRQ(ierr);
+  CHKKSG(ksg_bv_tsqr(GBV(V), R, R ? ldr : 1));
+  return 0;
+}
 static PetscErrorCode BVCopy_HIP(BV V, BV W) {
   PetscErrorCode ierr;
   ierr = Sync(V);CHKERRQ(ierr);
@@ -156,5 +162,6 @@ PetscErrorCode BVCreate_HIP(BV bv) {
   bv->ops.restorecolumn = BVRestoreColumn_HIP;
   bv->ops.destroy = BVDestroy_HIP;
   bv->ops.dotvec_post = BVDotVecPost_HIP;
+  bv->ops.orthogonalize_tsqr = BVOrthogonalizeTSQR_HIP;
   return 0;
 }

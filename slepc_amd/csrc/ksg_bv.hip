@@ -217,8 +217,9 @@ __device__ __forceinline__ void mvd_rows(const double2 *const (&col)[CW], const 
                                          double (&acc)[CW], double &self) {
   const int64_t step = (int64_t)gridDim.x * 64;
   int buf = 0;
+  int sw = 0;                                       /* the wave that stores this step's rows */
   /* the trip count is the same for every thread of the workgroup: the barrier inside is safe */
-  for (int64_t p0 = (int64_t)blockIdx.x * 64; p0 < npair; p0 += step, buf ^= 1) {
+  for (int64_t p0 = (int64_t)blockIdx.x * 64; p0 < npair; p0 += step, buf ^= 1, sw = (sw + 1) & (NW - 1)) {
     const int64_t p = p0 + lane;
     const bool live = p < npair;
     const int64_t pc = live ? p : npair - 1;
@@ -255,7 +256,7 @@ __device__ __forceinline__ void mvd_rows(const double2 *const (&col)[CW], const 
     }
     if (post != 1.0) { r.x *= post; r.y *= post; }
     if (!live) r = make_double2(0.0, 0.0);
-    if (w == 0 && live && store) y2[p] = r;
+    if (w == sw && live && store) y2[p] = r;
     if (dots) {
       if (w == 0) self = dot_acc(r, r, self);
 #pragma unroll

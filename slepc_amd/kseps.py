@@ -119,7 +119,8 @@ class BVOps(C.Structure):
                 ("getcolumn", C.CFUNCTYPE(Err, BVP, C.c_int, C.POINTER(VecP))),
                 ("restorecolumn", C.CFUNCTYPE(Err, BVP, C.c_int, C.POINTER(VecP))),
                 ("destroy", C.CFUNCTYPE(Err, BVP)),
-                ("dotvec_post", C.CFUNCTYPE(Err, BVP, VecP, C.POINTER(C.c_int)))]
+                ("dotvec_post", C.CFUNCTYPE(Err, BVP, VecP, C.POINTER(C.c_int))),
+                ("orthogonalize_tsqr", C.CFUNCTYPE(Err, BVP, c_dp, C.c_int))]
 
 
 BVStruct._fields_ = [("ops", BVOps), ("type_name", C.c_char * 32), ("t", VecP), ("n", c_i64),

@@ -83,6 +83,7 @@ SIGNATURES = {
     "ksg_bv_copy_column": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "ksg_bv_mult": (C.c_int, [C.c_void_p, C.c_double, C.c_double, C.c_void_p, c_dp, C.c_int]),
     "ksg_bv_dot": (C.c_int, [C.c_void_p, C.c_void_p, c_dp, C.c_int]),
+    "ksg_bv_tsqr": (C.c_int, [C.c_void_p, c_dp, C.c_int]),
     "ksg_mat_hot_columns": (C.c_int, [C.c_void_p, C.POINTER(c_i64)]),
     "ksg_bv_set_num_constraints": (C.c_int, [C.c_void_p, C.c_int]),
     "ksg_bv_matmult": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -355,6 +356,15 @@ class DeviceBV:
 
     def matmult(self, A, W):
         check(self.lib.ksg_bv_matmult(self.h, A.h, W.h))
+
+    def tsqr(self, R=None):
+        """Columns [0,k) <- Q of their QR factorisation; R (Fortran-ordered, at least k x k) receives the triangle."""
+        if R is None:
+            check(self.lib.ksg_bv_tsqr(self.h, None, 1))
+        else:
+            assert R.flags.f_contiguous
+            check(self.lib.ksg_bv_tsqr(self.h, _dptr(R), R.shape[0]))
+        return R
 
 
 class DeviceCSR:

@@ -703,6 +703,44 @@ def run_bv_test11(be, block, n=20, l=2, k=8):
         be.destroy_bv(Y)
 
 
+def run_bv_test11_tsqr(be, n=20, l=2, k=8):
+    """src/sys/classes/bv/examples/tests/test11.c with -bv_orthog_block tsqr (golden output
+    test11_3_tsqr.out: "Level of orthogonality < 100*eps"; the inner-product half is skipped
+    there, test11.c:129).  The factorisation covers the columns from the first one whatever the
+    leading index (bvorthog.c:778); Q and R are also compared with numpy's Householder QR."""
+    lib = be.lib
+    X0 = np.zeros((n, k))
+    if n == 20:
+        for j in range(k):
+            for i in range(n // 2 + 1):
+                if i + j < n:
+                    X0[i + j, j] = (3.0 * i + j - 2) / (2 * (i + j + 1))
+        tol = 100 * np.finfo(float).eps
+    else:
+        X0 = np.random.default_rng(n).standard_normal((n, k))
+        tol = 1e-12
+    Qo, Ro = np.linalg.qr(X0)
+    s = np.where(np.diag(Ro) < 0, -1.0, 1.0)
+    Qo, Ro = Qo * s, (Ro.T * s).T
+    for want_R in (False, True):
+        Y = be.bv(n, k)
+        K.check(lib.BVSetOrthogonalization(Y, K.BV_ORTHOG_CGS, K.BV_ORTHOG_REFINE_IFNEEDED, 0.0, K.BV_ORTHOG_BLOCK_TSQR))
+        for j in range(k):
+            be.set_col(Y, j, X0[:, j])
+        K.check(lib.BVSetActiveColumns(Y, l, k))
+        R = np.full((k, k), 7.0, order="F")
+        K.check(lib.BVOrthogonalize(Y, dp(R) if want_R else None, k))
+        Q = be.to_numpy(Y)
+        M = np.eye(k)
+        M[l:, l:] = Q[:, l:].T @ Q[:, l:]
+        assert np.abs(M - np.eye(k)).sum(axis=0).max() < tol      # MatNorm(M,NORM_1)
+        assert np.abs(Q - Qo).max() < 1e-11
+        if want_R:
+            assert np.abs(np.tril(R, -1)).max() == 0.0
+            assert np.abs(Q @ R - X0).max() < 1e-12 and np.abs(R - Ro).max() < 1e-10
+        be.destroy_bv(Y)
+
+
 def solve_svd(be, csr, ncols, nsv=1, ncv=0, mpd=0, tol=0.0, max_it=0, which="largest", solver=None, oneside=False,
               conv=None, v0=None, want_vectors=False):
     """SVDCreate / SVDSetOperator / ... / SVDSolve / SVDGetSingularTriplet / SVDComputeError."""

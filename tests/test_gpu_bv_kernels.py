@@ -500,3 +500,69 @@ def test_dot_matrix_core_kernel(gpu_ctx, n, mx, my, lx, kx, ly, ky):
     assert np.array_equal(M[ly:ky, lx:kx], Yi[:, ly:ky].T @ Xi[:, lx:kx])
     X.destroy()
     Y.destroy()
+
+
+def _qr_pos(A):
+    """Householder QR of numpy with the diagonal of R made positive (the unique factorisation)."""
+    Q, R = np.linalg.qr(A)
+    s = np.where(np.diag(R) < 0, -1.0, 1.0)
+    return Q * s, (R.T * s).T
+
+
+@pytest.mark.parametrize("n,m,k,cond", [(20, 8, 8, 1.0), (1000, 5, 5, 1.0), (30011, 40, 40, 1.0), (100003, 65, 64, 1.0),
+                                         (64, 64, 64, 1.0), (4097, 33, 17, 1e9), (200000, 16, 16, 1e10), (65, 3, 1, 1.0)])
+def test_tsqr(gpu_ctx, n, m, k, cond):
+    """ksg_bv_tsqr against numpy's Householder QR: Q orthogonal to a few eps whatever the
+    conditioning (columns scaled over `cond` and mixed), V = Q R, R upper triangular with a
+    positive diagonal, Q and R equal to the unique factorisation up to the conditioning; columns
+    beyond k untouched."""
+    from slepc_amd import ksgpu
+    rng = np.random.default_rng(n + k)
+    A = rng.standard_normal((n, m))
+    if cond > 1.0:
+        # singular values from 1 down to 1/cond
+        U, _ = np.linalg.qr(rng.standard_normal((n, k)))
+        W, _ = np.linalg.qr(rng.standard_normal((k, k)))
+        A[:, :k] = (U * np.logspace(0, -np.log10(cond), k)) @ W.T
+    G = ksgpu.DeviceBV(gpu_ctx, n, m)
+    G.from_numpy(A)
+    G.set_active(min(2, k - 1), k)                      # the leading index is ignored, as in the reference
+    R = np.full((m, m), np.nan, order="F")
+    G.tsqr(R)
+    Q = G.to_numpy()
+    eps = np.finfo(float).eps
+    assert np.abs(Q[:, :k].T @ Q[:, :k] - np.eye(k)).sum(axis=0).max() < 100 * eps * max(1.0, np.sqrt(k))
+    assert np.array_equal(Q[:, k:], A[:, k:])
+    Rk = R[:k, :k]
+    assert np.abs(np.tril(Rk, -1)).max() == 0.0 and (np.diag(Rk) > 0).all()
+    assert np.isnan(R[k:, :]).all() and np.isnan(R[:, k:]).all()
+    scale = np.abs(A[:, :k]).max()
+    assert np.abs(Q[:, :k] @ Rk - A[:, :k]).max() < 50 * eps * scale * np.sqrt(k)
+    Qo, Ro = _qr_pos(A[:, :k])
+    assert np.abs(Rk - Ro).max() < 1e-13 * cond * np.abs(Ro).max() * k
+    if cond == 1.0:
+        assert np.abs(Q[:, :k] - Qo).max() < 1e-11
+    G.destroy()
+
+
+def test_tsqr_errors(gpu_ctx):
+    """Numerically dependent columns, too many columns and constraints are refused; the basis
+    stays usable."""
+    from slepc_amd import ksgpu
+    rng = np.random.default_rng(5)
+    A = rng.standard_normal((500, 70))
+    A[:, 3] = A[:, 1] - 2.0 * A[:, 2]
+    G = ksgpu.DeviceBV(gpu_ctx, 500, 70)
+    G.from_numpy(A)
+    G.set_active(0, 6)
+    with pytest.raises(ksgpu.KsgError):
+        G.tsqr()
+    G.set_active(0, 70)
+    with pytest.raises(ksgpu.KsgError):
+        G.tsqr()
+    G.from_numpy(A)
+    G.set_active(0, 3)
+    G.tsqr()
+    Q = G.to_numpy()[:, :3]
+    assert np.abs(Q.T @ Q - np.eye(3)).max() < 1e-14
+    G.destroy()

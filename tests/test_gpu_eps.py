@@ -43,6 +43,11 @@ def test_bv_test11(be, block):
     common.run_bv_test11(be, block, n=30011, l=3, k=40)       # the Gram and block-update kernels at width 40
 
 
+def test_bv_test11_tsqr(be):
+    common.run_bv_test11_tsqr(be)
+    common.run_bv_test11_tsqr(be, n=30011, l=3, k=40)
+
+
 def test_bv_test13(be):
     common.run_bv_test13(be)
 
