@@ -222,6 +222,33 @@ def bv_ip_main(mode, out, rank, size, dist):
             full.append(np.concatenate(parts))
         cols = full
     res["Q"] = [a.tolist() for a in cols]
+    # tall-skinny QR of a second basis (standard inner product, no constraints): the reference
+    # runs bv test11 with -bv_orthog_block tsqr on two processes
+    kq = 6
+    Y = K.BVP()
+    K.check(lib.BVCreate(None, C.byref(Y)))
+    K.check(lib.BVSetSizesFromVec(Y, t.p, kq))
+    K.check(lib.BVSetType(Y, b"hip"))
+    K.check(lib.BVSetOrthogonalization(Y, K.BV_ORTHOG_CGS, K.BV_ORTHOG_REFINE_IFNEEDED, 0.0, K.BV_ORTHOG_BLOCK_TSQR))
+    for j in range(kq):
+        K.check(lib.BVGetColumn(Y, j, C.byref(col)))
+        K.check(lib.VecSetValuesHost(col, dp(np.ascontiguousarray(np.cos((j + 2) * (g + 1) / 13.0) + 0.25 * (g == 5 * j)))))
+        K.check(lib.BVRestoreColumn(Y, j, C.byref(col)))
+    Rq = np.zeros((kq, kq), order="F")
+    K.check(lib.BVOrthogonalize(Y, dp(Rq), kq))
+    qcols = []
+    for j in range(kq):
+        a = np.empty(n)
+        K.check(lib.BVGetColumn(Y, j, C.byref(col)))
+        K.check(lib.VecGetValuesHost(col, dp(a)))
+        K.check(lib.BVRestoreColumn(Y, j, C.byref(col)))
+        if size > 1:
+            parts = [None] * size
+            dist.all_gather_object(parts, a)
+            a = np.concatenate(parts)
+        qcols.append(a.tolist())
+    res["tsqr_Q"], res["tsqr_R"] = qcols, Rq.tolist()
+    K.check(lib.BVDestroy(C.byref(Y)))
     if rank == 0:
         with open(out, "w") as f:
             json.dump(res, f)

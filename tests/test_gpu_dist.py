@@ -64,6 +64,16 @@ def test_bv_inner_product_and_constraints_ranks_match_single(ranks):
     B = 2 * np.eye(n) - np.eye(n, k=1) - np.eye(n, k=-1)
     W = Qm @ B @ Qm.T
     assert np.abs(W - np.eye(W.shape[0])).max() < 1e-12
+    # the tall-skinny QR: orthonormal columns, and the one factorisation with a positive
+    # diagonal whatever the number of ranks
+    T1, Tm = np.array(one["tsqr_Q"]), np.array(many["tsqr_Q"])
+    assert np.abs(Tm @ Tm.T - np.eye(Tm.shape[0])).max() < 1e-14
+    assert np.abs(T1 - Tm).max() < 1e-12
+    R1, Rm = np.array(one["tsqr_R"]), np.array(many["tsqr_R"])
+    assert np.abs(R1 - Rm).max() < 1e-12 * np.abs(R1).max() and (np.diag(Rm) > 0).all()
+    g = np.arange(n, dtype=float)
+    Y0 = np.array([np.cos((j + 2) * (g + 1) / 13.0) + 0.25 * (g == 5 * j) for j in range(Tm.shape[0])]).T
+    assert np.abs(Tm.T @ Rm - Y0).max() < 1e-12
 
 
 @pytest.mark.parametrize("case,ranks", [("gen_sinvert", 2), ("gen_shift", 3)])
