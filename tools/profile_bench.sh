@@ -8,7 +8,9 @@ OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
-ARGS="--steps 5 --warmup 2 --no-cpu-baseline"
+# BENCH_ARGS overrides the workload, e.g. "--workload lap3d --grid 512 --steps 3 --warmup 2 --no-cpu-baseline"
+ARGS=${BENCH_ARGS:-"--steps 5 --warmup 2 --no-cpu-baseline"}
+export ARGS
 timeout -k 10 400 rocprofv3 --kernel-trace --stats -d $OUT -o trace --output-format csv -- python3 $R/bench.py $ARGS > $OUT/bench_trace.json 2> $OUT/trace.err
 timeout -s KILL 400 rocprofv3 --pmc FETCH_SIZE -d $OUT -o fetch --output-format csv -- python3 $R/bench.py $ARGS > $OUT/bench_fetch.json 2> $OUT/fetch.err
 timeout -s KILL 400 rocprofv3 --pmc WRITE_SIZE -d $OUT -o write --output-format csv -- python3 $R/bench.py $ARGS > $OUT/bench_write.json 2> $OUT/write.err
@@ -17,12 +19,12 @@ python3 tools/prof_summary.py trace $OUT/trace_kernel_trace.csv > $OUT/summary_t
 python3 tools/prof_summary.py pmc $OUT/fetch_counter_collection.csv $OUT/write_counter_collection.csv $OUT/bench_trace.json > $OUT/summary_pmc.txt
 # the file bench.py reads for roofline.traffic (copy it to profiles/pmc_traffic.json)
 python3 - "$OUT" <<'PY'
-import json, sys
+import json, os, sys
 out = sys.argv[1]
 kern = json.loads(open(out + "/summary_pmc.txt").read().strip().splitlines()[-1])
 line = json.loads(open(out + "/bench_trace.json").read().strip().splitlines()[-1])
-json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) of `python3 bench.py --steps 5 --warmup 2 "
-                     "--no-cpu-baseline`, dispatches between the bench markers; traffic = (2*FETCH_SIZE + WRITE_SIZE)*1024 bytes "
+json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) of `python3 bench.py " + os.environ["ARGS"] +
+                     "`, dispatches between the bench markers; traffic = (2*FETCH_SIZE + WRITE_SIZE)*1024 bytes "
                      "(FETCH_SIZE reads half of a wide coalesced stream on gfx950; calibrated on k_scale_cols, 8n read + 8n written "
                      "per launch: profiles/r01c_bench_pmc_summary.txt)",
            "workload": line["config"]["workload"], "steps": line["steps"], "warmup": line["warmup"], "kernels": kern},
