@@ -144,7 +144,7 @@ def main():
     else:
         N = 1 << g
         row0, row1 = matgen.split_rows(N, size, rank)
-        rp, ci, va = matgen.rmat_laplacian(g, row0=row0, row1=row1)
+        rp, ci, va = matgen.rmat_laplacian(g, row0=row0, row1=row1, progress=(lambda t: print(t, file=sys.stderr, flush=True)) if rank == 0 and g > 23 else None)
         wname = "R-MAT scale %d graph Laplacian (%d rows), symmetric Krylov-Schur nev=%d" % (g, N, args.nev)
     if rank == 0:
         print("operator: %s, %d local rows, %d local entries, generated in %.1f s" % (

@@ -209,15 +209,21 @@ static int tsqr_triangle(ksg_bv V, int k, double *Rd) {
     for (int g = 1; g < nt; g++) fold_triangle(k, R.data(), T.data() + (size_t)g * tri);
   }
   if (c->nranks > 1) {
-    /* every rank receives every triangle and folds them in rank order: the same R everywhere */
+    /* every rank receives the triangles of the others and folds all of them in rank order:
+     * the same R everywhere.  Nothing is sent to the rank itself. */
     const int P = c->nranks;
-    std::vector<double> send((size_t)P * tri), recv((size_t)P * tri);
     std::vector<int64_t> off(P + 1);
-    for (int p = 0; p <= P; p++) off[p] = (int64_t)p * tri;
-    for (int p = 0; p < P; p++) memcpy(send.data() + (size_t)p * tri, R.data(), (size_t)tri * sizeof(double));
+    off[0] = 0;
+    for (int p = 0; p < P; p++) off[p + 1] = off[p] + (p == c->rank ? 0 : tri);
+    std::vector<double> send((size_t)off[P] + 1), recv((size_t)off[P] + 1), own(R);
+    for (int p = 0; p < P; p++)
+      if (p != c->rank) memcpy(send.data() + off[p], own.data(), (size_t)tri * sizeof(double));
     KSG_CHK(ksg_comm_exchange_host(c, send.data(), off.data(), recv.data(), off.data()));
-    memcpy(R.data(), recv.data(), (size_t)tri * sizeof(double));
-    for (int p = 1; p < P; p++) fold_triangle(k, R.data(), recv.data() + (size_t)p * tri);
+    for (int p = 0; p < P; p++) {
+      double *Tp = p == c->rank ? own.data() : recv.data() + off[p];
+      if (p == 0) memcpy(R.data(), Tp, (size_t)tri * sizeof(double));
+      else fold_triangle(k, R.data(), Tp);
+    }
   }
   for (int j = 0; j < k; j++)
     for (int i = 0; i < k; i++) Rd[i + (size_t)j * k] = i <= j ? R[tri_idx(i, j)] : 0.0;

@@ -105,9 +105,10 @@ def markov(m, row0=0, row1=None):
 
 
 def rmat_laplacian(scale, edge_factor=8, a=0.57, b=0.19, c=0.19, seed=0x5EED, row0=0, row1=None,
-                   chunk=1 << 24):
+                   chunk=1 << 24, progress=None):
     """Graph Laplacian D - A of a symmetrised R-MAT graph with 2**scale vertices:
-    power-law row lengths, unit weights, duplicates and self-loops removed."""
+    power-law row lengths, unit weights, duplicates and self-loops removed.
+    `progress(text)` is called every few seconds of work (large scales take minutes)."""
     N = 1 << scale
     row1 = N if row1 is None else row1
     ne = edge_factor * N
@@ -132,17 +133,51 @@ def rmat_laplacian(scale, edge_factor=8, a=0.57, b=0.19, c=0.19, seed=0x5EED, ro
         src_l.append(s2[mine])
         dst_l.append(d2[mine])
         done += cnt
+        if progress:
+            progress("R-MAT: %d of %d edges drawn" % (done, ne))
     src = np.concatenate(src_l)
     dst = np.concatenate(dst_l)
-    key = np.unique(src * N + dst)
-    src = key // N
-    dst = key - src * N
+    del src_l, dst_l
+    key = src * N + dst
+    del src, dst
+    # duplicates removed bucket by bucket of the row range (the same sorted result as one
+    # np.unique over everything, in pieces small enough to report progress between them)
+    nbuck = max(1, min(16, key.size >> 26))
+    if nbuck == 1:
+        key = np.unique(key)
+    else:
+        edges = [(row0 + (row1 - row0) * i // nbuck) * N for i in range(nbuck + 1)]
+        parts = []
+        for i in range(nbuck):
+            parts.append(np.unique(key[(key >= edges[i]) & (key < edges[i + 1])]))
+            if progress:
+                progress("R-MAT: duplicates removed in %d of %d row ranges" % (i + 1, nbuck))
+        key = np.concatenate(parts)
+        del parts
+    # key is sorted by (row, column): the CSR follows without another sort, the diagonal entry
+    # of each row (its degree) slipped in at its place among the columns
     n_local = row1 - row0
-    deg = np.bincount(src - row0, minlength=n_local).astype(np.float64)
-    rows = np.concatenate((src - row0, np.arange(n_local, dtype=np.int64)))
-    cols = np.concatenate((dst, np.arange(row0, row1, dtype=np.int64)))
-    vals = np.concatenate((-np.ones(src.size), deg))
-    return _finish(n_local, rows, cols, vals)
+    src = key // N
+    dst = (key - src * N).astype(np.int32)
+    counts = np.bincount(src - row0, minlength=n_local)
+    del src
+    rowptr = np.zeros(n_local + 1, dtype=np.int64)
+    np.cumsum(counts + 1, out=rowptr[1:])
+    g = np.arange(row0, row1, dtype=np.int64)
+    pos = np.searchsorted(key, g * N + g) + np.arange(n_local, dtype=np.int64)
+    del key
+    total = int(rowptr[-1])
+    diag = np.zeros(total, dtype=bool)
+    diag[pos] = True
+    colidx = np.empty(total, dtype=np.int32)
+    colidx[pos] = g
+    colidx[~diag] = dst
+    del dst
+    val = np.full(total, -1.0)
+    val[pos] = counts
+    if progress:
+        progress("R-MAT: CSR of %d rows, %d entries built" % (n_local, total))
+    return rowptr, colidx, val
 
 
 def split_rows(N, nranks, rank):
