@@ -68,11 +68,11 @@ void *ksg_ctx_stream(ksg_ctx ctx);
  * first.  The stored values are bit for bit those of separate launches.
  * KSG_OPT_DOT_GRID / KSG_OPT_MV_GRID: upper bound on the workgroups along the rows of
  * the reduction (default 256, one per CU) and update (default 1024) kernels.
- * KSG_OPT_HOT_COLS (default 262144 = 2 MiB of x, half of one XCD's L2; 0 disables): a CSR
- * operator created afterwards whose local column block has more than four times that many
- * columns, with columns referenced at least four times as often as the average that together
+ * KSG_OPT_HOT_COLS (default 1048576 = 8 MiB of x; 0 disables): a CSR operator created
+ * afterwards whose local column block has more than four times that many columns (262144 =
+ * 2 MiB, half of one XCD's L2, are tried for a smaller one), with columns referenced at least four times as often as the average that together
  * hold 15 % or more of the entries (power-law graphs), keeps a packed copy of the x entries of
- * its most referenced columns: each product gathers them into a dense array that stays in L2,
+ * its most referenced columns: each product gathers them into a dense array that stays in cache,
  * and the matrix entries of those columns index it instead of x.  Same values, same order
  * of sums: results are bit for bit those without the packing. */
 enum { KSG_OPT_FUSE_DOTS = 1, KSG_OPT_DOT_GRID = 2, KSG_OPT_MV_GRID = 3, KSG_OPT_LAZY_UPDATE = 4, KSG_OPT_HOT_COLS = 5 };

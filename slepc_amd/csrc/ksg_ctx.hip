@@ -39,7 +39,7 @@ extern "C" int ksg_ctx_create(int device, ksg_ctx *out) {
   c->gen = 0;
   c->fuse_dots = 1;
   c->lazy_update = 1;
-  c->hot_cols = 262144;
+  c->hot_cols = 1048576;
   c->pend.active = false;
   c->dot_grid = KSG_DOT_GRID;
   c->mv_grid = KSG_MV_GRID;

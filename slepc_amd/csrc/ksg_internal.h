@@ -105,6 +105,9 @@ struct ksg_csr_dev {
   double *val;
   int32_t *tiles;    /* ntiles+1 row boundaries */
   int64_t *tile_p;   /* rowptr at those boundaries */
+  uint16_t *rowoff;  /* nrows + ntiles entries: tile i holds, from index tiles[i] + i on, the
+                      * entry offsets of its rows relative to the tile's first entry (one more
+                      * than it has rows); 2 bytes per row instead of the 8 of rowptr */
   int64_t ntiles;
   int64_t n_stream, n_group, n_long;
 };

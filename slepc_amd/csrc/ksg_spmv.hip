@@ -72,7 +72,7 @@ __device__ __forceinline__ double x_entry(const double *__restrict__ x, const do
 template <int RES, int HOT>
 __global__ __launch_bounds__(KSG_BLOCK) void k_spmv_tiles(const int32_t *__restrict__ tiles,
                                                            const int64_t *__restrict__ tile_p,
-                                                           const int64_t *__restrict__ rowptr,
+                                                           const uint16_t *__restrict__ rowoff,
                                                            const int32_t *__restrict__ colidx,
                                                            const double *__restrict__ val,
                                                            const double *__restrict__ x,
@@ -130,12 +130,13 @@ __global__ __launch_bounds__(KSG_BLOCK) void k_spmv_tiles(const int32_t *__restr
   /* this thread's row bounds, requested before the entry stream so that their latency
    * hides behind it */
   constexpr int RPT = KSG_TILE_ROWS / KSG_BLOCK;          /* rows per thread */
-  int64_t rb[RPT], re[RPT];
+  const uint16_t *ro = rowoff + r0 + blockIdx.x;        /* this tile's row offsets, relative to p0 */
+  int rb[RPT], re[RPT];
 #pragma unroll
   for (int j = 0; j < RPT; j++) {
     const int lr = threadIdx.x + j * KSG_BLOCK;
     rb[j] = re[j] = 0;
-    if (lr < nrows) { rb[j] = rowptr[r0 + lr]; re[j] = rowptr[r0 + lr + 1]; }
+    if (lr < nrows) { rb[j] = ro[lr]; re[j] = ro[lr + 1]; }
   }
 
   /* stream the tile's entries: val/colidx are read once (coalesced, non-temporal, all of
@@ -174,7 +175,7 @@ __global__ __launch_bounds__(KSG_BLOCK) void k_spmv_tiles(const int32_t *__restr
     for (int j = 0; j < RPT; j++) {
       const int lr = threadIdx.x + j * KSG_BLOCK;
       if (lr < nrows) {
-        const int b = (int)(rb[j] - p0), e = (int)(re[j] - p0);
+        const int b = rb[j], e = re[j];
         double s = 0.0;
         for (int t = b; t < e; t++) s += prod[t];
         spmv_emit<RES>(s, r0 + lr, x, y, kr, ki, xi, acc, true);
@@ -187,8 +188,7 @@ __global__ __launch_bounds__(KSG_BLOCK) void k_spmv_tiles(const int32_t *__restr
     const int lr = threadIdx.x / G, g = threadIdx.x % G;
     double s = 0.0;
     if (lr < nrows) {
-      const int r = r0 + lr;
-      const int b = (int)(rowptr[r] - p0), e = (int)(rowptr[r + 1] - p0);
+      const int b = ro[lr], e = ro[lr + 1];
       for (int t = b + g; t < e; t += G) s += prod[t];
     }
     s = wave_sum_width(s, G);
@@ -423,6 +423,9 @@ static int upload(T **dst, const T *src, size_t count) {
 static void choose_hot_columns(int64_t ncols, int64_t nnz, const int32_t *colidx, int64_t maxhot,
                                std::vector<int32_t> &hot, std::vector<int32_t> &relabeled) {
   hot.clear(); relabeled.clear();
+  /* the packed array has to stay much smaller than x: operators too small for the full limit
+   * get the 2 MiB (one half of an XCD's L2) that suits them */
+  if (ncols <= 4 * maxhot && maxhot > 262144) maxhot = 262144;
   if (maxhot <= 0 || ncols <= 4 * maxhot || nnz == 0 || ncols + maxhot > (int64_t)INT32_MAX) return;
   std::vector<int32_t> cnt((size_t)ncols, 0);
   for (int64_t p = 0; p < nnz; p++) cnt[colidx[p]]++;
@@ -460,6 +463,14 @@ static int csr_to_device(ksg_csr_dev *D, int64_t nrows, const int64_t *rowptr, c
   std::vector<int64_t> tile_p(tiles.size());
   for (size_t i = 0; i < tiles.size(); i++) tile_p[i] = rowptr[tiles[i]];
   KSG_CHK(upload(&D->tile_p, tile_p.data(), tile_p.size()));
+  /* row offsets inside the tiles (a tile that is one long row has no use for them) */
+  std::vector<uint16_t> rowoff((size_t)nrows + (size_t)D->ntiles + 1, 0);
+  for (int64_t i = 0; i < D->ntiles; i++) {
+    const int64_t base = rowptr[tiles[i]];
+    if (rowptr[tiles[i + 1]] - base > KSG_TILE_NNZ) continue;
+    for (int64_t r = tiles[i]; r <= tiles[i + 1]; r++) rowoff[(size_t)(r + i)] = (uint16_t)(rowptr[r] - base);
+  }
+  KSG_CHK(upload(&D->rowoff, rowoff.data(), rowoff.size()));
   return KSG_OK;
 }
 
@@ -481,6 +492,7 @@ static void csr_free(ksg_csr_dev *D) {
   if (D->val) hipFree(D->val);
   if (D->tiles) hipFree(D->tiles);
   if (D->tile_p) hipFree(D->tile_p);
+  if (D->rowoff) hipFree(D->rowoff);
   memset(D, 0, sizeof(*D));
 }
 
@@ -832,11 +844,11 @@ static int mat_mult_raw(ksg_mat A, const double *x, double *y) {
   if (A->diag.ntiles && A->nhot) {
     hipLaunchKernelGGL(k_gather, dim3(ksg_grid_for(A->nhot)), dim3(KSG_BLOCK), 0, c->stream, x, A->d_hot_idx, A->d_xhot, A->nhot);
     hipLaunchKernelGGL((k_spmv_tiles<0, 1>), dim3((unsigned)A->diag.ntiles), dim3(KSG_BLOCK), 0, c->stream,
-                       A->diag.tiles, A->diag.tile_p, A->diag.rowptr, A->diag.colidx, A->diag.val, x, y, 0.0, 0.0,
+                       A->diag.tiles, A->diag.tile_p, A->diag.rowoff, A->diag.colidx, A->diag.val, x, y, 0.0, 0.0,
                        (const double *)NULL, (double *)NULL, (const double *)A->d_xhot, (int32_t)A->nc);
   } else if (A->diag.ntiles)
     hipLaunchKernelGGL((k_spmv_tiles<0, 0>), dim3((unsigned)A->diag.ntiles), dim3(KSG_BLOCK), 0, c->stream,
-                       A->diag.tiles, A->diag.tile_p, A->diag.rowptr, A->diag.colidx, A->diag.val, x, y, 0.0, 0.0,
+                       A->diag.tiles, A->diag.tile_p, A->diag.rowoff, A->diag.colidx, A->diag.val, x, y, 0.0, 0.0,
                        (const double *)NULL, (double *)NULL, (const double *)NULL, (int32_t)0);
   KSG_HIP(hipGetLastError());
   if (halo) {
@@ -885,11 +897,11 @@ extern "C" int ksg_mat_residual_norm(ksg_mat A, double kr, double ki, const doub
       if (A->nhot) {
         hipLaunchKernelGGL(k_gather, dim3(ksg_grid_for(A->nhot)), dim3(KSG_BLOCK), 0, c->stream, x, A->d_hot_idx, A->d_xhot, A->nhot);
         hipLaunchKernelGGL((k_spmv_tiles<1, 1>), dim3((unsigned)nb), dim3(KSG_BLOCK), 0, c->stream, A->diag.tiles, A->diag.tile_p,
-                           A->diag.rowptr, A->diag.colidx, A->diag.val, x, (double *)NULL, kr, ki, xi, c->d_partial,
+                           A->diag.rowoff, A->diag.colidx, A->diag.val, x, (double *)NULL, kr, ki, xi, c->d_partial,
                            (const double *)A->d_xhot, (int32_t)A->nc);
       } else
         hipLaunchKernelGGL((k_spmv_tiles<1, 0>), dim3((unsigned)nb), dim3(KSG_BLOCK), 0, c->stream, A->diag.tiles, A->diag.tile_p,
-                           A->diag.rowptr, A->diag.colidx, A->diag.val, x, (double *)NULL, kr, ki, xi, c->d_partial,
+                           A->diag.rowoff, A->diag.colidx, A->diag.val, x, (double *)NULL, kr, ki, xi, c->d_partial,
                            (const double *)NULL, (int32_t)0);
     }
   } else {

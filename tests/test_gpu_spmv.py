@@ -189,13 +189,13 @@ def test_packed_hot_columns_bit_exact(gpu_ctx):
     assert A0.hot_columns() == 0
     ctx.set_option(ksgpu.OPT_HOT_COLS, 1024)
     A1 = ksgpu.DeviceCSR(ctx, rp, ci, va)
-    ctx.set_option(ksgpu.OPT_HOT_COLS, 262144)
+    ctx.set_option(ksgpu.OPT_HOT_COLS, 1048576)
     nhot = A1.hot_columns()
     assert 0 < nhot <= 1024
     # a stencil has no hot columns whatever the limit
     ctx.set_option(ksgpu.OPT_HOT_COLS, 64)
     L = ksgpu.DeviceCSR(ctx, *mg.laplacian2d(60, 60))
-    ctx.set_option(ksgpu.OPT_HOT_COLS, 262144)
+    ctx.set_option(ksgpu.OPT_HOT_COLS, 1048576)
     assert L.hot_columns() == 0
     L.destroy()
     A0.mult(xd, yd)
