@@ -415,6 +415,17 @@ static int launch_multvec(ksg_ctx c, const double *X, int64_t ld, int k, const d
  * wave-uniform broadcasts) and only then stores, so the update is in place with
  * no scratch copy of the basis.  Bq is the K x E panel, row-major, zero padded. */
 #define KSG_MIP_LDS 4096   /* doubles of the panel resident in LDS at a time */
+/* 1: in the two-rows-per-thread body the coefficients come straight from the device copy of the
+ * panel with wave-uniform (scalar) loads and enter the multiply-adds as scalar operands; the
+ * LDS copy serves the remainder loops.  With LDS broadcasts every pair of multiply-adds waits
+ * for a read of the shared LDS pipe (64x32: 2.75 ms against 2.56 ms). */
+#ifndef KSG_MIP_SCALAR
+#define KSG_MIP_SCALAR 1
+#endif
+/* columns of the input requested together by a thread (64x32: 3.12 ms with 4, 2.72 ms with 8 or 16) */
+#ifndef KSG_MIP_BATCH
+#define KSG_MIP_BATCH 16
+#endif
 
 template <int E, int R>
 __global__ __launch_bounds__(KSG_BLOCK) void k_multinplace(const double *__restrict__ Vin, int64_t ld, int K,
@@ -445,18 +456,24 @@ __global__ __launch_bounds__(KSG_BLOCK) void k_multinplace(const double *__restr
           const double2 *xp = reinterpret_cast<const double2 *>(Vin + (int64_t)kt * ld + r0);
           const int64_t ld2 = ld >> 1;
           int i = 0;
-          for (; i + 4 <= kn; i += 4) {
-            double2 xv[4];
+          /* U columns requested together: with 2 waves per SIMD (the accumulators take the
+           * registers) the bytes in flight per wave decide the rate */
+          constexpr int U = KSG_MIP_BATCH;
+          for (; i + U <= kn; i += U) {
+            double2 xv[U];
 #pragma unroll
-            for (int u = 0; u < 4; u++) xv[u] = xp[(int64_t)(i + u) * ld2];
+            for (int u = 0; u < U; u++) xv[u] = xp[(int64_t)(i + u) * ld2];
 #pragma unroll
-            for (int u = 0; u < 4; u++)
+            for (int u = 0; u < U; u++) ld_fence(xv[u]);
+#pragma unroll
+            for (int u = 0; u < U; u++) {
 #pragma unroll
               for (int e = 0; e < E; e++) {
-                const double b = Bs[(i + u) * E + e];
+                const double b = KSG_MIP_SCALAR ? Bq[(int64_t)(kt + i + u) * E + e] : Bs[(i + u) * E + e];
                 acc[0][e] = fma(xv[u].x, b, acc[0][e]);
                 acc[R - 1][e] = fma(xv[u].y, b, acc[R - 1][e]);
               }
+            }
           }
           for (; i < kn; i++) {
             const double2 xv = xp[(int64_t)i * ld2];
@@ -468,8 +485,22 @@ __global__ __launch_bounds__(KSG_BLOCK) void k_multinplace(const double *__restr
             }
           }
         } else {
-          for (int i = 0; i < kn; i++) {
-            const double xv = Vin[(int64_t)(kt + i) * ld + r0];
+          const double *xp = Vin + (int64_t)kt * ld + r0;
+          constexpr int U = KSG_MIP_BATCH;
+          int i = 0;
+          for (; i + U <= kn; i += U) {
+            double xv[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) xv[u] = xp[(int64_t)(i + u) * ld];
+#pragma unroll
+            for (int u = 0; u < U; u++) ld_fence(xv[u]);
+#pragma unroll
+            for (int u = 0; u < U; u++)
+#pragma unroll
+              for (int e = 0; e < E; e++) acc[0][e] = fma(xv[u], Bs[(i + u) * E + e], acc[0][e]);
+          }
+          for (; i < kn; i++) {
+            const double xv = xp[(int64_t)i * ld];
 #pragma unroll
             for (int e = 0; e < E; e++) acc[0][e] = fma(xv, Bs[i * E + e], acc[0][e]);
           }
