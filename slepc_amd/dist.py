@@ -87,6 +87,10 @@ def init_comm(ctx, transport="rccl", fallback=True):
     dist = init_process_group()
     if transport.startswith("rccl"):
         import torch
+        if os.environ.get("MASTER_ADDR", "127.0.0.1") in ("127.0.0.1", "localhost", "::1"):
+            # one node: RCCL's bootstrap sockets go over the loopback interface, which is there
+            # whatever the host name resolves to; the data path (xGMI peer-to-peer) is not affected
+            os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
         ok = 1
         try:
             uid = [ctx.unique_id() if rank == 0 else None]
