@@ -190,7 +190,7 @@ static int tsqr_triangle(ksg_bv V, int k, double *Rd) {
   const int grid = (int)(nblk < 768 ? (nblk > 0 ? nblk : 1) : 768);   /* three workgroups per CU */
   /* many workgroups: their triangles, stacked as a (grid k) x k matrix, go through the same
    * kernel once more and only a few triangles are folded on the host */
-  const int grid2 = grid > 16 ? 8 : 0;
+  const int grid2 = grid > 256 ? 64 : (grid > 16 ? 8 : 0);   /* at most 12 blocks per workgroup there */
   const int nt = grid2 ? grid2 : grid;
   std::vector<double> T((size_t)nt * tri, 0.0), R((size_t)tri, 0.0);
   if (V->n > 0) {
