@@ -529,3 +529,30 @@ def test_eps_target_changed_between_solves(be):
         assert abs(st.get_shift() - target) < 1e-15
     eps.destroy()
     A.destroy()
+
+
+def test_rmat_generator_structure_and_partition():
+    """The R-MAT graph Laplacian of the benchmark: symmetric, zero row sums, diagonal = degree,
+    columns ascending and unique in every row, no self loops left; a row block generated on its
+    own equals the same rows of the whole matrix (what lets every rank build only its share)."""
+    from scipy.sparse import csr_matrix
+    from slepc_amd import matgen as mg
+    scale = 12
+    N = 1 << scale
+    rp, ci, va = mg.rmat_laplacian(scale)
+    assert rp.dtype == np.int64 and ci.dtype == np.int32 and va.dtype == np.float64
+    A = csr_matrix((va, ci, rp), shape=(N, N))
+    assert abs(A - A.T).max() == 0.0
+    assert np.abs(A @ np.ones(N)).max() == 0.0
+    deg = np.diff(rp) - 1
+    assert np.array_equal(A.diagonal(), deg.astype(float))
+    for r in (0, 1, 17, N // 2, N - 1):
+        cols = ci[rp[r]:rp[r + 1]]
+        assert np.all(np.diff(cols) > 0) and r in cols
+    off = va[ci != np.repeat(np.arange(N), np.diff(rp))]
+    assert np.all(off == -1.0)
+    assert deg.max() > 20 * max(1.0, np.median(deg))            # power-law rows
+    for (a, b) in ((0, 1000), (1000, 3000), (3000, N)):
+        rq, cq, vq = mg.rmat_laplacian(scale, row0=a, row1=b)
+        assert np.array_equal(rq, rp[a:b + 1] - rp[a])
+        assert np.array_equal(cq, ci[rp[a]:rp[b]]) and np.array_equal(vq, va[rp[a]:rp[b]])
