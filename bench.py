@@ -68,6 +68,17 @@ def cpu_baseline(grid, nev, restarts, threads):
                       "scipy CSR) on a %dx%d 2-D Laplacian (%d rows)" % (restarts, nev, e.ncv, grid, grid, n)}
 
 
+def analytic_laplacian_top(dims, count):
+    """The `count` largest eigenvalues (with multiplicity) of the 5/7-point Laplacian on a grid
+    with `dims` points per direction: sums of 2 - 2 cos(k pi / (n + 1)), one term per direction
+    (src/eps/examples/tutorials/ex19.c:30-57 gives the 3-D formula)."""
+    tops = [2.0 - 2.0 * np.cos(np.arange(n, max(0, n - count), -1) * np.pi / (n + 1)) for n in dims]
+    acc = tops[0]
+    for t in tops[1:]:
+        acc = np.sort((acc[:, None] + t[None, :]).ravel())[::-1][:count]
+    return np.sort(acc)[::-1][:count]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -235,10 +246,17 @@ def main():
         nbytes, unfused = float(b[0]), float(b[1])
     value = nbytes / dt / 1e9
 
-    max_res = None
+    max_res = eig_err = None
     if args.to_convergence and eps.nconv > 0:
         # ||A x - lambda x|| / |lambda| of every converged pair (collective: all ranks take part)
         max_res = max(eps.compute_error(i) for i in range(min(eps.nconv, args.nev)))
+        if args.workload in ("ex2", "lap3d"):
+            # every computed eigenvalue against the nearest one of the analytic spectrum (multiple
+            # eigenvalues are found with a multiplicity that depends on the start vector)
+            dims = (gx, gy) if args.workload == "ex2" else (g, g, gz)
+            ana = analytic_laplacian_top(dims, 8 * args.nev)
+            got = np.array([eps.get_eigenvalue(i)[0] for i in range(min(eps.nconv, args.nev))])
+            eig_err = float(np.max(np.min(np.abs(got[:, None] - ana[None, :]), axis=1) / np.abs(got)))
     if rank == 0:
         kernels = {}
         for ev, v in st.items():
@@ -291,6 +309,7 @@ def main():
         if args.to_convergence:
             out["time_to_convergence_s"] = round(dt, 3)
             out["max_relative_residual"] = max_res
+            out["max_eigenvalue_error_vs_analytic"] = eig_err
         if not args.no_cpu_baseline and size == 1:
             threads = min(16, os.cpu_count() or 1)
             out["cpu_baseline"] = cpu_baseline(args.cpu_grid, args.nev, args.cpu_restarts, threads)

@@ -60,3 +60,18 @@ def test_bench_two_ranks_rehearsal():
     assert d["config"]["transport"] == "gloo"
     assert "cpu_baseline" not in d            # rank 0 at N = 1 only
     assert d["value"] > 0
+
+
+def test_bench_to_convergence_checks_eigenvalues():
+    """--to-convergence times the whole EPSSolve and reports the residuals of the converged pairs
+    and the distance of every eigenvalue to the analytic spectrum of the Laplacian (1e-10
+    relative is the bar for eigenvalues)."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "lap3d", "--grid", "48",
+                        "--to-convergence", "--no-cpu-baseline"],
+                       cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=240)
+    assert r.returncode == 0, r.stderr.decode(errors="replace")[-3000:]
+    d = json.loads([l for l in r.stdout.decode().splitlines() if l.strip().startswith("{")][0])
+    assert d["solver_state"]["nconv"] >= 32 and d["solver_state"]["reason"] > 0
+    assert d["steps"] == d["solver_state"]["restarts"] and d["time_to_convergence_s"] > 0
+    assert d["max_relative_residual"] < 1e-7
+    assert d["max_eigenvalue_error_vs_analytic"] < 1e-10
