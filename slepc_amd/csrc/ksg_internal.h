@@ -108,6 +108,9 @@ struct ksg_csr_dev {
   uint16_t *rowoff;  /* nrows + ntiles entries: tile i holds, from index tiles[i] + i on, the
                       * entry offsets of its rows relative to the tile's first entry (one more
                       * than it has rows); 2 bytes per row instead of the 8 of rowptr */
+  uint8_t *vidx;     /* nnz one-byte indices into vtab, when the matrix has at most 256 distinct values */
+  double *vtab;      /* 256 doubles */
+  int nvt;           /* 1 when vidx/vtab are there */
   int64_t ntiles;
   int64_t n_stream, n_group, n_long;
 };

@@ -229,3 +229,42 @@ def test_packed_hot_columns_bit_exact(gpu_ctx):
         o.destroy()
     for p in (xd, yd, zd):
         ctx.vec_free(p)
+
+
+@pytest.mark.parametrize("ndistinct", [1, 3, 256, 257])
+def test_value_table_spmv(gpu_ctx, ndistinct):
+    """An operator with at most 256 distinct values is multiplied through one-byte indices into a
+    value table, one with more through the values themselves: both give the bits of a sequential
+    CSR loop (rows short enough for the one-lane-per-row path), the residual variant and the
+    round trip through ksg_mat_get_csr included."""
+    from slepc_amd import ksgpu
+    rng = np.random.default_rng(ndistinct)
+    n, per = 3000, 5
+    rp = np.arange(0, (n + 1) * per, per, dtype=np.int64)
+    ci = np.sort(rng.integers(0, n, (n, per)), axis=1).astype(np.int32).ravel()
+    pool = rng.standard_normal(ndistinct)
+    pool[0] = -0.0 if ndistinct > 1 else 1.5                 # told apart by bits: -0.0 and 0.0 differ
+    if ndistinct > 2:
+        pool[1] = 0.0
+    va = pool[rng.integers(0, ndistinct, n * per)]
+    va[:ndistinct] = pool                                     # every value occurs
+    x = rng.standard_normal(n)
+    A = ksgpu.DeviceCSR(gpu_ctx, rp, ci, va)
+    xd, yd = gpu_ctx.vec_alloc(n), gpu_ctx.vec_alloc(n)
+    gpu_ctx.upload(xd, x)
+    A.mult(xd, yd)
+    y = gpu_ctx.download(yd, n)
+    ref = np.zeros(n)
+    for r in range(n):
+        s = 0.0
+        for p in range(rp[r], rp[r + 1]):
+            s += va[p] * x[ci[p]]
+        ref[r] = s
+    assert np.array_equal(y, ref)
+    rp2, ci2, va2 = A.get_csr()
+    assert np.array_equal(va2.view(np.uint64), va.view(np.uint64)) and np.array_equal(ci2, ci)
+    nrm = A.residual_norm(0.75, 0.0, xd)
+    assert abs(nrm - np.linalg.norm(ref - 0.75 * x)) < 1e-12 * np.linalg.norm(ref)
+    A.destroy()
+    gpu_ctx.vec_free(xd)
+    gpu_ctx.vec_free(yd)
