@@ -23,7 +23,7 @@
 #include "ksg_internal.h"
 
 #ifndef KSG_TILE_NNZ
-#define KSG_TILE_NNZ  4096     /* products held in LDS per workgroup (32 KiB)   */
+#define KSG_TILE_NNZ  2048     /* products held in LDS per workgroup (16 KiB: 8 workgroups per CU) */
 #endif
 #ifndef KSG_TILE_ROWS
 #define KSG_TILE_ROWS 512      /* rows per stream tile: a multiple of the workgroup size */
@@ -190,7 +190,7 @@ __global__ __launch_bounds__(KSG_BLOCK) void k_spmv_tiles(const int32_t *__restr
   }
   __syncthreads();
 
-  if (nrows > KSG_BLOCK / 2) {
+  if (nrows > KSG_BLOCK / 2 || nnz <= 8 * (int64_t)nrows) {   /* many rows, or few but short ones */
     /* one lane per row, products added in storage order */
 #pragma unroll
     for (int j = 0; j < RPT; j++) {
@@ -305,7 +305,7 @@ __global__ __launch_bounds__(KSG_BLOCK) void k_spmm_tiles(const int32_t *__restr
   }
   __syncthreads();
 
-  if (nrows > KSG_BLOCK / 2) {
+  if (nrows > KSG_BLOCK / 2 || nnz <= 8 * (int64_t)nrows) {   /* many rows, or few but short ones */
     /* one lane per row, KC columns at a time */
     constexpr int RPT = KSG_TILE_ROWS / KSG_BLOCK;
     int b[RPT], e[RPT];

@@ -200,10 +200,14 @@ def test_eps_parity_with_oracle(be, name):
         assert r["reason"] == K.EPS_DIVERGED_ITS
         return
     assert r["reason"] == K.EPS_CONVERGED_TOL and r["nconv"] >= kw["nev"] and e.nconv >= kw["nev"]
+    # 1e-10 relative is the bar for solves converged to 1e-10 or tighter; a solve stopped at a
+    # looser tolerance pins its eigenvalues only to about that tolerance, and two correct runs whose
+    # products round differently (the unrefined, delayed Arnoldi most of all) agree to a fraction of it
+    bar = max(1e-10, 1e-2 * kw.get("tol", 1e-8))
     for i in range(kw["nev"]):
         lam = e.get_eigenvalue(i)
-        assert abs(r["values"][i][0] - lam[0]) <= 1e-10 * abs(lam[0])
-        assert abs(r["values"][i][1] - lam[1]) <= 1e-10
+        assert abs(r["values"][i][0] - lam[0]) <= bar * abs(lam[0])
+        assert abs(r["values"][i][1] - lam[1]) <= bar
         assert r["errors"][i] < 10 * kw["tol"]
         xr, _ = e.get_eigenvector(i)
         gr = r["vectors"][i][0]

@@ -502,7 +502,10 @@ def test_pmc_traffic_file_layout():
         pmc = json.load(f)
     assert pmc["workload"].startswith("ex2 2-D 5-point Laplacian 4096x4096")
     for k in ("k_multvec_dot", "k_dotw", "k_spmv_tiles"):
-        assert 0.9 < pmc["kernels"][k]["traffic_over_algorithmic"] < 1.2 and pmc["kernels"][k]["launches"] > 0
+        # the SpMV moves less than the CSR model it is charged with (one-byte value indices and
+        # two-byte row offsets on this operator); the BV kernels move what the model says
+        lo = 0.4 if k == "k_spmv_tiles" else 0.9
+        assert lo < pmc["kernels"][k]["traffic_over_algorithmic"] < 1.2 and pmc["kernels"][k]["launches"] > 0
 
 
 def test_eps_target_changed_between_solves(be):
