@@ -143,6 +143,18 @@ int ksg_bv_touch(ksg_bv bv);
  * (BVDotVec_Svec svec.c:122 -> BVDotVec_BLAS_Private bvblas.c:242). */
 int ksg_bv_dotvec(ksg_bv X, const double *y_dev, double *q_host);
 int ksg_bv_dotvec_local(ksg_bv X, const double *y_dev, double *q_host);          /* svec.c:145 */
+/* No counterpart in the reference.  For callers that cannot allocate device memory (code
+ * under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc): the products
+ * of ksg_bv_dotvec_local, q[i] = sum over the LOCAL rows of X[r,l+i]*y[r], written to the
+ * DEVICE array q_dev (k-l doubles) by work enqueued on ksg_ctx_stream(); the call returns
+ * without synchronising and calls no hipMalloc/hipFree.  The per-workgroup partial sums go to a
+ * fixed 1 MiB device array (131072 doubles per GPU, held until the process ends) instead of the
+ * context's growable workspace: (k-l) x partial sums per column must fit, i.e. up to 128 active
+ * columns at the default KSG_OPT_DOT_GRID; more is refused with KSG_ERR_UNSUPPORTED.  The
+ * kernels and the order of sums are those of ksg_bv_dotvec_local: the values are bit for bit
+ * the same.  All calls on one GPU share that array: calls that overlap on one GPU (two
+ * contexts, two streams) race; calls on one context are ordered by its stream. */
+int ksg_bv_dotvec_noalloc(ksg_bv X, const double *y_dev, double *q_dev);
 /* Split-phase reductions (the role of BVDotVecBegin/End, BVNormVecBegin/End, VecDotBegin/End,
  * bvglobal.c:190-310, 732-830, which the delayed Arnoldi and the one-sided bidiagonalisations
  * use to pay one reduction round per step, epskrylov.c:107-129, trlanczos.c:201-217).

@@ -6,6 +6,8 @@
  * leading dimension, so a wave reads 64 consecutive row pairs of one column as
  * one 1 KiB coalesced request (16 B per lane); tall-skinny products keep the
  * per-column accumulators in registers and stream every column exactly once. */
+#include <mutex>
+
 #include "ksg_internal.h"
 
 /* ------------------------------------------------------------------------ */
@@ -167,28 +169,44 @@ static void launch_dotw(int CW, dim3 grid, dim3 block, hipStream_t st, const dou
 #undef KSG_DOTW_CASE
 }
 
-/* d_out[i] = sum_r X[r + i*ld] * y[r], i < k (local rows only). */
+/* Launch geometry of the reduction: column groups of at most 16 columns, evenly filled, at
+ * most 16 groups per workgroup; nb partial sums per column. */
+struct ksg_dot_geom { bool vec2; int CW, G, R, ny, ngroups, nb; unsigned gx; };
+
+static ksg_dot_geom dot_geometry(ksg_ctx c, const double *X, int64_t ld, int k, const double *y, int64_t n) {
+  ksg_dot_geom g;
+  g.vec2 = aligned16(X) && aligned16(y) && (ld % 2 == 0);
+  g.ngroups = (k + 15) / 16;
+  g.CW = (k + g.ngroups - 1) / g.ngroups;
+  g.G = g.ngroups < 16 ? g.ngroups : 16;
+  g.R = g.G == 1 ? 4 : (g.G == 2 ? 2 : 1);
+  g.ny = (g.ngroups + g.G - 1) / g.G;
+  const int64_t nwork = ((g.vec2 ? (n + 1) / 2 : n) + 63) / 64;          /* blocks of 64 lanes */
+  int64_t gx = (nwork + g.R - 1) / g.R;
+  if (gx > c->dot_grid) gx = c->dot_grid;
+  g.gx = (unsigned)gx;
+  g.nb = (int)gx * g.R;
+  return g;
+}
+
+/* d_out[i] = sum_r X[r + i*ld] * y[r], i < k (local rows only); `partial` holds k*g.nb doubles,
+ * every one of which the first kernel writes (nothing has to be cleared beforehand). */
+static int launch_dotvec_geom(ksg_ctx c, const ksg_dot_geom &g, const double *X, int64_t ld, int k, const double *y,
+                              int64_t n, double *partial, double *d_out) {
+  if (g.vec2) launch_dotw<2>(g.CW, dim3(g.gx, g.ny), dim3(64 * g.G * g.R), c->stream, X, ld, k, y, n, partial, g.nb, g.G, g.ngroups);
+  else        launch_dotw<1>(g.CW, dim3(g.gx, g.ny), dim3(64 * g.G * g.R), c->stream, X, ld, k, y, n, partial, g.nb, g.G, g.ngroups);
+  hipLaunchKernelGGL((k_reduce_partials<0>), dim3(k), dim3(KSG_BLOCK), 0, c->stream, partial, g.nb, d_out);
+  KSG_HIP(hipGetLastError());
+  return KSG_OK;
+}
+
 int ksg_launch_dotvec(ksg_ctx c, const double *X, int64_t ld, int k, const double *y, int64_t n,
                       double *d_out) {
   if (k <= 0) return KSG_OK;
   if (n <= 0) { KSG_HIP(hipMemsetAsync(d_out, 0, (size_t)k * sizeof(double), c->stream)); return KSG_OK; }
-  const bool vec2 = aligned16(X) && aligned16(y) && (ld % 2 == 0);
-  /* column groups of at most 16 columns, evenly filled; at most 16 groups per workgroup */
-  const int ngroups = (k + 15) / 16;
-  const int CW = (k + ngroups - 1) / ngroups;
-  const int G = ngroups < 16 ? ngroups : 16;
-  const int R = G == 1 ? 4 : (G == 2 ? 2 : 1);
-  const int ny = (ngroups + G - 1) / G;
-  const int64_t nwork = ((vec2 ? (n + 1) / 2 : n) + 63) / 64;          /* blocks of 64 lanes */
-  int64_t gx = (nwork + R - 1) / R;
-  if (gx > c->dot_grid) gx = c->dot_grid;
-  const int nb = (int)gx * R;
-  KSG_CHK(ksg_ensure_partial(c, (size_t)k * nb));
-  if (vec2) launch_dotw<2>(CW, dim3((unsigned)gx, ny), dim3(64 * G * R), c->stream, X, ld, k, y, n, c->d_partial, nb, G, ngroups);
-  else      launch_dotw<1>(CW, dim3((unsigned)gx, ny), dim3(64 * G * R), c->stream, X, ld, k, y, n, c->d_partial, nb, G, ngroups);
-  hipLaunchKernelGGL((k_reduce_partials<0>), dim3(k), dim3(KSG_BLOCK), 0, c->stream, c->d_partial, nb, d_out);
-  KSG_HIP(hipGetLastError());
-  return KSG_OK;
+  const ksg_dot_geom g = dot_geometry(c, X, ld, k, y, n);
+  KSG_CHK(ksg_ensure_partial(c, (size_t)k * g.nb));
+  return launch_dotvec_geom(c, g, X, ld, k, y, n, c->d_partial, d_out);
 }
 
 /* ------------------------------------------------------------------------ */
@@ -1039,6 +1057,64 @@ static int dotvec_impl(ksg_bv X, const double *y, double *q_host, int global) {
 
 extern "C" int ksg_bv_dotvec(ksg_bv X, const double *y, double *q) { return dotvec_impl(X, y, q, 1); }
 extern "C" int ksg_bv_dotvec_local(ksg_bv X, const double *y, double *q) { return dotvec_impl(X, y, q, 0); }
+
+/* ---- the reduction for callers that cannot allocate ----------------------------------------
+ * The per-workgroup partial sums live in a fixed device array instead of the context's
+ * workspace (which ksg_ensure_partial grows with hipMalloc).  The array's name is only a
+ * host-side handle: its device address is looked up once per device (ksg_scratch_bind, from
+ * ksg_ctx_create with that device current) and kept; kernels and copies get that address. */
+#define KSG_SCRATCH_DOUBLES 131072            /* 1 MiB per device, held until the process ends */
+#define KSG_SCRATCH_MAXDEV  64
+static __device__ __align__(256) double ksg_scratch[KSG_SCRATCH_DOUBLES];
+static double *g_scratch_ptr[KSG_SCRATCH_MAXDEV];
+static std::mutex g_scratch_mutex;
+
+int ksg_scratch_bind(ksg_ctx c) {
+  c->d_scratch = NULL;
+  if (c->device < 0 || c->device >= KSG_SCRATCH_MAXDEV) return KSG_OK;      /* the entry point reports it */
+  std::lock_guard<std::mutex> lock(g_scratch_mutex);
+  if (!g_scratch_ptr[c->device]) {
+    double *p = NULL;
+    KSG_HIP(hipGetSymbolAddress((void **)&p, HIP_SYMBOL(ksg_scratch)));
+    g_scratch_ptr[c->device] = p;
+  }
+  c->d_scratch = g_scratch_ptr[c->device];
+  return KSG_OK;
+}
+
+extern "C" int ksg_bv_dotvec_noalloc(ksg_bv X, const double *y, double *q_dev) {
+  BV_CHECK(X, "ksg_bv_dotvec_noalloc");
+  if (!y || !q_dev) KSG_FAIL(KSG_ERR_ARG, "ksg_bv_dotvec_noalloc: NULL vector");
+  KSG_CHK(check_active(X, "ksg_bv_dotvec_noalloc"));
+  ksg_ctx c = X->ctx;
+  const int k = X->k - X->l;
+  if (k == 0) return KSG_OK;
+  if (!c->d_scratch) KSG_FAIL(KSG_ERR_UNSUPPORTED, "ksg_bv_dotvec_noalloc: no scratch array bound on device %d", c->device);
+  KSG_HIP(hipSetDevice(c->device));
+  const double *Xb = bv_col(X, X->l);
+  ksg_dot_geom g;
+  if (X->n > 0) {
+    g = dot_geometry(c, Xb, X->ld, k, y, X->n);
+    if ((int64_t)k * g.nb > KSG_SCRATCH_DOUBLES)
+      KSG_FAIL(KSG_ERR_UNSUPPORTED, "ksg_bv_dotvec_noalloc: %d columns x %d partial sums exceed the fixed scratch of %d doubles "
+               "(at most %d columns at the default KSG_OPT_DOT_GRID)", k, g.nb, KSG_SCRATCH_DOUBLES, KSG_SCRATCH_DOUBLES / 1024);
+  }
+  if (c->pend.active) {
+    /* a deferred Gram-Schmidt update is applied first, without the event pair that timing
+     * would create for it */
+    const int timing = c->timing;
+    c->timing = 0;
+    const int rc = ksg_flush_pending(c);
+    c->timing = timing;
+    if (rc) return rc;
+  }
+  if (X->n <= 0) { KSG_HIP(hipMemsetAsync(q_dev, 0, (size_t)k * sizeof(double), c->stream)); }
+  else KSG_CHK(launch_dotvec_geom(c, g, Xb, X->ld, k, y, X->n, c->d_scratch, q_dev));
+  c->stats.calls[KSG_EV_DOTVEC] += 1;
+  c->stats.bytes[KSG_EV_DOTVEC] += 8.0 * (double)X->n * (k + 1);
+  c->stats.flops[KSG_EV_DOTVEC] += 2.0 * (double)X->n * k;
+  return KSG_OK;
+}
 
 /* ---- posted reductions ------------------------------------------------------------------
  * Split-phase reductions (BVDotVecBegin/End, VecDotBegin/End, ... of the reference,

@@ -15,35 +15,11 @@ void ksg_set_error(const char *fmt, ...) {
 
 extern "C" const char *ksg_last_error(void) { return g_err; }
 
-extern "C" int ksg_ctx_create(int device, ksg_ctx *out) {
-  if (!out) KSG_FAIL(KSG_ERR_ARG, "ksg_ctx_create: NULL output");
-  int ndev = 0;
-  KSG_HIP(hipGetDeviceCount(&ndev));
-  if (device < 0 || device >= ndev)
-    KSG_FAIL(KSG_ERR_ARG, "ksg_ctx_create: device %d out of range (%d visible)", device, ndev);
-  KSG_HIP(hipSetDevice(device));
-  ksg_ctx c = new (std::nothrow) ksg_ctx_s();
-  if (!c) KSG_FAIL(KSG_ERR_MEM, "ksg_ctx_create: out of host memory");
-  c->device = device;
-  c->comm_kind = KSG_COMM_NONE;
-  c->rank = 0;
-  c->nranks = 1;
-  c->rccl_comm = NULL;
-  c->d_partial = NULL; c->partial_cap = 0;
-  c->d_q = NULL; c->q_cap = 0;
-  c->d_work = NULL; c->work_cap = 0;
-  c->h_q = NULL; c->hq_cap = 0;
-  c->timing = 0;
-  c->d_spec = NULL;
-  c->spec.valid = false;
-  c->gen = 0;
-  c->fuse_dots = 1;
-  c->lazy_update = 1;
-  c->hot_cols = 1048576;
-  c->pend.active = false;
-  c->dot_grid = KSG_DOT_GRID;
-  c->mv_grid = KSG_MV_GRID;
-  memset(&c->stats, 0, sizeof(c->stats));
+int ksg_comm_destroy(ksg_ctx c);
+extern "C" int ksg_ctx_destroy(ksg_ctx c);
+
+/* Streams, events and the small fixed buffers of a context whose plain fields are set. */
+static int ctx_init_device(ksg_ctx c) {
   KSG_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
   KSG_HIP(hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking));
   KSG_HIP(hipEventCreateWithFlags(&c->ev_x_ready, hipEventDisableTiming));
@@ -52,7 +28,33 @@ extern "C" int ksg_ctx_create(int device, ksg_ctx *out) {
   KSG_HIP(hipHostMalloc(&c->h_red, KSG_RED_MAX * sizeof(double), hipHostMallocDefault));
   KSG_HIP(hipMalloc(&c->d_spec, (KSG_QMAX + 1) * sizeof(double)));
   KSG_HIP(hipMalloc(&c->d_batch, KSG_RED_MAX * sizeof(double)));
-  c->batch_open = 0; c->batch_count = 0;
+  KSG_CHK(ksg_scratch_bind(c));
+  return KSG_OK;
+}
+
+extern "C" int ksg_ctx_create(int device, ksg_ctx *out) {
+  if (!out) KSG_FAIL(KSG_ERR_ARG, "ksg_ctx_create: NULL output");
+  int ndev = 0;
+  KSG_HIP(hipGetDeviceCount(&ndev));
+  if (device < 0 || device >= ndev)
+    KSG_FAIL(KSG_ERR_ARG, "ksg_ctx_create: device %d out of range (%d visible)", device, ndev);
+  KSG_HIP(hipSetDevice(device));
+  ksg_ctx c = new (std::nothrow) ksg_ctx_s();       /* value-initialised: every pointer NULL */
+  if (!c) KSG_FAIL(KSG_ERR_MEM, "ksg_ctx_create: out of host memory");
+  c->device = device;
+  c->comm_kind = KSG_COMM_NONE;
+  c->rank = 0;
+  c->nranks = 1;
+  c->spec.valid = false;
+  c->fuse_dots = 1;
+  c->lazy_update = 1;
+  c->hot_cols = 1048576;
+  c->pend.active = false;
+  c->dot_grid = KSG_DOT_GRID;
+  c->mv_grid = KSG_MV_GRID;
+  memset(&c->stats, 0, sizeof(c->stats));
+  const int rc = ctx_init_device(c);
+  if (rc) { ksg_ctx_destroy(c); return rc; }        /* frees whatever was created (the message is kept) */
   *out = c;
   return KSG_OK;
 }
@@ -92,13 +94,11 @@ extern "C" int ksg_ctx_set_option(ksg_ctx c, int option, int value) {
   }
 }
 
-int ksg_comm_destroy(ksg_ctx c);
-
 extern "C" int ksg_ctx_destroy(ksg_ctx c) {
   if (!c) return KSG_OK;
   hipSetDevice(c->device);
-  hipStreamSynchronize(c->comm_stream);
-  hipStreamSynchronize(c->stream);
+  if (c->comm_stream) hipStreamSynchronize(c->comm_stream);
+  if (c->stream) hipStreamSynchronize(c->stream);
   ksg_comm_destroy(c);
   for (auto &t : c->timers) { hipEventDestroy(t.e0); hipEventDestroy(t.e1); }
   for (auto &e : c->event_pool) hipEventDestroy(e);
@@ -106,14 +106,14 @@ extern "C" int ksg_ctx_destroy(ksg_ctx c) {
   if (c->d_q) hipFree(c->d_q);
   if (c->d_work) hipFree(c->d_work);
   if (c->h_q) hipHostFree(c->h_q);
-  hipFree(c->d_red);
-  hipFree(c->d_spec);
-  hipFree(c->d_batch);
-  hipHostFree(c->h_red);
-  hipEventDestroy(c->ev_x_ready);
-  hipEventDestroy(c->ev_halo_done);
-  hipStreamDestroy(c->comm_stream);
-  hipStreamDestroy(c->stream);
+  if (c->d_red) hipFree(c->d_red);
+  if (c->d_spec) hipFree(c->d_spec);
+  if (c->d_batch) hipFree(c->d_batch);
+  if (c->h_red) hipHostFree(c->h_red);
+  if (c->ev_x_ready) hipEventDestroy(c->ev_x_ready);
+  if (c->ev_halo_done) hipEventDestroy(c->ev_halo_done);
+  if (c->comm_stream) hipStreamDestroy(c->comm_stream);
+  if (c->stream) hipStreamDestroy(c->stream);
   delete c;
   return KSG_OK;
 }

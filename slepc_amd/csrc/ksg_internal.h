@@ -60,6 +60,7 @@ struct ksg_ctx_s {
   double *d_red;             /* device reduction buffer, KSG_RED_MAX doubles */
   double *h_red;             /* pinned host mirror */
   double *d_partial;         /* per-workgroup partial sums */
+  double *d_scratch;         /* this device's copy of the fixed scratch array (ksg_scratch_bind), not owned */
   size_t partial_cap;        /* doubles */
   double *d_q;               /* device copy of small host matrices (Q for multinplace) */
   size_t q_cap;
@@ -158,6 +159,7 @@ int ksg_comm_exchange_host(ksg_ctx ctx, const double *send, const int64_t *sendo
                            double *recv, const int64_t *recvoff);
 
 /* workspace helpers */
+int ksg_scratch_bind(ksg_ctx ctx);                /* ksg_bv.hip; the context's device must be current */
 int ksg_ensure_partial(ksg_ctx ctx, size_t doubles);
 int ksg_ensure_q(ksg_ctx ctx, size_t doubles);
 int ksg_ensure_work(ksg_ctx ctx, size_t doubles);

@@ -74,6 +74,7 @@ SIGNATURES = {
     "ksg_bv_touch": (C.c_int, [C.c_void_p]),
     "ksg_bv_dotvec": (C.c_int, [C.c_void_p, C.c_void_p, c_dp]),
     "ksg_bv_dotvec_local": (C.c_int, [C.c_void_p, C.c_void_p, c_dp]),
+    "ksg_bv_dotvec_noalloc": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "ksg_bv_multvec": (C.c_int, [C.c_void_p, C.c_double, C.c_double, C.c_void_p, c_dp]),
     "ksg_bv_multinplace": (C.c_int, [C.c_void_p, c_dp, C.c_int, C.c_int, C.c_int, C.c_int]),
     "ksg_bv_scale": (C.c_int, [C.c_void_p, C.c_int, C.c_double]),
@@ -312,6 +313,10 @@ class DeviceBV:
         fn = self.lib.ksg_bv_dotvec_local if local else self.lib.ksg_bv_dotvec
         check(fn(self.h, y_dev, _dptr(q)))
         return q[:self.k - self.l]
+
+    def dotvec_noalloc(self, y_dev, q_dev):
+        """Local products into the device array q_dev; no allocation, no synchronisation."""
+        check(self.lib.ksg_bv_dotvec_noalloc(self.h, y_dev, q_dev))
 
     def dotvec_cols(self, l, k, j):
         """Products of columns [l,k) with column j."""
