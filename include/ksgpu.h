@@ -53,6 +53,11 @@ int ksg_ctx_sync(ksg_ctx ctx);
  * waiting for it: afterwards work enqueued on ksg_ctx_stream() by the caller sees every
  * column up to date.  Every other entry point does this itself where it matters. */
 int ksg_ctx_flush(ksg_ctx ctx);
+/* Must be called after device vectors of this context were written by anything other than
+ * this library (a kernel or copy of the caller, e.g. the MatMult of a user-defined operator):
+ * applies a pending update and drops reductions formed ahead of their request
+ * (KSG_OPT_FUSE_DOTS).  ksg_bv_touch is the same for a caller that holds the BV. */
+int ksg_ctx_touch(ksg_ctx ctx);
 /* The HIP stream (hipStream_t) all kernels are launched on. */
 void *ksg_ctx_stream(ksg_ctx ctx);
 /* Tuning switches.  KSG_OPT_FUSE_DOTS (default 1): ksg_bv_multvec on the column that
@@ -243,6 +248,13 @@ int ksg_mat_sizes(ksg_mat A, int64_t *n_local, int64_t *N, int64_t *row0, int64_
  * stream path, the grouped (several lanes per row) path and the long-row path,
  * and the number of ghost entries received per multiply. */
 int ksg_mat_info(ksg_mat A, int64_t info[4]);
+/* Bytes one ksg_mat_mult moves on this rank: *executed by the model of the kernel variant that
+ * runs (value table, 2-byte row offsets, packed columns, ghost block, halo pack: what the
+ * statistics of KSG_EV_MATMULT are charged with), *csr_model by the plain CSR layout of PETSc's
+ * AIJ (12 bytes per entry, 8 per row pointer, x and y once).  Either pointer may be NULL. */
+int ksg_mat_traffic_model(ksg_mat A, double *executed, double *csr_model);
+/* One line of text naming the kernel variant and data layout the operator's products use. */
+int ksg_mat_describe(ksg_mat A, char *buf, size_t len);
 /* number of columns whose x entries the operator keeps packed (KSG_OPT_HOT_COLS), 0 if none */
 int ksg_mat_hot_columns(ksg_mat A, int64_t *nhot);
 

@@ -43,13 +43,14 @@ class EPS:
                  tol=1e-8, max_it=0, which=None, keep=0.5, lock=True, comm=None,
                  row0=0, v0=None, monitor=None, solver="krylovschur", delayed=False,
                  orthog_refine=REFINE_IFNEEDED, reorthog="local", Bmatvec=None, positive=True,
-                 st="shift", sigma=None, target=0.0, solve=None, purify=True, deflation=None):
+                 st="shift", sigma=None, target=0.0, solve=None, purify=True, deflation=None, bv_factory=None):
         """Generalized problem: ``Bmatvec(x, y)`` computes y = B x.  ``st`` is the spectral
         transformation ("shift", "sinvert"), ``sigma`` its shift (sinvert: the target when not
         given, sinvert.c:112) and ``solve(b, x)`` solves with the matrix the transformation needs
         -- B for shift, A - sigma B for sinvert -- the KSPSolve the reference delegates to PETSc
         (stsles.c).  ``deflation``: vectors of EPSSetDeflationSpace."""
         self.matvec = matvec
+        self.bv_factory = bv_factory or BV           # storage type of the basis (-bv_type)
         self.Bmatvec = Bmatvec
         self.generalized = Bmatvec is not None
         self.positive = self.generalized and positive and (hermitian or positive == "pgnhep")
@@ -115,7 +116,7 @@ class EPS:
         if not self.keep:
             self.keep = 0.5                                  # krylovschur.c:103
         ncv = self.ncv
-        self.V = BV(self.n, ncv + 1, N=self.N, comm=self.comm)   # EPSAllocateSolution(eps,1)
+        self.V = self.bv_factory(self.n, ncv + 1, N=self.N, comm=self.comm)   # EPSAllocateSolution(eps,1)
         self.V.orthog_ref = self.orthog_refine
         if self.solver == "lanczos" and self.reorthog != "full":
             self.V.orthog_type = bvmod.MGS            # EPSSetUp_Lanczos lanczos.c:77-81

@@ -24,6 +24,8 @@ PetscErrorCode KSRedBegin_Private(const void *owner, const struct _VecOps *ops, 
 void KSRedPosted_Private(PetscInt dev_off);
 PetscErrorCode KSRedEnd_Private(const void *owner, PetscInt count, PetscScalar *out);
 void KSRedAbandon_Private(void);
+PetscErrorCode VecForeignAccessBegin_Private(Vec x);
+PetscErrorCode VecForeignAccessEnd_Private(Vec y);
 
 #define PETSC_MACHINE_EPSILON 2.2204460492503131e-16
 #define PetscMax(a, b) ((a) < (b) ? (b) : (a))

@@ -107,7 +107,15 @@ PetscErrorCode MatMult(Mat A, Vec x, Vec y) {
   if (!A || !x || !y) SETERRQ(PETSC_ERR_ARG_NULL, "Null argument");
   if (x == y || x->array == y->array) SETERRQ(PETSC_ERR_ARG_WRONG, "x and y must be different vectors");
   if (x->n != A->cn || y->n != A->n) SETERRQ(PETSC_ERR_ARG_SIZ, "Mat local size %lld x %lld, vectors %lld and %lld", (long long)A->n, (long long)A->cn, (long long)x->n, (long long)y->n);
-  ierr = A->ops.mult(A, x, y);CHKERRQ(ierr);
+  if (A->ops.mult == MatMult_AIJHIP) { ierr = A->ops.mult(A, x, y);CHKERRQ(ierr); }
+  else {
+    /* user code: it may read x->array and write y->array with kernels or copies of its own,
+     * so x must hold every update the device library defers, and the library must learn that
+     * y changed (it keeps reductions it formed ahead of their request) */
+    ierr = VecForeignAccessBegin_Private(x);CHKERRQ(ierr);
+    ierr = A->ops.mult(A, x, y);CHKERRQ(ierr);
+    ierr = VecForeignAccessEnd_Private(y);CHKERRQ(ierr);
+  }
   y->state++;
   return 0;
 }

@@ -31,6 +31,19 @@ PetscErrorCode VecCreateHIP(ksg_ctx ctx, PetscInt64 n, PetscInt64 N, PetscInt64 
   return VecCreateWithOps(&VecOps_HIP, ctx, n, N, row0, PETSC_TRUE, v);
 }
 
+/* Brackets for code outside the library that reads or writes the device arrays of "hip"
+ * vectors on its own (the MatMult of a shell operator): before it, updates the library still
+ * holds back are applied (the arrays are then current for work on the context's stream); after
+ * it, the library is told that device data changed behind its back.  Other vector types: no-ops. */
+PetscErrorCode VecForeignAccessBegin_Private(Vec x) {
+  if (x && x->ops == &VecOps_HIP && x->ctx) CHKKSG(ksg_ctx_flush((ksg_ctx)x->ctx));
+  return 0;
+}
+PetscErrorCode VecForeignAccessEnd_Private(Vec y) {
+  if (y && y->ops == &VecOps_HIP && y->ctx) CHKKSG(ksg_ctx_touch((ksg_ctx)y->ctx));
+  return 0;
+}
+
 /* ---- generic ---------------------------------------------------------------------- */
 PetscErrorCode VecCreateWithOps(const struct _VecOps *ops, void *ctx, PetscInt64 n, PetscInt64 N, PetscInt64 row0,
                                 PetscBool allocate, Vec *v) {

@@ -210,16 +210,20 @@ int ksg_comm_exchange_host(ksg_ctx c, const double *send, const int64_t *sendoff
   }
   int64_t ns = sendoff[P], nr = recvoff[P];
   double *ds = NULL, *dr = NULL;
-  KSG_HIP(hipMalloc(&ds, (size_t)(ns > 0 ? ns : 1) * sizeof(double)));
-  KSG_HIP(hipMalloc(&dr, (size_t)(nr > 0 ? nr : 1) * sizeof(double)));
-  if (ns) KSG_HIP(hipMemcpyAsync(ds, send, (size_t)ns * sizeof(double), hipMemcpyHostToDevice, c->stream));
-  int rc = exchange_device(c, ds, sendoff, dr, recvoff, c->stream);
+  int rc = KSG_OK;
+  hipError_t e = hipMalloc(&ds, (size_t)(ns > 0 ? ns : 1) * sizeof(double));
+  if (e == hipSuccess) e = hipMalloc(&dr, (size_t)(nr > 0 ? nr : 1) * sizeof(double));
+  if (e == hipSuccess && ns) e = hipMemcpyAsync(ds, send, (size_t)ns * sizeof(double), hipMemcpyHostToDevice, c->stream);
+  if (e != hipSuccess) { ksg_set_error("halo set-up staging failed: %s", hipGetErrorString(e)); rc = KSG_ERR_HIP; }
+  /* a rank whose staging failed must not leave the others alone in the exchange: it is a
+   * collective, so this rank takes part with whatever it has and reports its error afterwards */
+  if (ds && dr) { const int rc2 = exchange_device(c, ds, sendoff, dr, recvoff, c->stream); if (!rc) rc = rc2; }
   if (!rc && nr) {
-    hipError_t e = hipMemcpyAsync(recv, dr, (size_t)nr * sizeof(double), hipMemcpyDeviceToHost, c->stream);
+    e = hipMemcpyAsync(recv, dr, (size_t)nr * sizeof(double), hipMemcpyDeviceToHost, c->stream);
     if (e != hipSuccess) { ksg_set_error("halo set-up copy failed: %s", hipGetErrorString(e)); rc = KSG_ERR_HIP; }
   }
   hipStreamSynchronize(c->stream);
-  hipFree(ds);
-  hipFree(dr);
+  if (ds) hipFree(ds);
+  if (dr) hipFree(dr);
   return rc;
 }

@@ -74,6 +74,14 @@ extern "C" int ksg_ctx_flush(ksg_ctx c) {
   return ksg_flush_pending(c);
 }
 
+extern "C" int ksg_ctx_touch(ksg_ctx c) {
+  if (!c) KSG_FAIL(KSG_ERR_ARG, "ksg_ctx_touch: NULL context");
+  KSG_HIP(hipSetDevice(c->device));
+  KSG_CHK(ksg_flush_pending(c));
+  c->gen++;                       /* reductions formed ahead of their request are stale now */
+  return KSG_OK;
+}
+
 extern "C" void *ksg_ctx_stream(ksg_ctx c) { return c ? (void *)c->stream : NULL; }
 
 extern "C" int ksg_ctx_set_option(ksg_ctx c, int option, int value) {

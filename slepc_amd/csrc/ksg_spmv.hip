@@ -577,6 +577,17 @@ static int gather_starts(ksg_ctx c, int64_t first, int64_t count, std::vector<in
   return KSG_OK;
 }
 
+/* Ranks agree on whether a set-up stage succeeded everywhere, so that a rank-local failure does
+ * not leave the others waiting in the next collective: every rank returns an error or none does. */
+static int agree(ksg_ctx c, int rc, const char *stage) {
+  double flag = rc ? 1.0 : 0.0;
+  const int rc2 = ksg_comm_allreduce_host(c, &flag, 1, 1);
+  if (rc) return rc;                                   /* the local failure and its message */
+  if (rc2) return rc2;
+  if (flag != 0.0) KSG_FAIL(KSG_ERR_COMM, "ksg_mat_create_csr: another rank failed while %s", stage);
+  return KSG_OK;
+}
+
 static int mat_create(ksg_ctx c, int64_t n, int64_t N, int64_t row0, int64_t nc, int64_t NC, int64_t col0,
                       const int64_t *rowptr, const int32_t *colidx, const double *val, ksg_mat *out) {
   if (!c || !out || !rowptr || n < 0 || N < n || row0 < 0 || row0 + n > N || nc < 0 || NC < nc || col0 < 0 || col0 + nc > NC)
@@ -607,15 +618,16 @@ static int mat_create(ksg_ctx c, int64_t n, int64_t N, int64_t row0, int64_t nc,
   }
 
   /* ---- several ranks: ownership ranges (allgather through a zero-padded sum) ---- */
+  if ((size_t)P * P > KSG_RED_MAX) { delete A; KSG_FAIL(KSG_ERR_UNSUPPORTED, "ksg_mat_create_csr: too many ranks"); }   /* the same on every rank */
   std::vector<int64_t> rs;
   rc = gather_starts(c, row0, n, rs);
-  if (rc) { delete A; return rc; }
+  /* the vector x is distributed by column blocks (the same as the rows for a square operator) */
+  if (!rc) rc = gather_starts(c, col0, nc, A->cstarts);
+  if (rc) { delete A; return rc; }                     /* a failed collective: nothing to agree on */
+  const std::vector<int64_t> &cs = A->cstarts;
+  /* every rank holds the same two tables, so these checks fail on all ranks or on none */
   if (rs[0] != 0 || rs[P] != N) { delete A; KSG_FAIL(KSG_ERR_ARG, "ksg_mat_create_csr: row blocks do not tile [0,N)"); }
   for (int p = 0; p < P; p++) if (rs[p + 1] < rs[p]) { delete A; KSG_FAIL(KSG_ERR_ARG, "ksg_mat_create_csr: row blocks are not ordered by rank"); }
-  /* the vector x is distributed by column blocks (the same as the rows for a square operator) */
-  rc = gather_starts(c, col0, nc, A->cstarts);
-  if (rc) { delete A; return rc; }
-  const std::vector<int64_t> &cs = A->cstarts;
   if (cs[0] != 0 || cs[P] != NC) { delete A; KSG_FAIL(KSG_ERR_ARG, "ksg_mat_create_csr: column blocks do not tile [0,NC)"); }
   for (int p = 0; p < P; p++) if (cs[p + 1] < cs[p]) { delete A; KSG_FAIL(KSG_ERR_ARG, "ksg_mat_create_csr: column blocks are not ordered by rank"); }
 
@@ -656,7 +668,6 @@ static int mat_create(ksg_ctx c, int64_t n, int64_t N, int64_t row0, int64_t nc,
     A->recvoff[P] = (int64_t)ghosts.size();
   }
   /* ---- counts matrix (all-to-all of counts through a sum) ---- */
-  if ((size_t)P * P > KSG_RED_MAX) { delete A; KSG_FAIL(KSG_ERR_UNSUPPORTED, "ksg_mat_create_csr: too many ranks"); }
   std::vector<double> counts((size_t)P * P, 0.0);
   for (int p = 0; p < P; p++) counts[(size_t)c->rank * P + p] = (double)(A->recvoff[p + 1] - A->recvoff[p]);
   rc = ksg_comm_allreduce_host(c, counts.data(), P * P, 0);
@@ -671,11 +682,13 @@ static int mat_create(ksg_ctx c, int64_t n, int64_t N, int64_t row0, int64_t nc,
   rc = ksg_comm_exchange_host(c, want.data(), A->recvoff.data(), asked.data(), A->sendoff.data());
   if (rc) { delete A; return rc; }
   std::vector<int32_t> send_idx((size_t)std::max<int64_t>(A->nsend, 1));
-  for (int64_t i = 0; i < A->nsend; i++) {
+  for (int64_t i = 0; i < A->nsend && !rc; i++) {
     const int64_t gidx = (int64_t)asked[i];
-    if (gidx < lo || gidx >= hi) { delete A; KSG_FAIL(KSG_ERR_COMM, "halo plan: rank asked for entry %lld that is not mine", (long long)gidx); }
+    if (gidx < lo || gidx >= hi) { ksg_set_error("halo plan: rank asked for entry %lld that is not mine", (long long)gidx); rc = KSG_ERR_COMM; break; }
     send_idx[i] = (int32_t)(gidx - lo);
   }
+  rc = agree(c, rc, "building the halo plan");
+  if (rc) { delete A; return rc; }
 
   /* ---- upload ---- */
   rc = diag_to_device(A, n, d_rp.data(), d_ci.data(), d_v.data());
@@ -692,7 +705,9 @@ static int mat_create(ksg_ctx c, int64_t n, int64_t N, int64_t row0, int64_t nc,
     if (hipHostMalloc(&A->h_ghost, (size_t)std::max<int64_t>(A->nghost, 1) * sizeof(double), hipHostMallocDefault) != hipSuccess) rc = KSG_ERR_MEM;
     if (!rc && hipHostMalloc(&A->h_send, (size_t)std::max<int64_t>(A->nsend, 1) * sizeof(double), hipHostMallocDefault) != hipSuccess) rc = KSG_ERR_MEM;
   }
-  if (rc) { ksg_mat_destroy(A); if (rc == KSG_ERR_MEM) ksg_set_error("ksg_mat_create_csr: out of device memory"); return rc; }
+  if (rc == KSG_ERR_MEM) ksg_set_error("ksg_mat_create_csr: out of device memory");
+  rc = agree(c, rc, "uploading the matrix");
+  if (rc) { ksg_mat_destroy(A); return rc; }
   *out = A;
   return KSG_OK;
 }
@@ -926,8 +941,43 @@ static int mat_mult_raw(ksg_mat A, const double *x, double *y) {
   return KSG_OK;
 }
 
+/* Bytes one product moves, by the model of the kernel variant that runs (what the statistics are
+ * charged with): the entry stream is 12 bytes per entry, or 5 when the values travel as one-byte
+ * indices into the value table; the rows cost 2 bytes of tile-relative offset each instead of the
+ * 8 of a row pointer, plus 12 bytes of tile tables per tile; x is counted once, y is written once;
+ * packed hot columns add the gather that refreshes them (index, read, write); the ghost block adds
+ * its own entry stream, row tables and the read-modify-write of the rows it touches; the halo adds
+ * the pack kernel (index, read, write) and the received entries. */
+static double block_stream_bytes(const ksg_csr_dev &D) {
+  return (D.nvt ? 5.0 : 12.0) * (double)D.nnz + 2.0 * (double)(D.nrows + D.ntiles) + 12.0 * (double)(D.ntiles + 1);
+}
 static inline double spmv_bytes(ksg_mat A) {
+  double b = block_stream_bytes(A->diag) + 8.0 * (double)A->nc + 8.0 * (double)A->n + 20.0 * (double)A->nhot;
+  if (A->ctx->nranks > 1)
+    b += 12.0 * (double)A->o_nnz + 8.0 * (double)(A->no_rows + 1) + 20.0 * (double)A->no_rows +
+         8.0 * (double)A->nghost + 20.0 * (double)A->nsend;
+  return b;
+}
+/* The same product by the plain CSR model (12 bytes per entry, 8 per row pointer, x and y once):
+ * what a kernel reading rowptr/colidx/val as they stand would move. */
+static inline double spmv_bytes_csr_model(ksg_mat A) {
   return 12.0 * (double)A->nnz + 8.0 * (double)(A->n + 1) + 8.0 * (double)(A->nc + A->nghost) + 8.0 * (double)A->n;
+}
+
+extern "C" int ksg_mat_traffic_model(ksg_mat A, double *executed, double *csr_model) {
+  if (!A) KSG_FAIL(KSG_ERR_ARG, "ksg_mat_traffic_model: NULL matrix");
+  if (executed) *executed = spmv_bytes(A);
+  if (csr_model) *csr_model = spmv_bytes_csr_model(A);
+  return KSG_OK;
+}
+
+extern "C" int ksg_mat_describe(ksg_mat A, char *buf, size_t len) {
+  if (!A || !buf || !len) KSG_FAIL(KSG_ERR_ARG, "ksg_mat_describe: NULL argument");
+  snprintf(buf, len, "row tiles of <= %d entries / %d rows: %lld one lane per row, %lld several lanes per row, %lld single long rows; "
+           "2-byte row offsets; values: %s; packed hot columns: %lld; ghost entries received per product: %lld",
+           KSG_TILE_NNZ, KSG_TILE_ROWS, (long long)A->diag.n_stream, (long long)A->diag.n_group, (long long)A->diag.n_long,
+           A->diag.nvt ? "1-byte indices into a 256-entry table" : "8-byte stream", (long long)A->nhot, (long long)A->nghost);
+  return KSG_OK;
 }
 
 extern "C" int ksg_mat_mult(ksg_mat A, const double *x, double *y) {
@@ -984,8 +1034,8 @@ extern "C" int ksg_mat_residual_norm(ksg_mat A, double kr, double ki, const doub
   KSG_HIP(hipGetLastError());
   if (nb) { KSG_CHK(ksg_launch_reduce_sum(c, c->d_partial, nb, 1, c->d_red)); }
   else KSG_HIP(hipMemsetAsync(c->d_red, 0, sizeof(double), c->stream));
-  const double bytes = 12.0 * (double)A->nnz + 8.0 * (double)(A->n + 1) + 8.0 * (double)(A->n + A->nghost) +
-                       (xi ? 8.0 * (double)A->n : 0.0) + (halo ? 16.0 * (double)A->n : 0.0);
+  /* one rank: the product's bytes without the store of y; several: the product, then a pass over it */
+  const double bytes = spmv_bytes(A) + (xi ? 8.0 * (double)A->n : 0.0) + (halo ? 16.0 * (double)A->n : -8.0 * (double)A->n);
   KSG_CHK(ksg_op_end(c, KSG_EV_MATMULT, bytes, 2.0 * (double)A->nnz + 5.0 * (double)A->n));
   double s = 0.0;
   KSG_CHK(ksg_comm_allreduce(c, c->d_red, &s, 1, 0));
@@ -1008,7 +1058,8 @@ extern "C" int ksg_bv_matmult(ksg_bv V, ksg_mat A, ksg_bv W) {
     hipLaunchKernelGGL(k_spmm_tiles<8>, dim3((unsigned)A->diag.ntiles), dim3(KSG_BLOCK), 0, c->stream, A->diag.tiles,
                        A->diag.tile_p, A->diag.rowptr, A->diag.colidx, A->diag.val, X, V->ld, Y, W->ld, nc);
     KSG_HIP(hipGetLastError());
-    const double bytes = 12.0 * (double)A->nnz + 8.0 * (double)(A->n + 1) + 8.0 * nc * (double)(A->nc + A->n);
+    /* k_spmm_tiles reads the 8-byte values and the row pointers as they stand */
+    const double bytes = 12.0 * (double)A->nnz + 8.0 * (double)(A->n + 1) + 12.0 * (double)(A->diag.ntiles + 1) + 8.0 * nc * (double)(A->nc + A->n);
     return ksg_op_end(c, KSG_EV_MATMULT, bytes, 2.0 * nc * (double)A->nnz);
   }
   /* several ranks, or packed x entries: column by column, each product with its halo exchange */

@@ -44,6 +44,7 @@ SIGNATURES = {
     "ksg_ctx_destroy": (C.c_int, [C.c_void_p]),
     "ksg_ctx_sync": (C.c_int, [C.c_void_p]),
     "ksg_ctx_flush": (C.c_int, [C.c_void_p]),
+    "ksg_ctx_touch": (C.c_int, [C.c_void_p]),
     "ksg_ctx_stream": (C.c_void_p, [C.c_void_p]),
     "ksg_ctx_set_option": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "ksg_last_error": (C.c_char_p, []),
@@ -106,6 +107,8 @@ SIGNATURES = {
     "ksg_mat_sizes": (C.c_int, [C.c_void_p, C.POINTER(c_i64), C.POINTER(c_i64), C.POINTER(c_i64),
                                 C.POINTER(c_i64)]),
     "ksg_mat_info": (C.c_int, [C.c_void_p, C.POINTER(c_i64)]),
+    "ksg_mat_traffic_model": (C.c_int, [C.c_void_p, c_dp, c_dp]),
+    "ksg_mat_describe": (C.c_int, [C.c_void_p, C.c_char_p, C.c_size_t]),
     "ksg_stats_enable_timing": (C.c_int, [C.c_void_p, C.c_int]),
     "ksg_stats_get": (C.c_int, [C.c_void_p, C.POINTER(Stats)]),
     "ksg_stats_reset": (C.c_int, [C.c_void_p]),
@@ -437,6 +440,17 @@ class DeviceCSR:
         n = c_i64()
         check(self.lib.ksg_mat_hot_columns(self.h, C.byref(n)))
         return n.value
+
+    def traffic_model(self):
+        """(executed, csr_model) bytes of one product on this rank."""
+        a, b = C.c_double(), C.c_double()
+        check(self.lib.ksg_mat_traffic_model(self.h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def describe(self):
+        buf = C.create_string_buffer(512)
+        check(self.lib.ksg_mat_describe(self.h, buf, 512))
+        return buf.value.decode()
 
     def info(self):
         a = (c_i64 * 4)()

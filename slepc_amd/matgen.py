@@ -180,6 +180,49 @@ def rmat_laplacian(scale, edge_factor=8, a=0.57, b=0.19, c=0.19, seed=0x5EED, ro
     return rowptr, colidx, val
 
 
+def slab_rows(dims, nranks, rank):
+    """Row block of `rank` when a grid operator in natural ordering (fastest index first,
+    ex2.c:56-63, ex19.c:70-86) is split into slabs along its slowest dimension: whole grid
+    lines (2-D) or planes (3-D) per rank, as even as PetscSplitOwnership makes them.  Every
+    rank then needs exactly one line / plane of x from each neighbour."""
+    lead = int(np.prod(dims[:-1]))
+    k0, k1 = split_rows(dims[-1], nranks, rank)
+    return k0 * lead, k1 * lead
+
+
+def rmat_row_weights(scale, edge_factor=8, a=0.57, b=0.19, c=0.19):
+    """Expected number of entries of every row of `rmat_laplacian` (before duplicates are
+    removed): an edge has its source bit set with probability c+d and its destination bit with
+    b+d at every level, independently across levels, and every edge is stored in both
+    directions; plus the diagonal."""
+    N = 1 << scale
+    d = 1.0 - a - b - c
+    v = np.arange(N, dtype=np.uint32) if scale <= 32 else np.arange(N, dtype=np.uint64)
+    ones = np.zeros(N, dtype=np.int8)
+    for bit in range(scale):
+        ones += ((v >> bit) & 1).astype(np.int8)
+    ps, pd = c + d, b + d
+    k = np.arange(scale + 1, dtype=np.float64)
+    table = edge_factor * N * (ps ** k * (1 - ps) ** (scale - k) + pd ** k * (1 - pd) ** (scale - k)) + 1.0
+    return table[ones]
+
+
+def balanced_row_blocks(weights, nranks, row_weight=0.0):
+    """Contiguous row blocks of (nearly) equal total weight: starts[p] is the first row of rank p,
+    starts[nranks] = N.  weights[i] is the cost of row i in matrix entries (its number of entries,
+    exact or expected); `row_weight` adds a cost per row in the same unit, for the work that grows
+    with the rows whatever they hold (the basis-vector kernels: with it at 0 the split balances the
+    entries only, and a power-law operator leaves some ranks with several times the rows of others)."""
+    w = np.asarray(weights, dtype=np.float64) + float(row_weight)
+    cum = np.cumsum(w)
+    total = cum[-1]
+    starts = [0]
+    for p in range(1, nranks):
+        starts.append(max(starts[-1], int(np.searchsorted(cum, total * p / nranks, side="left")) + 1))
+    starts.append(len(w))
+    return [min(s, len(w)) for s in starts]
+
+
 def split_rows(N, nranks, rank):
     """Contiguous row blocks as PETSc's default layout (PetscSplitOwnership):
     the first N % nranks ranks get one extra row."""

@@ -35,21 +35,28 @@ def test_bench_line_schema():
     assert rl["bound"] == "hbm" and rl["unit"] == "GB/s" and rl["peak"] == 8000.0
     assert abs(rl["frac"] - rl["achieved"] / rl["peak"]) < 1e-3
     cb = d["cpu_baseline"]
-    assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and cb["sample"]
+    assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and cb["sample"] and cb["host_stream_triad_GBps"] > 0
+    assert d["config"]["tol"] == 1e-8 and "value" in d["config"]["spmv_variant"]
+    assert d["kernels"]["matmult"]["csr_model_GBps"] >= d["kernels"]["matmult"]["GBps"]
 
 
-def test_bench_two_ranks_rehearsal():
-    """The N > 1 code path of bench.py (launcher environment, barriers, max over ranks, sums
-    over ranks) with two ranks sharing the one GPU of the test box over the gloo transport."""
+def _free_port():
     import socket
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
+    return port
+
+
+def test_bench_two_ranks_under_torchrun():
+    """The N > 1 code path of bench.py as a launcher starts it (RANK/WORLD_SIZE in the
+    environment): barriers, max over ranks, sums over ranks; two ranks share the one GPU of the
+    test box over the gloo transport.  --weak: every rank keeps grid^2 rows."""
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-                        "--master-addr", "127.0.0.1", "--master-port", str(port),
+                        "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
                         os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
-                        "--grid", "256", "--transport", "gloo", "--share-device"],
+                        "--workload", "ex2", "--weak", "--grid", "256", "--transport", "gloo", "--share-device"],
                        cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
     assert r.returncode == 0, r.stderr.decode(errors="replace")[-3000:]
     lines = [l for l in r.stdout.decode().splitlines() if l.strip().startswith("{")]
@@ -60,6 +67,41 @@ def test_bench_two_ranks_rehearsal():
     assert d["config"]["transport"] == "gloo"
     assert "cpu_baseline" not in d            # rank 0 at N = 1 only
     assert d["value"] > 0
+
+
+def test_bench_starts_its_own_ranks_strong_scaling():
+    """`python bench.py --gpus 2` from a plain shell starts the two rank processes itself; the
+    default workload on several GPUs is the 3-D Laplacian on a fixed grid cut into slabs of
+    planes (strong scaling)."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--grid", "64", "--workload", "lap3d", "--transport", "gloo", "--share-device"],
+                       cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300,
+                       env={k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")})
+    assert r.returncode == 0, r.stderr.decode(errors="replace")[-3000:]
+    lines = [l for l in r.stdout.decode().splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1, r.stdout.decode()[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["steps"] == 2
+    assert d["config"]["workload"].startswith("3-D 7-point Laplacian 64x64x64 (262144 rows)")
+    assert d["config"]["rows_per_gpu"] == 32 * 64 * 64 and "planes" in d["config"]["partition"]
+    assert "ghost entries received per product: 4096" in d["config"]["spmv_variant"]
+    assert d["value"] > 0
+
+
+def test_bench_refuses_a_transport_other_than_rccl():
+    """No silent fallback: two ranks on one device cannot form an RCCL communicator, and the
+    run must fail rather than print a line measured over host-staged collectives; asking for
+    gloo without --share-device is refused as well."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1",
+                        "--grid", "32", "--workload", "lap3d", "--share-device"],
+                       cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300, env=env)
+    assert r.returncode != 0
+    assert not [l for l in r.stdout.decode().splitlines() if l.strip().startswith("{")]
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1",
+                        "--grid", "32", "--workload", "lap3d", "--transport", "gloo"],
+                       cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300, env=env)
+    assert r.returncode != 0 and b"rehearsal" in r.stderr
 
 
 def test_bench_to_convergence_checks_eigenvalues():
