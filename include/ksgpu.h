@@ -116,6 +116,9 @@ int ksg_vec_scale(ksg_ctx ctx, double *x, double alpha, int64_t n);
 int ksg_vec_axpy(ksg_ctx ctx, double *y, double alpha, const double *x, int64_t n);
 int ksg_vec_dot(ksg_ctx ctx, const double *x, const double *y, int64_t n, double *result); /* collective */
 int ksg_vec_norm2(ksg_ctx ctx, const double *x, int64_t n, double *result);                 /* collective */
+/* local rows only, no reduction over the ranks (VecDot_Seq under VecDot_MPI; the dot_local /
+ * norm_local slots that VecDotBegin / VecNormBegin call before PETSc's own merged MPI_Allreduce) */
+int ksg_vec_dot_local(ksg_ctx ctx, const double *x, const double *y, int64_t n, double *result);
 /* x[i] = 2*u(splitmix64(seed ^ (row0+i))) - 1: start vector that depends only on
  * the global row index (stands in for BVSetRandomColumn, bvops.c:462-479). */
 int ksg_vec_fill_hash(ksg_ctx ctx, double *x, int64_t n, int64_t row0, uint64_t seed);

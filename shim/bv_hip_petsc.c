@@ -10,17 +10,24 @@
  *     BVRegister("hip", BVCreate_HIP);          (include/slepcbv.h:196)
  * after SlepcInitialize and select with -bv_type hip.
  *
- * Column views are device vectors (with the PETSc generation of the reference the
- * equivalent was VECCUDA and VecCUDAPlaceArray, sveccuda.cu:500-525).  libksgpu may hold an
- * update of a column back until the next call decides how to apply it (include/ksgpu.h,
- * KSG_OPT_LAZY_UPDATE), so the accessors through which code outside this file reaches a
- * view's device pointer must bracket it: readers call ksg_ctx_flush() first, writers call
- * ksg_bv_touch() afterwards.  The VecHIP* names below stand for those bracketed accessors
- * of the view type; the ops in this file use the raw pointer (no bracket needed: they hand
- * it straight back to libksgpu).
+ * Column views are vectors of the device Vec type of vec_hip_petsc.c (with the PETSc
+ * generation of the reference the equivalent was VECCUDA and VecCUDAPlaceArray,
+ * sveccuda.cu:500-525).  libksgpu may hold an update of a column back until the next call
+ * decides how to apply it (include/ksgpu.h, KSG_OPT_LAZY_UPDATE); the public accessors of that
+ * Vec type (VecHIPGetArrayRead, ...) bracket foreign code accordingly.  The ops in this file
+ * hand every device pointer straight back to libksgpu, which needs no bracket, so they use
+ * VecHIPGetDevicePointer_Private.
  */
 #include <slepc/private/bvimpl.h>
 #include "ksgpu.h"
+
+/* vec_hip_petsc.c */
+PETSC_EXTERN PetscErrorCode KSGGetContext(MPI_Comm,ksg_ctx*);
+PETSC_EXTERN PetscErrorCode VecHIPGetDevicePointer_Private(Vec,PetscBool write,PetscScalar**);
+PETSC_EXTERN PetscErrorCode VecHIPPlaceArray(Vec,const PetscScalar*);
+PETSC_EXTERN PetscErrorCode VecHIPResetArray(Vec);
+PETSC_EXTERN PetscErrorCode VecCreateMPIHIPWithArray(MPI_Comm,PetscInt,PetscInt,PetscInt,const PetscScalar*,Vec*);
+PETSC_EXTERN PetscErrorCode KSGRedOpenIfNeeded(ksg_ctx);
 
 typedef struct { ksg_ctx ctx; ksg_bv bv; } BV_HIP;
 
@@ -44,9 +51,8 @@ static PetscErrorCode BVDotVec_HIP(BV X,Vec y,PetscScalar *q)
     z = X->Bx;
   }
   if (!q) { ierr = VecGetArray(X->buffer,&qq);CHKERRQ(ierr); }      /* svec.c:137 */
-  ierr = VecHIPGetArrayRead(z,&py);CHKERRQ(ierr);
+  ierr = VecHIPGetDevicePointer_Private(z,PETSC_FALSE,(PetscScalar**)&py);CHKERRQ(ierr);
   KSG(ksg_bv_dotvec(x->bv,py,qq));                                  /* reduction included */
-  ierr = VecHIPRestoreArrayRead(z,&py);CHKERRQ(ierr);
   if (!q) { ierr = VecRestoreArray(X->buffer,&qq);CHKERRQ(ierr); }
   PetscFunctionReturn(0);
 }
@@ -60,9 +66,9 @@ static PetscErrorCode BVMultVec_HIP(BV X,PetscScalar alpha,PetscScalar beta,Vec 
   PetscFunctionBegin;
   SYNC(X);
   if (!q) { ierr = VecGetArray(X->buffer,&qq);CHKERRQ(ierr); }      /* svec.c:60 */
-  ierr = VecHIPGetArray(y,&py);CHKERRQ(ierr);
+  ierr = VecHIPGetDevicePointer_Private(y,PETSC_TRUE,&py);CHKERRQ(ierr);
   KSG(ksg_bv_multvec(x->bv,alpha,beta,py,qq));
-  ierr = VecHIPRestoreArray(y,&py);CHKERRQ(ierr);
+  ierr = PetscObjectStateIncrease((PetscObject)y);CHKERRQ(ierr);
   if (!q) { ierr = VecRestoreArray(X->buffer,&qq);CHKERRQ(ierr); }
   PetscFunctionReturn(0);
 }
@@ -175,18 +181,17 @@ static PetscErrorCode BVDotVec_Local_HIP(BV X,Vec y,PetscScalar *m)
     ierr = BV_IPMatMult(X,y);CHKERRQ(ierr);
     z = X->Bx;
   }
-  ierr = VecHIPGetArrayRead(z,&py);CHKERRQ(ierr);
+  ierr = VecHIPGetDevicePointer_Private(z,PETSC_FALSE,(PetscScalar**)&py);CHKERRQ(ierr);
   KSG(ksg_bv_dotvec_local(((BV_HIP*)X->data)->bv,py,m));            /* svec.c:145-163: no reduction */
-  ierr = VecHIPRestoreArrayRead(z,&py);CHKERRQ(ierr);
   PetscFunctionReturn(0);
 }
 
 /* Split phase (ops->dotvec_begin / dotvec_end, bvimpl.h:43-44, called from bvglobal.c:223-224,
    272-273 in place of PETSc's PetscSplitReduction): the kernel is queued into the batch of
-   the context, which the device Vec type opens on its first VecDotBegin/VecNormBegin or here,
-   and the first ...End of the group closes it with one all-reduce (ksg_red_close); the values
-   are handed out in posting order.  KSGRedPost/KSGRedFetch stand for that bookkeeping, shared
-   with the Vec type (a per-communicator queue of {offset,count} as PetscSplitReduction keeps). */
+   the context (opened by the first Begin of a group, KSGRedOpenIfNeeded), and the first ...End
+   of the group closes it with one all-reduce (ksg_red_close); the values are handed out in
+   posting order.  KSGRedPost/KSGRedFetch are that bookkeeping (vec_hip_petsc.c: a queue of
+   {offset,count} as PetscSplitReduction keeps). */
 PETSC_EXTERN PetscErrorCode KSGRedPost(MPI_Comm,ksg_ctx,PetscInt offset,PetscInt count);
 PETSC_EXTERN PetscErrorCode KSGRedFetch(MPI_Comm,ksg_ctx,PetscInt count,PetscScalar *out);
 
@@ -204,9 +209,9 @@ static PetscErrorCode BVDotVec_Begin_HIP(BV X,Vec y,PetscScalar *m)
     ierr = BV_IPMatMult(X,y);CHKERRQ(ierr);
     z = X->Bx;
   }
-  ierr = VecHIPGetArrayRead(z,&py);CHKERRQ(ierr);
+  ierr = VecHIPGetDevicePointer_Private(z,PETSC_FALSE,(PetscScalar**)&py);CHKERRQ(ierr);
+  ierr = KSGRedOpenIfNeeded(x->ctx);CHKERRQ(ierr);
   KSG(ksg_red_post_dotvec(x->bv,py,&offset));
-  ierr = VecHIPRestoreArrayRead(z,&py);CHKERRQ(ierr);
   ierr = KSGRedPost(PetscObjectComm((PetscObject)X),x->ctx,offset,X->k-X->l);CHKERRQ(ierr);
   PetscFunctionReturn(0);
 }
@@ -315,8 +320,7 @@ static PetscErrorCode BVDestroy_HIP(BV bv)
   BV_HIP         *ctx = (BV_HIP*)bv->data;
 
   PetscFunctionBegin;
-  KSG(ksg_bv_destroy(ctx->bv));
-  KSG(ksg_ctx_destroy(ctx->ctx));
+  KSG(ksg_bv_destroy(ctx->bv));                 /* the context belongs to the communicator (KSGGetContext) */
   ierr = VecDestroy(&bv->cv[0]);CHKERRQ(ierr);
   ierr = VecDestroy(&bv->cv[1]);CHKERRQ(ierr);
   ierr = PetscFree(bv->data);CHKERRQ(ierr);
@@ -328,22 +332,15 @@ PETSC_EXTERN PetscErrorCode BVCreate_HIP(BV bv)
   PetscErrorCode ierr;
   BV_HIP         *ctx;
   PetscInt       nloc,bs;
-  PetscMPIInt    rank,size;
 
   PetscFunctionBegin;
   ierr = PetscNewLog(bv,&ctx);CHKERRQ(ierr);
   bv->data = (void*)ctx;
   ierr = VecGetLocalSize(bv->t,&nloc);CHKERRQ(ierr);
   ierr = VecGetBlockSize(bv->t,&bs);CHKERRQ(ierr);
-  ierr = MPI_Comm_rank(PetscObjectComm((PetscObject)bv),&rank);CHKERRQ(ierr);
-  ierr = MPI_Comm_size(PetscObjectComm((PetscObject)bv),&size);CHKERRQ(ierr);
-  KSG(ksg_ctx_create(/* device of this rank */ rank % 8,&ctx->ctx));
-  if (size>1) {          /* one RCCL communicator per BV communicator */
-    char id[128];
-    if (!rank) KSG(ksg_comm_unique_id(id));
-    ierr = MPI_Bcast(id,128,MPI_BYTE,0,PetscObjectComm((PetscObject)bv));CHKERRQ(ierr);
-    KSG(ksg_ctx_comm_init_rccl(ctx->ctx,rank,size,id));
-  }
+  /* the context of this rank on the BV's communicator: device, streams and -- with several
+     ranks -- the RCCL communicator, shared with the vectors and the operator */
+  ierr = KSGGetContext(PetscObjectComm((PetscObject)bv),&ctx->ctx);CHKERRQ(ierr);
   KSG(ksg_bv_create(ctx->ctx,nloc,bv->N,bv->m,&ctx->bv));
   /* the two reusable column views, as svec.c:458-476 */
   ierr = VecCreateMPIHIPWithArray(PetscObjectComm((PetscObject)bv->t),bs,nloc,PETSC_DECIDE,NULL,&bv->cv[0]);CHKERRQ(ierr);

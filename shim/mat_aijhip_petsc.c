@@ -14,9 +14,9 @@
  *
  * Register with
  *     MatRegister("aijhip", MatCreate_AIJHIP);
- * after PetscInitialize.  The VecHIP* names stand for the accessors of the device Vec type
- * of the shim (see bv_hip_petsc.c); the communicator context of the matrix is the one of the
- * BV created on the same MPI communicator (one ksg_ctx per rank, KSGGetContext below).
+ * after PetscInitialize.  Vectors are of the device Vec type of vec_hip_petsc.c; the libksgpu
+ * context of the matrix is the one of its MPI communicator (one ksg_ctx per rank, shared with
+ * the vectors and the BV: KSGGetContext).
  */
 #include <petsc/private/matimpl.h>
 #include "ksgpu.h"
@@ -29,8 +29,10 @@ typedef struct {
 
 #define KSG(call) do { if ((call)) SETERRQ1(PETSC_COMM_SELF,PETSC_ERR_LIB,"libksgpu: %s",ksg_last_error()); } while (0)
 
+/* vec_hip_petsc.c */
 PETSC_EXTERN PetscErrorCode KSGGetContext(MPI_Comm,ksg_ctx*);      /* the per-rank context shared with the BV type */
 PETSC_EXTERN PetscErrorCode VecCreateMPIHIP(MPI_Comm,PetscInt,PetscInt,Vec*);
+PETSC_EXTERN PetscErrorCode VecHIPGetDevicePointer_Private(Vec,PetscBool write,PetscScalar**);
 
 static PetscErrorCode MatGetHIP(Mat A,Mat_AIJHIP **h)
 {
@@ -54,11 +56,11 @@ static PetscErrorCode MatMult_AIJHIP(Mat A,Vec x,Vec y)
 
   PetscFunctionBegin;
   ierr = MatGetHIP(A,&h);CHKERRQ(ierr);
-  ierr = VecHIPGetArrayRead(x,&px);CHKERRQ(ierr);
-  ierr = VecHIPGetArrayWrite(y,&py);CHKERRQ(ierr);
+  /* both pointers go straight into libksgpu, which applies what it holds back itself */
+  ierr = VecHIPGetDevicePointer_Private(x,PETSC_FALSE,(PetscScalar**)&px);CHKERRQ(ierr);
+  ierr = VecHIPGetDevicePointer_Private(y,PETSC_TRUE,&py);CHKERRQ(ierr);
   KSG(ksg_mat_mult(h->m,px,py));
-  ierr = VecHIPRestoreArrayRead(x,&px);CHKERRQ(ierr);
-  ierr = VecHIPRestoreArrayWrite(y,&py);CHKERRQ(ierr);
+  ierr = PetscObjectStateIncrease((PetscObject)y);CHKERRQ(ierr);
   PetscFunctionReturn(0);
 }
 

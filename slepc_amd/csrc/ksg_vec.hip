@@ -124,6 +124,20 @@ extern "C" int ksg_vec_dot(ksg_ctx c, const double *x, const double *y, int64_t 
   return ksg_comm_allreduce(c, c->d_red, result, 1, 0);
 }
 
+/* the same product over the local rows only (the dot_local slot of a Vec type, which PETSc's
+ * split-phase VecDotBegin/VecNormBegin sum over the ranks themselves) */
+extern "C" int ksg_vec_dot_local(ksg_ctx c, const double *x, const double *y, int64_t n, double *result) {
+  VEC_ARGS("ksg_vec_dot_local");
+  if (!result || (n && (!x || !y))) KSG_FAIL(KSG_ERR_ARG, "ksg_vec_dot_local: NULL pointer");
+  KSG_CHK(ksg_op_begin(c, KSG_EV_VECOPS));
+  KSG_CHK(ksg_launch_dotvec(c, x, 2, 1, y, n, c->d_red));
+  KSG_CHK(ksg_op_end(c, KSG_EV_VECOPS, (x == y ? 8.0 : 16.0) * (double)n, 2.0 * (double)n));
+  KSG_HIP(hipMemcpyAsync(c->h_red, c->d_red, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  KSG_HIP(hipStreamSynchronize(c->stream));
+  *result = c->h_red[0];
+  return KSG_OK;
+}
+
 extern "C" int ksg_vec_norm2(ksg_ctx c, const double *x, int64_t n, double *result) {
   VEC_ARGS("ksg_vec_norm2");
   if (!result || (n && !x)) KSG_FAIL(KSG_ERR_ARG, "ksg_vec_norm2: NULL pointer");

@@ -64,6 +64,7 @@ SIGNATURES = {
     "ksg_vec_axpy": (C.c_int, [C.c_void_p, C.c_void_p, C.c_double, C.c_void_p, c_i64]),
     "ksg_vec_dot": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, c_i64, c_dp]),
     "ksg_vec_norm2": (C.c_int, [C.c_void_p, C.c_void_p, c_i64, c_dp]),
+    "ksg_vec_dot_local": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, c_i64, c_dp]),
     "ksg_vec_fill_hash": (C.c_int, [C.c_void_p, C.c_void_p, c_i64, c_i64, C.c_uint64]),
     "ksg_bv_create": (C.c_int, [C.c_void_p, c_i64, c_i64, C.c_int, C.POINTER(C.c_void_p)]),
     "ksg_bv_destroy": (C.c_int, [C.c_void_p]),
@@ -242,6 +243,11 @@ class Context:
     def vec_dot(self, x, y, n):
         r = C.c_double()
         check(self.lib.ksg_vec_dot(self.h, x, y, n, C.byref(r)))
+        return r.value
+
+    def vec_dot_local(self, x, y, n):
+        r = C.c_double()
+        check(self.lib.ksg_vec_dot_local(self.h, x, y, n, C.byref(r)))
         return r.value
 
     def vec_norm2(self, x, n):
