@@ -128,13 +128,17 @@ struct ksg_mat_s {
   std::vector<int32_t> hot_cols; /* local column of every slot                  */
   int32_t *d_hot_idx;        /* the same on the device                         */
   double *d_xhot;            /* nhot doubles, refreshed by every product       */
-  /* ghost block: only rows that have ghost entries */
+  /* ghost block: a CSR over only the rows that have ghost entries (row i of it is local row
+   * o_rows[i]); its column indices are slots of the ghost buffer, or -- for its own most
+   * referenced columns -- ghost count + slot of a packed array, as in the diagonal block */
   int64_t no_rows;           /* number of such rows                            */
   int32_t *o_rows;           /* their local row indices                        */
-  int64_t *o_rowptr;
-  int32_t *o_colidx;         /* index into the ghost buffer                    */
-  double *o_val;
+  ksg_csr_dev ghost;
   int64_t o_nnz;
+  int64_t g_nhot;
+  std::vector<int32_t> g_hot_cols;
+  int32_t *d_g_hot_idx;
+  double *d_g_xhot;
   /* halo plan */
   int64_t nghost, nsend;
   double *d_ghost, *d_send;  /* device staging buffers                         */

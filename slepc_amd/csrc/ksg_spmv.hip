@@ -39,14 +39,19 @@ __device__ __forceinline__ void fence_i(int32_t &v) { asm volatile("" : "+v"(v))
 
 #define KSG_TILE_PER_THREAD (KSG_TILE_NNZ / KSG_BLOCK)    /* entries of a tile per thread: 8 */
 
-/* RES = 0: y = A x.  RES = 1: nothing is stored; every row's sum goes into the residual
+/* RES = 2: y[rowmap[row]] += (A x)_row -- the ghost block of a distributed operator, whose rows
+ * are a subset of the local rows, added to what the diagonal block left in y.
+ * RES = 0: y = A x.  RES = 1: nothing is stored; every row's sum goes into the residual
  * r = (A x)_row - kr x_row + ki xi_row (xi may be NULL) and the workgroup leaves the sum
  * of r^2 over its rows in partial[blockIdx.x] -- the norm EPSComputeResidualNorm_Private
  * (src/eps/interface/epssolve.c:506-556) needs, without materialising A x. */
 template <int RES>
 __device__ __forceinline__ void spmv_emit(double s, int row, const double *__restrict__ x, double *__restrict__ y,
-                                          double kr, double ki, const double *__restrict__ xi, double &acc, bool nt) {
-  if (RES) {
+                                          double kr, double ki, const double *__restrict__ xi, double &acc, bool nt,
+                                          const int32_t *__restrict__ rowmap) {
+  if (RES == 2) {
+    y[rowmap[row]] += s;               /* every row of the block belongs to one workgroup, one lane */
+  } else if (RES) {
     double r = fma(-kr, x[row], s);
     if (xi) r = fma(ki, xi[row], r);
     acc = fma(r, r, acc);
@@ -85,7 +90,8 @@ __global__ __launch_bounds__(KSG_BLOCK) void k_spmv_tiles(const int32_t *__restr
                                                            double *__restrict__ partial,
                                                            const double *__restrict__ xh, int32_t nx,
                                                            const uint8_t *__restrict__ vidx,
-                                                           const double *__restrict__ vtab) {
+                                                           const double *__restrict__ vtab,
+                                                           const int32_t *__restrict__ rowmap) {
   __shared__ double prod[KSG_TILE_NNZ];
   __shared__ double red[KSG_BLOCK / 64];
   double acc = 0.0;
@@ -127,8 +133,8 @@ __global__ __launch_bounds__(KSG_BLOCK) void k_spmv_tiles(const int32_t *__restr
       double s = red[0];
 #pragma unroll
       for (int w = 1; w < KSG_BLOCK / 64; w++) s += red[w];
-      spmv_emit<RES>(s, r0, x, y, kr, ki, xi, acc, false);
-      if (RES) partial[blockIdx.x] = acc;
+      spmv_emit<RES>(s, r0, x, y, kr, ki, xi, acc, false, rowmap);
+      if (RES == 1) partial[blockIdx.x] = acc;
     }
     return;
   }
@@ -199,7 +205,7 @@ __global__ __launch_bounds__(KSG_BLOCK) void k_spmv_tiles(const int32_t *__restr
         const int b = rb[j], e = re[j];
         double s = 0.0;
         for (int t = b; t < e; t++) s += prod[t];
-        spmv_emit<RES>(s, r0 + lr, x, y, kr, ki, xi, acc, true);
+        spmv_emit<RES>(s, r0 + lr, x, y, kr, ki, xi, acc, true, rowmap);
       }
     }
   } else {
@@ -213,9 +219,9 @@ __global__ __launch_bounds__(KSG_BLOCK) void k_spmv_tiles(const int32_t *__restr
       for (int t = b + g; t < e; t += G) s += prod[t];
     }
     s = wave_sum_width(s, G);
-    if (lr < nrows && g == 0) spmv_emit<RES>(s, r0 + lr, x, y, kr, ki, xi, acc, false);
+    if (lr < nrows && g == 0) spmv_emit<RES>(s, r0 + lr, x, y, kr, ki, xi, acc, false, rowmap);
   }
-  if (RES) {
+  if (RES == 1) {
     /* sum of the squared residuals of the tile, in a fixed order */
     __syncthreads();                                   /* prod is dead: red is free again */
     acc = wave_sum_width(acc, 64);
@@ -361,25 +367,23 @@ __global__ __launch_bounds__(KSG_BLOCK) void k_spmm_tiles(const int32_t *__restr
   }
 }
 
-/* ghost block: y[rows[i]] += sum of its ghost entries (few rows, thread per row) */
-__global__ __launch_bounds__(KSG_BLOCK) void k_spmv_ghost_add(int64_t nrows, const int32_t *__restrict__ rows,
-                                                               const int64_t *__restrict__ rowptr,
-                                                               const int32_t *__restrict__ colidx,
-                                                               const double *__restrict__ val,
-                                                               const double *__restrict__ xg,
-                                                               double *__restrict__ y) {
-  const int64_t stride = (int64_t)gridDim.x * KSG_BLOCK;
-  for (int64_t i = (int64_t)blockIdx.x * KSG_BLOCK + threadIdx.x; i < nrows; i += stride) {
-    double s = 0.0;
-    for (int64_t p = rowptr[i]; p < rowptr[i + 1]; p++) s = fma(val[p], xg[colidx[p]], s);
-    y[rows[i]] += s;
-  }
-}
-
 __global__ __launch_bounds__(KSG_BLOCK) void k_gather(const double *__restrict__ x, const int32_t *__restrict__ idx,
                                                        double *__restrict__ out, int64_t n) {
   const int64_t stride = (int64_t)gridDim.x * KSG_BLOCK;
   for (int64_t i = (int64_t)blockIdx.x * KSG_BLOCK + threadIdx.x; i < n; i += stride) out[i] = x[idx[i]];
+}
+
+/* One launch of the tile kernel over the block D: xh != NULL selects the variant whose column
+ * indices from nx on are slots of the packed array xh, D.nvt the one-byte value indices. */
+template <int RES>
+static void launch_tiles(hipStream_t st, const ksg_csr_dev &D, const double *x, double *y, double kr, double ki,
+                         const double *xi, double *partial, const double *xh, int32_t nx, const int32_t *rowmap) {
+  const dim3 grid((unsigned)D.ntiles), block(KSG_BLOCK);
+#define KSG_TILES(HOT, VT) hipLaunchKernelGGL((k_spmv_tiles<RES, HOT, VT>), grid, block, 0, st, D.tiles, D.tile_p, D.rowoff, D.colidx, \
+                           D.val, x, y, kr, ki, xi, partial, xh, nx, (const uint8_t *)D.vidx, (const double *)D.vtab, rowmap)
+  if (xh) { if (D.nvt) KSG_TILES(1, 1); else KSG_TILES(1, 0); }
+  else    { if (D.nvt) KSG_TILES(0, 1); else KSG_TILES(0, 0); }
+#undef KSG_TILES
 }
 
 /* ------------------------------------------------------------------------ */
@@ -467,9 +471,6 @@ static void choose_hot_columns(int64_t ncols, int64_t nnz, const int32_t *colidx
   }
 }
 
-/* decides on the packing for the diagonal block of A and uploads it */
-static int diag_to_device(ksg_mat A, int64_t nrows, const int64_t *rowptr, const int32_t *colidx, const double *val);
-
 static int csr_to_device(ksg_csr_dev *D, int64_t nrows, const int64_t *rowptr, const int32_t *colidx,
                          const double *val) {
   D->nrows = nrows;
@@ -529,16 +530,23 @@ static int csr_to_device(ksg_csr_dev *D, int64_t nrows, const int64_t *rowptr, c
   return KSG_OK;
 }
 
-static int diag_to_device(ksg_mat A, int64_t nrows, const int64_t *rowptr, const int32_t *colidx, const double *val) {
+/* Uploads one block whose column indices address a vector of `ncols` entries, after deciding
+ * on the packing of its most referenced columns. */
+static int block_to_device(ksg_ctx c, ksg_csr_dev *D, int64_t ncols, int64_t nrows, const int64_t *rowptr, const int32_t *colidx,
+                           const double *val, std::vector<int32_t> &hot_cols, int64_t *nhot, int32_t **d_hot_idx, double **d_xhot) {
   std::vector<int32_t> relabeled;
-  choose_hot_columns(A->nc, rowptr[nrows], colidx, A->ctx->hot_cols, A->hot_cols, relabeled);
-  A->nhot = (int64_t)A->hot_cols.size();
-  if (A->nhot) {
-    KSG_CHK(upload(&A->d_hot_idx, A->hot_cols.data(), A->hot_cols.size()));
-    hipError_t e = hipMalloc(&A->d_xhot, (size_t)A->nhot * sizeof(double));
-    if (e != hipSuccess) KSG_FAIL(KSG_ERR_MEM, "matrix upload: %zu bytes: %s", (size_t)A->nhot * sizeof(double), hipGetErrorString(e));
+  choose_hot_columns(ncols, rowptr[nrows], colidx, c->hot_cols, hot_cols, relabeled);
+  *nhot = (int64_t)hot_cols.size();
+  if (*nhot) {
+    KSG_CHK(upload(d_hot_idx, hot_cols.data(), hot_cols.size()));
+    hipError_t e = hipMalloc(d_xhot, (size_t)*nhot * sizeof(double));
+    if (e != hipSuccess) KSG_FAIL(KSG_ERR_MEM, "matrix upload: %zu bytes: %s", (size_t)*nhot * sizeof(double), hipGetErrorString(e));
   }
-  return csr_to_device(&A->diag, nrows, rowptr, A->nhot ? relabeled.data() : colidx, val);
+  return csr_to_device(D, nrows, rowptr, *nhot ? relabeled.data() : colidx, val);
+}
+
+static int diag_to_device(ksg_mat A, int64_t nrows, const int64_t *rowptr, const int32_t *colidx, const double *val) {
+  return block_to_device(A->ctx, &A->diag, A->nc, nrows, rowptr, colidx, val, A->hot_cols, &A->nhot, &A->d_hot_idx, &A->d_xhot);
 }
 
 static void csr_free(ksg_csr_dev *D) {
@@ -602,7 +610,9 @@ static int mat_create(ksg_ctx c, int64_t n, int64_t N, int64_t row0, int64_t nc,
   A->ctx = c; A->n = n; A->N = N; A->row0 = row0; A->nnz = rowptr[n];
   A->nc = nc; A->NC = NC; A->col0 = col0;
   memset(&A->diag, 0, sizeof(A->diag));
-  A->no_rows = 0; A->o_rows = NULL; A->o_rowptr = NULL; A->o_colidx = NULL; A->o_val = NULL; A->o_nnz = 0;
+  A->no_rows = 0; A->o_rows = NULL; A->o_nnz = 0;
+  memset(&A->ghost, 0, sizeof(A->ghost));
+  A->g_nhot = 0; A->d_g_hot_idx = NULL; A->d_g_xhot = NULL;
   A->nghost = A->nsend = 0;
   A->d_ghost = A->d_send = A->h_ghost = A->h_send = NULL; A->d_send_idx = NULL;
   A->nhot = 0; A->d_hot_idx = NULL; A->d_xhot = NULL;
@@ -695,9 +705,9 @@ static int mat_create(ksg_ctx c, int64_t n, int64_t N, int64_t row0, int64_t nc,
   A->no_rows = (int64_t)o_rows.size();
   A->o_nnz = (int64_t)o_ci.size();
   if (!rc) rc = upload(&A->o_rows, o_rows.data(), o_rows.size());
-  if (!rc) rc = upload(&A->o_rowptr, o_rp.data(), o_rp.size());
-  if (!rc) rc = upload(&A->o_colidx, o_ci.data(), o_ci.size());
-  if (!rc) rc = upload(&A->o_val, o_v.data(), o_v.size());
+  if (!rc && A->no_rows)
+    rc = block_to_device(c, &A->ghost, A->nghost, A->no_rows, o_rp.data(), o_ci.data(), o_v.data(), A->g_hot_cols, &A->g_nhot,
+                         &A->d_g_hot_idx, &A->d_g_xhot);
   if (!rc) rc = upload(&A->d_send_idx, send_idx.data(), (size_t)A->nsend);
   if (!rc) { hipError_t e = hipMalloc(&A->d_ghost, (size_t)std::max<int64_t>(A->nghost, 1) * sizeof(double)); if (e != hipSuccess) rc = KSG_ERR_MEM; }
   if (!rc) { hipError_t e = hipMalloc(&A->d_send, (size_t)std::max<int64_t>(A->nsend, 1) * sizeof(double)); if (e != hipSuccess) rc = KSG_ERR_MEM; }
@@ -763,9 +773,12 @@ static int mat_to_host(ksg_mat A, std::vector<int64_t> &rp, std::vector<int32_t>
   std::vector<int64_t> orp;
   std::vector<double> ova;
   KSG_CHK(download(orows, A->o_rows, (size_t)A->no_rows));
-  KSG_CHK(download(orp, A->o_rowptr, (size_t)A->no_rows + 1));
-  KSG_CHK(download(oci, A->o_colidx, (size_t)A->o_nnz));
-  KSG_CHK(download(ova, A->o_val, (size_t)A->o_nnz));
+  if (A->no_rows) {
+    KSG_CHK(download(orp, A->ghost.rowptr, (size_t)A->no_rows + 1));
+    KSG_CHK(download(oci, A->ghost.colidx, (size_t)A->o_nnz));
+    KSG_CHK(download(ova, A->ghost.val, (size_t)A->o_nnz));
+    if (A->g_nhot) for (size_t p = 0; p < oci.size(); p++) if ((int64_t)oci[p] >= A->nghost) oci[p] = A->g_hot_cols[(size_t)((int64_t)oci[p] - A->nghost)];
+  } else orp.assign(1, 0);
   rp.assign((size_t)A->n + 1, 0);
   ci.clear(); va.clear();
   ci.reserve((size_t)A->nnz); va.reserve((size_t)A->nnz);
@@ -865,10 +878,10 @@ extern "C" int ksg_mat_destroy(ksg_mat A) {
   hipStreamSynchronize(A->ctx->comm_stream);
   hipStreamSynchronize(A->ctx->stream);
   csr_free(&A->diag);
+  csr_free(&A->ghost);
   if (A->o_rows) hipFree(A->o_rows);
-  if (A->o_rowptr) hipFree(A->o_rowptr);
-  if (A->o_colidx) hipFree(A->o_colidx);
-  if (A->o_val) hipFree(A->o_val);
+  if (A->d_g_hot_idx) hipFree(A->d_g_hot_idx);
+  if (A->d_g_xhot) hipFree(A->d_g_xhot);
   if (A->d_send_idx) hipFree(A->d_send_idx);
   if (A->d_hot_idx) hipFree(A->d_hot_idx);
   if (A->d_xhot) hipFree(A->d_xhot);
@@ -913,29 +926,23 @@ static int mat_mult_raw(ksg_mat A, const double *x, double *y) {
     if (A->nsend)
       hipLaunchKernelGGL(k_gather, dim3(ksg_grid_for(A->nsend)), dim3(KSG_BLOCK), 0, c->comm_stream, x, A->d_send_idx, A->d_send, A->nsend);
   }
-  if (A->diag.ntiles && A->nhot) {
-    hipLaunchKernelGGL(k_gather, dim3(ksg_grid_for(A->nhot)), dim3(KSG_BLOCK), 0, c->stream, x, A->d_hot_idx, A->d_xhot, A->nhot);
-    { if (A->diag.nvt) { hipLaunchKernelGGL((k_spmv_tiles<0, 1, 1>), dim3((unsigned)A->diag.ntiles), dim3(KSG_BLOCK), 0, c->stream,
-                       A->diag.tiles, A->diag.tile_p, A->diag.rowoff, A->diag.colidx, A->diag.val, x, y, 0.0, 0.0,
-                       (const double *)NULL, (double *)NULL, (const double *)A->d_xhot, (int32_t)A->nc, (const uint8_t *)A->diag.vidx, (const double *)A->diag.vtab); }
-      else { hipLaunchKernelGGL((k_spmv_tiles<0, 1, 0>), dim3((unsigned)A->diag.ntiles), dim3(KSG_BLOCK), 0, c->stream,
-                       A->diag.tiles, A->diag.tile_p, A->diag.rowoff, A->diag.colidx, A->diag.val, x, y, 0.0, 0.0,
-                       (const double *)NULL, (double *)NULL, (const double *)A->d_xhot, (int32_t)A->nc, (const uint8_t *)NULL, (const double *)NULL); } }
-  } else if (A->diag.ntiles)
-    { if (A->diag.nvt) { hipLaunchKernelGGL((k_spmv_tiles<0, 0, 1>), dim3((unsigned)A->diag.ntiles), dim3(KSG_BLOCK), 0, c->stream,
-                       A->diag.tiles, A->diag.tile_p, A->diag.rowoff, A->diag.colidx, A->diag.val, x, y, 0.0, 0.0,
-                       (const double *)NULL, (double *)NULL, (const double *)NULL, (int32_t)0, (const uint8_t *)A->diag.vidx, (const double *)A->diag.vtab); }
-      else { hipLaunchKernelGGL((k_spmv_tiles<0, 0, 0>), dim3((unsigned)A->diag.ntiles), dim3(KSG_BLOCK), 0, c->stream,
-                       A->diag.tiles, A->diag.tile_p, A->diag.rowoff, A->diag.colidx, A->diag.val, x, y, 0.0, 0.0,
-                       (const double *)NULL, (double *)NULL, (const double *)NULL, (int32_t)0, (const uint8_t *)NULL, (const double *)NULL); } }
+  if (A->diag.ntiles) {
+    if (A->nhot) hipLaunchKernelGGL(k_gather, dim3(ksg_grid_for(A->nhot)), dim3(KSG_BLOCK), 0, c->stream, x, A->d_hot_idx, A->d_xhot, A->nhot);
+    launch_tiles<0>(c->stream, A->diag, x, y, 0.0, 0.0, NULL, NULL, A->nhot ? A->d_xhot : NULL, (int32_t)A->nc, NULL);
+  } else if (A->n) {
+    KSG_HIP(hipMemsetAsync(y, 0, (size_t)A->n * sizeof(double), c->stream));     /* no local columns at all */
+  }
   KSG_HIP(hipGetLastError());
   if (halo) {
     KSG_CHK(ksg_comm_exchange(c, A));
     KSG_HIP(hipEventRecord(c->ev_halo_done, c->comm_stream));
     KSG_HIP(hipStreamWaitEvent(c->stream, c->ev_halo_done, 0));
-    if (A->no_rows)
-      hipLaunchKernelGGL(k_spmv_ghost_add, dim3(ksg_grid_for(A->no_rows)), dim3(KSG_BLOCK), 0, c->stream,
-                         A->no_rows, A->o_rows, A->o_rowptr, A->o_colidx, A->o_val, A->d_ghost, y);
+    if (A->no_rows) {
+      /* the ghost block through the same tile kernel (one lane per row, several lanes per row,
+       * whole workgroup for a long row), adding into the rows it touches */
+      if (A->g_nhot) hipLaunchKernelGGL(k_gather, dim3(ksg_grid_for(A->g_nhot)), dim3(KSG_BLOCK), 0, c->stream, (const double *)A->d_ghost, A->d_g_hot_idx, A->d_g_xhot, A->g_nhot);
+      launch_tiles<2>(c->stream, A->ghost, A->d_ghost, y, 0.0, 0.0, NULL, NULL, A->g_nhot ? A->d_g_xhot : NULL, (int32_t)A->nghost, A->o_rows);
+    }
     KSG_HIP(hipGetLastError());
   }
   return KSG_OK;
@@ -954,7 +961,7 @@ static double block_stream_bytes(const ksg_csr_dev &D) {
 static inline double spmv_bytes(ksg_mat A) {
   double b = block_stream_bytes(A->diag) + 8.0 * (double)A->nc + 8.0 * (double)A->n + 20.0 * (double)A->nhot;
   if (A->ctx->nranks > 1)
-    b += 12.0 * (double)A->o_nnz + 8.0 * (double)(A->no_rows + 1) + 20.0 * (double)A->no_rows +
+    b += (A->no_rows ? block_stream_bytes(A->ghost) : 0.0) + 20.0 * (double)A->no_rows + 20.0 * (double)A->g_nhot +
          8.0 * (double)A->nghost + 20.0 * (double)A->nsend;
   return b;
 }
@@ -973,10 +980,14 @@ extern "C" int ksg_mat_traffic_model(ksg_mat A, double *executed, double *csr_mo
 
 extern "C" int ksg_mat_describe(ksg_mat A, char *buf, size_t len) {
   if (!A || !buf || !len) KSG_FAIL(KSG_ERR_ARG, "ksg_mat_describe: NULL argument");
-  snprintf(buf, len, "row tiles of <= %d entries / %d rows: %lld one lane per row, %lld several lanes per row, %lld single long rows; "
+  int k = snprintf(buf, len, "row tiles of <= %d entries / %d rows: %lld one lane per row, %lld several lanes per row, %lld single long rows; "
            "2-byte row offsets; values: %s; packed hot columns: %lld; ghost entries received per product: %lld",
            KSG_TILE_NNZ, KSG_TILE_ROWS, (long long)A->diag.n_stream, (long long)A->diag.n_group, (long long)A->diag.n_long,
            A->diag.nvt ? "1-byte indices into a 256-entry table" : "8-byte stream", (long long)A->nhot, (long long)A->nghost);
+  if (A->ctx->nranks > 1 && k > 0 && (size_t)k < len)
+    snprintf(buf + k, len - (size_t)k, "; ghost block: %lld entries in %lld rows through the same tile kernel (%lld/%lld/%lld tiles, %lld packed)",
+             (long long)A->o_nnz, (long long)A->no_rows, (long long)A->ghost.n_stream, (long long)A->ghost.n_group, (long long)A->ghost.n_long,
+             (long long)A->g_nhot);
   return KSG_OK;
 }
 
@@ -1007,21 +1018,8 @@ extern "C" int ksg_mat_residual_norm(ksg_mat A, double kr, double ki, const doub
     nb = (int)A->diag.ntiles;
     if (nb) {
       KSG_CHK(ksg_ensure_partial(c, (size_t)nb));
-      if (A->nhot) {
-        hipLaunchKernelGGL(k_gather, dim3(ksg_grid_for(A->nhot)), dim3(KSG_BLOCK), 0, c->stream, x, A->d_hot_idx, A->d_xhot, A->nhot);
-        { if (A->diag.nvt) { hipLaunchKernelGGL((k_spmv_tiles<1, 1, 1>), dim3((unsigned)nb), dim3(KSG_BLOCK), 0, c->stream, A->diag.tiles, A->diag.tile_p,
-                           A->diag.rowoff, A->diag.colidx, A->diag.val, x, (double *)NULL, kr, ki, xi, c->d_partial,
-                           (const double *)A->d_xhot, (int32_t)A->nc, (const uint8_t *)A->diag.vidx, (const double *)A->diag.vtab); }
-      else { hipLaunchKernelGGL((k_spmv_tiles<1, 1, 0>), dim3((unsigned)nb), dim3(KSG_BLOCK), 0, c->stream, A->diag.tiles, A->diag.tile_p,
-                           A->diag.rowoff, A->diag.colidx, A->diag.val, x, (double *)NULL, kr, ki, xi, c->d_partial,
-                           (const double *)A->d_xhot, (int32_t)A->nc, (const uint8_t *)NULL, (const double *)NULL); } }
-      } else
-        { if (A->diag.nvt) { hipLaunchKernelGGL((k_spmv_tiles<1, 0, 1>), dim3((unsigned)nb), dim3(KSG_BLOCK), 0, c->stream, A->diag.tiles, A->diag.tile_p,
-                           A->diag.rowoff, A->diag.colidx, A->diag.val, x, (double *)NULL, kr, ki, xi, c->d_partial,
-                           (const double *)NULL, (int32_t)0, (const uint8_t *)A->diag.vidx, (const double *)A->diag.vtab); }
-      else { hipLaunchKernelGGL((k_spmv_tiles<1, 0, 0>), dim3((unsigned)nb), dim3(KSG_BLOCK), 0, c->stream, A->diag.tiles, A->diag.tile_p,
-                           A->diag.rowoff, A->diag.colidx, A->diag.val, x, (double *)NULL, kr, ki, xi, c->d_partial,
-                           (const double *)NULL, (int32_t)0, (const uint8_t *)NULL, (const double *)NULL); } }
+      if (A->nhot) hipLaunchKernelGGL(k_gather, dim3(ksg_grid_for(A->nhot)), dim3(KSG_BLOCK), 0, c->stream, x, A->d_hot_idx, A->d_xhot, A->nhot);
+      launch_tiles<1>(c->stream, A->diag, x, NULL, kr, ki, xi, c->d_partial, A->nhot ? A->d_xhot : NULL, (int32_t)A->nc, NULL);
     }
   } else {
     KSG_CHK(mat_mult_raw(A, x, work));

@@ -454,8 +454,8 @@ class DeviceCSR:
         return a.value, b.value
 
     def describe(self):
-        buf = C.create_string_buffer(512)
-        check(self.lib.ksg_mat_describe(self.h, buf, 512))
+        buf = C.create_string_buffer(1024)
+        check(self.lib.ksg_mat_describe(self.h, buf, 1024))
         return buf.value.decode()
 
     def info(self):

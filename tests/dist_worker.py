@@ -18,6 +18,7 @@ import numpy as np  # noqa: E402
 
 def main():
     mode, case, out = sys.argv[1], sys.argv[2], sys.argv[3]
+    hot_limit = None
     from slepc_amd import dist as kdist, kseps as K, matgen as mg
     rank, _, size = kdist.env_rank()
     dist = kdist.init_process_group() if size > 1 else None
@@ -51,6 +52,16 @@ def main():
         row0, row1 = mg.split_rows(N, size, rank)
         csr = mg.rmat_laplacian(11, row0=row0, row1=row1)
         herm, kw = True, dict(nev=4, tol=1e-10)
+    elif case in ("rmat_nnz", "rmat_cost"):
+        # row blocks balanced by entries (rmat_nnz) or by entries plus a cost per row (rmat_cost),
+        # small limit on the packed columns so that both blocks of every rank pack some
+        scale = 13
+        N = 1 << scale
+        starts = mg.balanced_row_blocks(mg.rmat_row_weights(scale), size, 0.0 if case == "rmat_nnz" else 12.0)
+        row0, row1 = starts[rank], starts[rank + 1]
+        csr = mg.rmat_laplacian(scale, row0=row0, row1=row1)
+        herm, kw = True, dict(nev=4, tol=1e-10)
+        hot_limit = 256
     else:
         raise ValueError(case)
     n = row1 - row0
@@ -100,6 +111,8 @@ def main():
         ctx = ksgpu.Context(0)
         if size > 1:
             kdist.init_comm(ctx, transport=os.environ.get("KS_TRANSPORT", "gloo"))
+        if hot_limit is not None:
+            ctx.set_option(ksgpu.OPT_HOT_COLS, hot_limit)
         Am = K.Mat.create_aij_hip(ctx, rp, ci, va, N=N, row0=row0)
         eps = K.EPS(ctx.h)
         bvtype = "hip"
@@ -130,8 +143,26 @@ def main():
     else:
         res["x0"] = local.tolist()
     if mode == "gpu":
+        # one product against the whole matrix on the host, and what the operator packed
         from slepc_amd import ksgpu  # noqa: F811
-        res["mat_info"] = None
+        dev = ksgpu.DeviceCSR.__new__(ksgpu.DeviceCSR)
+        dev.ctx, dev.lib, dev.h = ctx, ctx.lib, Am.p.contents.data
+        res["variant"] = dev.describe()
+        res["rows"] = [row0, row1]
+        xv, yv = Am.create_vecs(), Am.create_vecs()
+        xv.set_values(np.cos(0.37 * np.arange(row0, row1)) + (np.arange(row0, row1) % 7 == 0))
+        Am.mult(xv, yv)
+        yl = yv.get_values()
+        if size > 1:
+            parts = [None] * size
+            dist.all_gather_object(parts, yl)
+            yl = np.concatenate(parts)
+            descr = [None] * size
+            dist.all_gather_object(descr, res["variant"])
+            res["variant"] = descr
+        res["y"] = yl.tolist()
+        for o in (xv, yv):
+            o.destroy()
     if rank == 0:
         with open(out, "w") as f:
             json.dump(res, f)

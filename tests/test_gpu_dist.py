@@ -24,6 +24,38 @@ def test_ranks_match_single(case, nev, ranks):
     assert np.abs(s * x2 - x1).max() < 1e-6
 
 
+@pytest.mark.parametrize("case,ranks", [("rmat_nnz", 2), ("rmat_nnz", 3), ("rmat_cost", 3)])
+def test_rmat_balanced_blocks_match_single(case, ranks):
+    """The power-law operator split into row blocks balanced by entries (and by entries plus a
+    cost per row): eigenvalues to 1e-10 of the single-rank run, and one product against the
+    whole matrix on the host.  Most entries of every rank are ghost entries here; they go through
+    the tile kernel with its own packed columns."""
+    import re
+    from scipy.sparse import csr_matrix
+    from slepc_amd import matgen as mg
+    one = run_ranks("gpu", case, 1)
+    many = run_ranks("gpu", case, ranks)
+    assert one["reason"] == many["reason"] == 1
+    for a, b in zip(one["values"][:4], many["values"][:4]):
+        assert abs(a[0] - b[0]) <= 1e-10 * abs(a[0])
+    assert max(many["errors"]) < 1e-8
+    x1, x2 = np.array(one["x0"]), np.array(many["x0"])
+    assert np.abs(np.sign(x1 @ x2) * x2 - x1).max() < 1e-6
+    rp, ci, va = mg.rmat_laplacian(13)
+    N = 1 << 13
+    g = np.arange(N)
+    want = csr_matrix((va, ci, rp), shape=(N, N)) @ (np.cos(0.37 * g) + (g % 7 == 0))
+    for res in (one, many):
+        assert np.abs(np.array(res["y"]) - want).max() <= 1e-13 * np.abs(want).max()
+    # every rank received ghosts and multiplied a ghost block; columns were packed in diagonal
+    # and in ghost blocks (a rank whose block of columns is small packs nothing)
+    ghosts = [int(re.search(r"ghost entries received per product: (\d+)", d).group(1)) for d in many["variant"]]
+    assert min(ghosts) > 0
+    assert all(int(re.search(r"ghost block: (\d+) entries", d).group(1)) > 0 for d in many["variant"])
+    assert sum(int(re.search(r"packed hot columns: (\d+)", d).group(1)) for d in many["variant"]) > 0
+    assert sum(int(re.search(r"(\d+) packed\)", d).group(1)) for d in many["variant"]) > 0
+
+
 @pytest.mark.parametrize("case,ranks", [("svd_tall", 2), ("svd_wide", 3)])
 def test_svd_ranks_match_single(case, ranks):
     """Rectangular operator with rows and columns split over the ranks, its transpose built

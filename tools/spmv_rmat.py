@@ -13,7 +13,14 @@ from slepc_amd import ksgpu, matgen
 def main():
     scale = int(sys.argv[1]) if len(sys.argv) > 1 else 22
     limits = [int(v) for v in (sys.argv[2] if len(sys.argv) > 2 else "0,65536,262144,524288").split(",")]
-    rp, ci, va = matgen.rmat_laplacian(scale)
+    cache = "/tmp/rmat_laplacian_%d.npz" % scale          # several profiler passes share one generation
+    if os.path.exists(cache):
+        z = np.load(cache)
+        rp, ci, va = z["rp"], z["ci"], z["va"]
+    else:
+        rp, ci, va = matgen.rmat_laplacian(scale)
+        if os.environ.get("KSG_RMAT_CACHE"):
+            np.savez(cache, rp=rp, ci=ci, va=va)
     n = len(rp) - 1
     lens = np.diff(rp)
     print("n=%d nnz=%d max row %d, rows > 32: %d, > 256: %d, > 4096: %d" % (
@@ -29,7 +36,7 @@ def main():
         ctx.sync()
         ctx.enable_timing(True)
         ctx.stats_reset()
-        for _ in range(20):
+        for _ in range(int(os.environ.get("KSG_SPMV_REPS", "20"))):
             A.mult(x, y)
         ctx.sync()
         s = ctx.stats()["matmult"]
