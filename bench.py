@@ -245,6 +245,11 @@ def main():
     if size > 1 and args.transport == "gloo" and not args.share_device:
         raise SystemExit("--transport gloo stages every collective through the host: it is accepted for "
                          "rehearsals with --share-device only")
+    if size > 1:
+        # a rank that hangs in a collective (a peer died, a communicator that never comes up) must
+        # not hold the launcher for ever: after the limit the process ends with SIGALRM's status
+        import signal
+        signal.alarm(int(os.environ.get("KSG_BENCH_WATCHDOG_S", "1500")))
     dist = kdist.init_process_group() if size > 1 else None
 
     ctx = ksgpu.Context(0 if args.share_device else local_rank)
