@@ -111,7 +111,10 @@ struct ksg_csr_dev {
                       * than it has rows); 2 bytes per row instead of the 8 of rowptr */
   uint8_t *vidx;     /* nnz one-byte indices into vtab, when the matrix has at most 256 distinct values */
   double *vtab;      /* 256 doubles */
-  int nvt;           /* 1 when vidx/vtab are there */
+  int nvt;           /* 1 when vidx/vtab are there; 2: the table covers the off-diagonal entries (at most
+                      * 255 distinct values) and the index 255 marks a diagonal entry, whose value is dvals[row] */
+  double *dvals;     /* nrows diagonal values (nvt == 2) */
+  int32_t dshift;    /* column index of row r's diagonal entry minus r (nvt == 2) */
   int64_t ntiles;
   int64_t n_stream, n_group, n_long;
 };

@@ -77,7 +77,10 @@ __device__ __forceinline__ double x_entry(const double *__restrict__ x, const do
 /* VT = 1: the operator has at most 256 distinct values (stencils, unweighted graphs): the entry
  * stream carries a one-byte index per entry instead of the eight-byte value, and the value comes
  * from a table of at most 2 KiB that stays in the CU's L1 -- the same values, 7 bytes per entry
- * less to move. */
+ * less to move.  VT = 2: the same for an operator whose off-diagonal entries have at most 255
+ * distinct values while the diagonal is arbitrary (graph Laplacians: -1 off the diagonal, the
+ * degree on it; shifted stencils): the index 255 marks a diagonal entry, whose value is read from
+ * a dense vector of the diagonal at its column (= its row: neighbouring rows, neighbouring loads). */
 template <int RES, int HOT, int VT>
 __global__ __launch_bounds__(KSG_BLOCK) void k_spmv_tiles(const int32_t *__restrict__ tiles,
                                                            const int64_t *__restrict__ tile_p,
@@ -91,7 +94,8 @@ __global__ __launch_bounds__(KSG_BLOCK) void k_spmv_tiles(const int32_t *__restr
                                                            const double *__restrict__ xh, int32_t nx,
                                                            const uint8_t *__restrict__ vidx,
                                                            const double *__restrict__ vtab,
-                                                           const int32_t *__restrict__ rowmap) {
+                                                           const int32_t *__restrict__ rowmap,
+                                                           const double *__restrict__ dvals, int32_t dshift) {
   __shared__ double prod[KSG_TILE_NNZ];
   __shared__ double red[KSG_BLOCK / 64];
   double acc = 0.0;
@@ -113,7 +117,11 @@ __global__ __launch_bounds__(KSG_BLOCK) void k_spmv_tiles(const int32_t *__restr
 #pragma unroll
       for (int i = 0; i < 8; i++) {
         ci[i] = __builtin_nontemporal_load(colidx + p + i * KSG_BLOCK);
-        v[i] = VT ? vtab[__builtin_nontemporal_load(vidx + p + i * KSG_BLOCK)] : __builtin_nontemporal_load(val + p + i * KSG_BLOCK);
+        if (VT) {
+          const int t = __builtin_nontemporal_load(vidx + p + i * KSG_BLOCK);
+          v[i] = vtab[t];
+          if (VT == 2 && t == 255) v[i] = dvals[ci[i] - dshift];
+        } else v[i] = __builtin_nontemporal_load(val + p + i * KSG_BLOCK);
       }
 #pragma unroll
       for (int i = 0; i < 8; i++) fence_i(ci[i]);
@@ -124,8 +132,16 @@ __global__ __launch_bounds__(KSG_BLOCK) void k_spmv_tiles(const int32_t *__restr
 #pragma unroll
       for (int i = 0; i < 8; i++) a = fma(v[i], xv[i], a);
     }
-    for (; p < p1; p += KSG_BLOCK)
-      a = fma(VT ? vtab[__builtin_nontemporal_load(vidx + p)] : __builtin_nontemporal_load(val + p), x_entry<HOT>(x, xh, nx, __builtin_nontemporal_load(colidx + p)), a);
+    for (; p < p1; p += KSG_BLOCK) {
+      const int32_t c1 = __builtin_nontemporal_load(colidx + p);
+      double v1;
+      if (VT) {
+        const int t = __builtin_nontemporal_load(vidx + p);
+        v1 = vtab[t];
+        if (VT == 2 && t == 255) v1 = dvals[c1 - dshift];
+      } else v1 = __builtin_nontemporal_load(val + p);
+      a = fma(v1, x_entry<HOT>(x, xh, nx, c1), a);
+    }
     a = wave_sum_width(a, 64);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = a;
     __syncthreads();
@@ -183,6 +199,10 @@ __global__ __launch_bounds__(KSG_BLOCK) void k_spmv_tiles(const int32_t *__restr
     if (VT) {
 #pragma unroll
       for (int i = 0; i < KSG_TILE_PER_THREAD; i++) v[i] = vtab[vi[i]];
+      if (VT == 2) {
+#pragma unroll
+        for (int i = 0; i < KSG_TILE_PER_THREAD; i++) if (vi[i] == 255) v[i] = dvals[ci[i] - dshift];
+      }
 #pragma unroll
       for (int i = 0; i < KSG_TILE_PER_THREAD; i++) fence_d(v[i]);
     }
@@ -380,9 +400,10 @@ static void launch_tiles(hipStream_t st, const ksg_csr_dev &D, const double *x, 
                          const double *xi, double *partial, const double *xh, int32_t nx, const int32_t *rowmap) {
   const dim3 grid((unsigned)D.ntiles), block(KSG_BLOCK);
 #define KSG_TILES(HOT, VT) hipLaunchKernelGGL((k_spmv_tiles<RES, HOT, VT>), grid, block, 0, st, D.tiles, D.tile_p, D.rowoff, D.colidx, \
-                           D.val, x, y, kr, ki, xi, partial, xh, nx, (const uint8_t *)D.vidx, (const double *)D.vtab, rowmap)
-  if (xh) { if (D.nvt) KSG_TILES(1, 1); else KSG_TILES(1, 0); }
-  else    { if (D.nvt) KSG_TILES(0, 1); else KSG_TILES(0, 0); }
+                           D.val, x, y, kr, ki, xi, partial, xh, nx, (const uint8_t *)D.vidx, (const double *)D.vtab, rowmap, \
+                           (const double *)D.dvals, D.dshift)
+  if (xh) { if (D.nvt == 2) KSG_TILES(1, 2); else if (D.nvt) KSG_TILES(1, 1); else KSG_TILES(1, 0); }
+  else    { if (D.nvt == 2) KSG_TILES(0, 2); else if (D.nvt) KSG_TILES(0, 1); else KSG_TILES(0, 0); }
 #undef KSG_TILES
 }
 
@@ -471,8 +492,43 @@ static void choose_hot_columns(int64_t ncols, int64_t nnz, const int32_t *colidx
   }
 }
 
+/* Indices of the entries' values in a table of their distinct bit patterns (at most `limit`);
+ * entries with skip[p] set are left out (their index becomes 255).  false: too many values. */
+static bool build_value_table(int64_t nnz, const double *val, const uint8_t *skip, size_t limit, std::vector<double> &tab,
+                              std::vector<uint8_t> &idx) {
+  tab.clear();
+  idx.assign((size_t)nnz, 255);
+  /* values are told apart by their bits; open addressing over 1024 slots, at most 256 in use */
+  uint64_t hkey[1024];
+  int hval[1024];
+  for (int t = 0; t < 1024; t++) hval[t] = -1;
+  uint64_t lastbits = 0;
+  int last = -1;
+  for (int64_t p = 0; p < nnz; p++) {
+    if (skip && skip[p]) continue;
+    uint64_t bits;
+    memcpy(&bits, &val[p], 8);
+    if (last < 0 || bits != lastbits) {
+      unsigned h = (unsigned)((bits * 0x9E3779B97F4A7C15ull) >> 54);
+      while (hval[h] >= 0 && hkey[h] != bits) h = (h + 1) & 1023;
+      if (hval[h] < 0) {
+        if (tab.size() == limit) return false;
+        hkey[h] = bits; hval[h] = (int)tab.size();
+        tab.push_back(val[p]);
+      }
+      last = hval[h]; lastbits = bits;
+    }
+    idx[(size_t)p] = (uint8_t)last;
+  }
+  tab.resize(256, 0.0);
+  return true;
+}
+
+/* diag_cols: for a block that holds the operator's diagonal, the column index every entry had
+ * before the packed columns were relabelled (row r's diagonal entry is the one in column
+ * r + dshift); NULL for a block without a diagonal (ghost blocks). */
 static int csr_to_device(ksg_csr_dev *D, int64_t nrows, const int64_t *rowptr, const int32_t *colidx,
-                         const double *val) {
+                         const double *val, const int32_t *diag_cols = NULL, int64_t dshift = 0) {
   D->nrows = nrows;
   D->nnz = rowptr[nrows];
   std::vector<int32_t> tiles;
@@ -485,38 +541,32 @@ static int csr_to_device(ksg_csr_dev *D, int64_t nrows, const int64_t *rowptr, c
   std::vector<int64_t> tile_p(tiles.size());
   for (size_t i = 0; i < tiles.size(); i++) tile_p[i] = rowptr[tiles[i]];
   KSG_CHK(upload(&D->tile_p, tile_p.data(), tile_p.size()));
-  /* at most 256 distinct values: one-byte indices into a table for the product kernel */
+  /* at most 256 distinct values: one-byte indices into a table for the product kernel; failing
+   * that, at most 255 distinct values off the diagonal and the diagonal as a dense vector */
   D->nvt = 0;
   if (D->nnz >= 4096) {
     std::vector<double> tab;
-    std::vector<uint8_t> idx((size_t)D->nnz);
-    /* values are told apart by their bits; open addressing over 1024 slots, at most 256 in use */
-    uint64_t hkey[1024];
-    int hval[1024];
-    for (int t = 0; t < 1024; t++) hval[t] = -1;
-    uint64_t lastbits = 0;
-    int last = -1;
-    bool ok = true;
-    for (int64_t p = 0; p < D->nnz && ok; p++) {
-      uint64_t bits;
-      memcpy(&bits, &val[p], 8);
-      if (last < 0 || bits != lastbits) {
-        unsigned h = (unsigned)((bits * 0x9E3779B97F4A7C15ull) >> 54);
-        while (hval[h] >= 0 && hkey[h] != bits) h = (h + 1) & 1023;
-        if (hval[h] < 0) {
-          if (tab.size() == 256) { ok = false; break; }
-          hkey[h] = bits; hval[h] = (int)tab.size();
-          tab.push_back(val[p]);
-        }
-        last = hval[h]; lastbits = bits;
+    std::vector<uint8_t> idx;
+    if (build_value_table(D->nnz, val, NULL, 256, tab, idx)) D->nvt = 1;
+    else if (diag_cols && dshift > -(int64_t)INT32_MAX && dshift < (int64_t)INT32_MAX) {
+      std::vector<uint8_t> isdiag((size_t)D->nnz, 0);
+      std::vector<double> dv((size_t)nrows, 0.0);
+      bool one_per_row = true;
+      for (int64_t r = 0; r < nrows && one_per_row; r++) {
+        int seen = 0;
+        for (int64_t p = rowptr[r]; p < rowptr[r + 1]; p++)
+          if ((int64_t)diag_cols[p] == r + dshift) { isdiag[(size_t)p] = 1; dv[(size_t)r] = val[p]; seen++; }
+        if (seen > 1) one_per_row = false;              /* duplicate entries: leave the matrix as it is */
       }
-      idx[(size_t)p] = (uint8_t)last;
+      if (one_per_row && build_value_table(D->nnz, val, isdiag.data(), 255, tab, idx)) {
+        KSG_CHK(upload(&D->dvals, dv.data(), dv.size()));
+        D->dshift = (int32_t)dshift;
+        D->nvt = 2;
+      }
     }
-    if (ok) {
-      tab.resize(256, 0.0);
+    if (D->nvt) {
       KSG_CHK(upload(&D->vidx, idx.data(), idx.size()));
       KSG_CHK(upload(&D->vtab, tab.data(), tab.size()));
-      D->nvt = 1;
     }
   }
   /* row offsets inside the tiles (a tile that is one long row has no use for them) */
@@ -533,20 +583,31 @@ static int csr_to_device(ksg_csr_dev *D, int64_t nrows, const int64_t *rowptr, c
 /* Uploads one block whose column indices address a vector of `ncols` entries, after deciding
  * on the packing of its most referenced columns. */
 static int block_to_device(ksg_ctx c, ksg_csr_dev *D, int64_t ncols, int64_t nrows, const int64_t *rowptr, const int32_t *colidx,
-                           const double *val, std::vector<int32_t> &hot_cols, int64_t *nhot, int32_t **d_hot_idx, double **d_xhot) {
+                           const double *val, std::vector<int32_t> &hot_cols, int64_t *nhot, int32_t **d_hot_idx, double **d_xhot,
+                           bool has_diag = false, int64_t dshift = 0) {
   std::vector<int32_t> relabeled;
   choose_hot_columns(ncols, rowptr[nrows], colidx, c->hot_cols, hot_cols, relabeled);
   *nhot = (int64_t)hot_cols.size();
   if (*nhot) {
+    /* a diagonal entry keeps its own column: the kernel finds its value by that column, and the
+     * x entry it multiplies sits next to those of the neighbouring rows anyway */
+    if (has_diag)
+      for (int64_t r = 0; r < nrows; r++)
+        for (int64_t p = rowptr[r]; p < rowptr[r + 1]; p++)
+          if ((int64_t)colidx[p] == r + dshift) relabeled[(size_t)p] = colidx[p];
     KSG_CHK(upload(d_hot_idx, hot_cols.data(), hot_cols.size()));
     hipError_t e = hipMalloc(d_xhot, (size_t)*nhot * sizeof(double));
     if (e != hipSuccess) KSG_FAIL(KSG_ERR_MEM, "matrix upload: %zu bytes: %s", (size_t)*nhot * sizeof(double), hipGetErrorString(e));
   }
-  return csr_to_device(D, nrows, rowptr, *nhot ? relabeled.data() : colidx, val);
+  return csr_to_device(D, nrows, rowptr, *nhot ? relabeled.data() : colidx, val, has_diag ? colidx : NULL, dshift);
 }
 
 static int diag_to_device(ksg_mat A, int64_t nrows, const int64_t *rowptr, const int32_t *colidx, const double *val) {
-  return block_to_device(A->ctx, &A->diag, A->nc, nrows, rowptr, colidx, val, A->hot_cols, &A->nhot, &A->d_hot_idx, &A->d_xhot);
+  /* the diagonal of a square operator lies in this block: row r (global row0 + r) has it in the
+   * local column row0 + r - col0 */
+  const bool square = A->N == A->NC;
+  return block_to_device(A->ctx, &A->diag, A->nc, nrows, rowptr, colidx, val, A->hot_cols, &A->nhot, &A->d_hot_idx, &A->d_xhot,
+                         square, A->row0 - A->col0);
 }
 
 static void csr_free(ksg_csr_dev *D) {
@@ -558,6 +619,7 @@ static void csr_free(ksg_csr_dev *D) {
   if (D->rowoff) hipFree(D->rowoff);
   if (D->vidx) hipFree(D->vidx);
   if (D->vtab) hipFree(D->vtab);
+  if (D->dvals) hipFree(D->dvals);
   memset(D, 0, sizeof(*D));
 }
 
@@ -956,7 +1018,8 @@ static int mat_mult_raw(ksg_mat A, const double *x, double *y) {
  * its own entry stream, row tables and the read-modify-write of the rows it touches; the halo adds
  * the pack kernel (index, read, write) and the received entries. */
 static double block_stream_bytes(const ksg_csr_dev &D) {
-  return (D.nvt ? 5.0 : 12.0) * (double)D.nnz + 2.0 * (double)(D.nrows + D.ntiles) + 12.0 * (double)(D.ntiles + 1);
+  return (D.nvt ? 5.0 : 12.0) * (double)D.nnz + (D.nvt == 2 ? 8.0 * (double)D.nrows : 0.0) +
+         2.0 * (double)(D.nrows + D.ntiles) + 12.0 * (double)(D.ntiles + 1);
 }
 static inline double spmv_bytes(ksg_mat A) {
   double b = block_stream_bytes(A->diag) + 8.0 * (double)A->nc + 8.0 * (double)A->n + 20.0 * (double)A->nhot;
@@ -983,6 +1046,7 @@ extern "C" int ksg_mat_describe(ksg_mat A, char *buf, size_t len) {
   int k = snprintf(buf, len, "row tiles of <= %d entries / %d rows: %lld one lane per row, %lld several lanes per row, %lld single long rows; "
            "2-byte row offsets; values: %s; packed hot columns: %lld; ghost entries received per product: %lld",
            KSG_TILE_NNZ, KSG_TILE_ROWS, (long long)A->diag.n_stream, (long long)A->diag.n_group, (long long)A->diag.n_long,
+           A->diag.nvt == 2 ? "1-byte indices into a 255-entry table off the diagonal, the diagonal as a dense vector" :
            A->diag.nvt ? "1-byte indices into a 256-entry table" : "8-byte stream", (long long)A->nhot, (long long)A->nghost);
   if (A->ctx->nranks > 1 && k > 0 && (size_t)k < len)
     snprintf(buf + k, len - (size_t)k, "; ghost block: %lld entries in %lld rows through the same tile kernel (%lld/%lld/%lld tiles, %lld packed)",

@@ -268,3 +268,77 @@ def test_value_table_spmv(gpu_ctx, ndistinct):
     A.destroy()
     gpu_ctx.vec_free(xd)
     gpu_ctx.vec_free(yd)
+
+
+@pytest.mark.parametrize("hot", [0, 256])
+def test_value_table_with_dense_diagonal(gpu_ctx, hot):
+    """Off-diagonal entries with few distinct values and an arbitrary diagonal (graph Laplacians,
+    shifted stencils): the entry stream carries one-byte indices, the diagonal is a dense vector.
+    Bit for bit the sequential CSR loop on short rows, the CSR read back unchanged; with packed
+    hot columns the diagonal entries keep their own column."""
+    from slepc_amd import ksgpu, matgen as mg
+    ctx = gpu_ctx
+    rng = np.random.default_rng(11)
+    # a 2-D stencil whose diagonal is replaced by random values: more than 256 distinct values
+    rp, ci, va = mg.laplacian2d(70, 61)
+    n = len(rp) - 1
+    rows = np.repeat(np.arange(n), np.diff(rp))
+    va = va.copy()
+    va[ci == rows] = rng.standard_normal(n) * 3.0
+    va[(ci != rows) & (rng.random(va.size) < 0.3)] = 0.25
+    x = rng.standard_normal(n)
+    xd, yd = ctx.vec_alloc(n), ctx.vec_alloc(n)
+    ctx.upload(xd, x)
+    A = ksgpu.DeviceCSR(ctx, rp, ci, va)
+    assert "the diagonal as a dense vector" in A.describe()
+    A.mult(xd, yd)
+    y = ctx.download(yd, n)
+    ref = np.zeros(n)
+    for r in range(n):
+        s = 0.0
+        for p in range(rp[r], rp[r + 1]):
+            s += va[p] * x[ci[p]]
+        ref[r] = s
+    assert np.array_equal(y, ref)
+    r2, c2, v2 = A.get_csr()
+    assert np.array_equal(c2, ci) and np.array_equal(v2.view(np.uint64), va.view(np.uint64))
+    assert abs(A.residual_norm(0.5, 0.0, xd) - np.linalg.norm(ref - 0.5 * x)) < 1e-12 * np.linalg.norm(ref)
+    A.destroy()
+    # the graph Laplacian of a power-law graph: -1 off the diagonal, degrees on it; grouped and
+    # long-row tiles, packed columns or not: the same bits as the operator with its values streamed
+    rp, ci, va = mg.rmat_laplacian(14, 8, seed=3)
+    n2 = len(rp) - 1
+    va = va.copy()
+    va[ci == np.repeat(np.arange(n2), np.diff(rp))] += rng.random(n2)      # a shifted Laplacian: every diagonal value its own
+    x2 = rng.standard_normal(n2)
+    x2d, y2d, z2d = ctx.vec_alloc(n2), ctx.vec_alloc(n2), ctx.vec_alloc(n2)
+    ctx.upload(x2d, x2)
+    ctx.set_option(ksgpu.OPT_HOT_COLS, hot)
+    L = ksgpu.DeviceCSR(ctx, rp, ci, va)
+    # the same matrix with one off-diagonal value perturbed in 300 places: no table fits, the values are streamed
+    vb = va.copy()
+    rows2 = np.repeat(np.arange(n2), np.diff(rp))
+    off = np.flatnonzero(ci != rows2)
+    pick = rng.choice(off, 300, replace=False)
+    vb[pick] = -1.0 - 1e-3 * np.arange(1, 301)
+    Lb = ksgpu.DeviceCSR(ctx, rp, ci, vb)
+    ctx.set_option(ksgpu.OPT_HOT_COLS, 1048576)
+    assert "the diagonal as a dense vector" in L.describe() and "8-byte stream" in Lb.describe()
+    assert (L.hot_columns() > 0) == (hot > 0)
+    L.mult(x2d, y2d)
+    yl = ctx.download(y2d, n2)
+    from scipy.sparse import csr_matrix
+    want = csr_matrix((va, ci, rp), shape=(n2, n2)) @ x2
+    assert np.abs(yl - want).max() <= 1e-13 * np.abs(want).max() * 10
+    # bit-equality of the two value paths where the values agree: rows none of whose entries was perturbed
+    Lb.mult(x2d, z2d)
+    yb = ctx.download(z2d, n2)
+    touched = np.zeros(n2, dtype=bool)
+    touched[rows2[pick]] = True
+    assert np.array_equal(yl[~touched], yb[~touched])
+    r3, c3, v3 = L.get_csr()
+    assert np.array_equal(c3, ci) and np.array_equal(v3, va)
+    for o in (L, Lb):
+        o.destroy()
+    for p in (xd, yd, x2d, y2d, z2d):
+        ctx.vec_free(p)
