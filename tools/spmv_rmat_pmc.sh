@@ -11,14 +11,20 @@ OUT=$R/gpurun_out/pmc_rmat$S
 mkdir -p $OUT
 export TMPDIR=/tmp KSG_RMAT_CACHE=1 KSG_SPMV_REPS=5
 cd /tmp
-timeout -k 10 600 python3 $R/tools/spmv_rmat.py $S $HOT > $OUT/plain.txt 2>&1
+timeout -k 10 ${KSG_PMC_PLAIN_TIMEOUT:-600} python3 $R/tools/spmv_rmat.py $S $HOT > $OUT/plain.txt 2>&1
 i=0
-for set in "TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum" "TCP_TOTAL_ACCESSES_sum TCP_PENDING_STALL_CYCLES_sum" \
-           "TCC_HIT_sum TCC_MISS_sum" "TCC_REQ_sum TCC_READ_sum" "FETCH_SIZE" "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum" \
-           "TA_BUSY_avr TA_ADDR_STALLED_BY_TC_CYCLES_sum" "SQ_WAVES SQ_INSTS_VMEM_RD SQ_WAIT_INST_ANY SQ_BUSY_CYCLES" \
-           "GRBM_GUI_ACTIVE" "TCP_TCC_READ_REQ_LATENCY_sum TCP_TA_TCP_STATE_READ_sum"; do
+# KSG_PMC_SHORT=1: two passes only (large scales, where every pass spends minutes setting the operator up)
+if [ -n "$KSG_PMC_SHORT" ]; then
+  SETS=("TCP_TCC_READ_REQ_sum TCC_EA0_RDREQ_sum TCC_HIT_sum TCC_MISS_sum" "FETCH_SIZE")
+else
+  SETS=("TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum" "TCP_TOTAL_ACCESSES_sum TCP_PENDING_STALL_CYCLES_sum"
+        "TCC_HIT_sum TCC_MISS_sum" "TCC_REQ_sum TCC_READ_sum" "FETCH_SIZE" "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum"
+        "TA_BUSY_avr TA_ADDR_STALLED_BY_TC_CYCLES_sum" "SQ_WAVES SQ_INSTS_VMEM_RD SQ_WAIT_INST_ANY SQ_BUSY_CYCLES"
+        "GRBM_GUI_ACTIVE" "TCP_TCC_READ_REQ_LATENCY_sum TCP_TA_TCP_STATE_READ_sum")
+fi
+for set in "${SETS[@]}"; do
   i=$((i+1))
-  timeout -s KILL 240 rocprofv3 --pmc $set -d $OUT -o pass$i --output-format csv -- python3 $R/tools/spmv_rmat.py $S $HOT > $OUT/pass$i.txt 2> $OUT/pass$i.err || echo "pass $i ($set) failed" >> $OUT/failed.txt
+  timeout -s KILL ${KSG_PMC_PASS_TIMEOUT:-240} rocprofv3 --pmc $set -d $OUT -o pass$i --output-format csv -- python3 $R/tools/spmv_rmat.py $S $HOT > $OUT/pass$i.txt 2> $OUT/pass$i.err || echo "pass $i ($set) failed" >> $OUT/failed.txt
 done
 cd $R
 python3 - "$OUT" "$S" <<'PY'
