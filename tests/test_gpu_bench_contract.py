@@ -88,6 +88,23 @@ def test_bench_starts_its_own_ranks_strong_scaling():
     assert d["value"] > 0
 
 
+def test_bench_eight_ranks_rehearsal():
+    """The rank count the scaling run ends at: eight rank processes started by bench.py itself,
+    sharing the one GPU of the test box over gloo, on a 64^3 grid (8 planes per rank, every inner
+    rank with two neighbours)."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "1", "--warmup", "1",
+                        "--grid", "64", "--transport", "gloo", "--share-device", "--no-kernel-timing"],
+                       cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=420,
+                       env={k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")})
+    assert r.returncode == 0, r.stderr.decode(errors="replace")[-3000:]
+    lines = [l for l in r.stdout.decode().splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1, r.stdout.decode()[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["scaling"] == "strong"
+    assert d["config"]["rows_per_gpu"] == 8 * 64 * 64 and "8 rank(s)" in d["config"]["partition"]
+    assert d["solver_state"]["restarts"] == 2 and d["value"] > 0
+
+
 def test_bench_refuses_a_transport_other_than_rccl():
     """No silent fallback: two ranks on one device cannot form an RCCL communicator, and the
     run must fail rather than print a line measured over host-staged collectives; asking for

@@ -11,7 +11,7 @@ from tests.dist_util import run_ranks
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("case,nev,ranks", [("lap2d", 6, 2), ("markov", 5, 2), ("lap3d", 5, 3), ("rmat", 4, 2)])
+@pytest.mark.parametrize("case,nev,ranks", [("lap2d", 6, 2), ("markov", 5, 2), ("lap3d", 5, 3), ("rmat", 4, 2), ("lap3d", 5, 8)])
 def test_ranks_match_single(case, nev, ranks):
     one = run_ranks("gpu", case, 1)
     many = run_ranks("gpu", case, ranks)
@@ -24,7 +24,7 @@ def test_ranks_match_single(case, nev, ranks):
     assert np.abs(s * x2 - x1).max() < 1e-6
 
 
-@pytest.mark.parametrize("case,ranks", [("rmat_nnz", 2), ("rmat_nnz", 3), ("rmat_cost", 3)])
+@pytest.mark.parametrize("case,ranks", [("rmat_nnz", 2), ("rmat_nnz", 3), ("rmat_cost", 3), ("rmat_nnz", 8)])
 def test_rmat_balanced_blocks_match_single(case, ranks):
     """The power-law operator split into row blocks balanced by entries (and by entries plus a
     cost per row): eigenvalues to 1e-10 of the single-rank run, and one product against the
