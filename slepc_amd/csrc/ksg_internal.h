@@ -117,6 +117,14 @@ struct ksg_csr_dev {
   int32_t dshift;    /* column index of row r's diagonal entry minus r (nvt == 2) */
   int64_t ntiles;
   int64_t n_stream, n_group, n_long;
+  /* row-code form (banded operators with few distinct (column - row, value) pairs and short
+   * rows -- stencils): one byte per entry naming the pair, stored by entry position across the
+   * rows (in one or two 8-byte words per row), and the two tables */
+  int pc_w;          /* longest row, 0: the block has no row-code form */
+  int pc_chunk;      /* consecutive 256-row blocks that go to the same XCD */
+  uint64_t *pc_words;  /* 1 or 2 words per row: byte 7 of the first is the row's length, the rest its codes */
+  int32_t *pc_off;   /* 256 column offsets */
+  double *pc_val;    /* 256 values */
 };
 
 struct ksg_mat_s {

@@ -393,6 +393,97 @@ __global__ __launch_bounds__(KSG_BLOCK) void k_gather(const double *__restrict__
   for (int64_t i = (int64_t)blockIdx.x * KSG_BLOCK + threadIdx.x; i < n; i += stride) out[i] = x[idx[i]];
 }
 
+/* ------------------------------------------------------------------------ */
+/* row-code kernel: stencils and other banded operators                        */
+/* ------------------------------------------------------------------------ */
+/* An operator whose entries take at most 256 distinct (column - row, value) pairs, with short
+ * rows, needs neither column indices nor values in its entry stream: one byte per entry names
+ * the pair.  One lane owns a row; a row's codes and its length travel in one 8-byte word (two
+ * for rows of 8 to 15 entries), the words of consecutive rows are consecutive, and entry k of 64
+ * consecutive rows gathers 64 consecutive x entries -- coalesced loads instead of the scattered
+ * gather of the tile kernel, no LDS staging.  The products are rounded one by one and added in storage order: the bits of
+ * the sequential CSR loop, like the tile kernel's one-lane-per-row path.
+ * Workgroup b takes the 256-row block xcd*C + j of its group of 8*C blocks (xcd = b % 8, the
+ * XCD a workgroup lands on under round-robin dispatch; j = (b / 8) % C): C consecutive blocks
+ * share an XCD, so the x lines that neighbouring grid lines have in common are fetched into one
+ * L2 instead of several.  C is chosen at creation from the operator's offsets. */
+#define KSG_PC_ROWS 256
+/* The codes of a row travel in NW 8-byte words (NW = 1: up to 7 entries, NW = 2: up to 15):
+ * byte 7 of the first word is the row's length, the other bytes are its codes in storage order;
+ * word j of row r is at words[j*nrows + r], so a wave reads 512 consecutive bytes per word. */
+template <int RES, int NW>
+__global__ __launch_bounds__(KSG_PC_ROWS) void k_spmv_rowcode(const uint64_t *__restrict__ words,
+                                                               const int32_t *__restrict__ otab, const double *__restrict__ vtab,
+                                                               int64_t nrows, int C, const double *__restrict__ x,
+                                                               double *__restrict__ y, double kr, double ki,
+                                                               const double *__restrict__ xi, double *__restrict__ partial) {
+#pragma clang fp contract(off)
+  constexpr int WT = 8 * NW - 1;
+  __shared__ int32_t so[256];
+  __shared__ double sv[256];
+  __shared__ double red[KSG_PC_ROWS / 64];
+  so[threadIdx.x] = otab[threadIdx.x];
+  sv[threadIdx.x] = vtab[threadIdx.x];
+  const int64_t b = blockIdx.x;
+  const int64_t per = 8 * (int64_t)C;
+  const int64_t within = b % per;
+  const int64_t rb = (b / per) * per + (within % 8) * C + within / 8;
+  const int64_t row = rb * KSG_PC_ROWS + threadIdx.x;
+  uint64_t w[NW];
+#pragma unroll
+  for (int j = 0; j < NW; j++) w[j] = row < nrows ? __builtin_nontemporal_load(words + (int64_t)j * nrows + row) : 0;
+  __syncthreads();
+  double acc = 0.0;
+  if (row < nrows) {
+    const int n_ = (int)(w[0] >> 56);
+    int c[WT];
+#pragma unroll
+    for (int k = 0; k < WT; k++) c[k] = k < 7 ? (int)((w[0] >> (8 * k)) & 255) : (int)((w[NW - 1] >> (8 * (k - 7))) & 255);
+    double xv[WT];
+#pragma unroll
+    for (int k = 0; k < WT; k++) xv[k] = (k < n_) ? x[row + so[c[k]]] : 0.0;
+#pragma unroll
+    for (int k = 0; k < WT; k++) fence_d(xv[k]);
+    double s = 0.0;
+#pragma unroll
+    for (int k = 0; k < WT; k++)
+      if (k < n_) { const double p = sv[c[k]] * xv[k]; s = s + p; }
+    if (RES) {
+      double r = fma(-kr, x[row], s);
+      if (xi) r = fma(ki, xi[row], r);
+      acc = r * r;
+    } else {
+      __builtin_nontemporal_store(s, &y[row]);
+    }
+  }
+  if (RES) {
+    acc = wave_sum_width(acc, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      double t = red[0];
+#pragma unroll
+      for (int w2 = 1; w2 < KSG_PC_ROWS / 64; w2++) t += red[w2];
+      partial[blockIdx.x] = t;
+    }
+  }
+}
+
+static inline int64_t rowcode_blocks(const ksg_csr_dev &D) {
+  const int64_t nb = (D.nrows + KSG_PC_ROWS - 1) / KSG_PC_ROWS, per = 8 * (int64_t)D.pc_chunk;
+  return (nb + per - 1) / per * per;              /* whole groups: the blocks past the last row do nothing */
+}
+
+template <int RES>
+static void launch_rowcode(hipStream_t st, const ksg_csr_dev &D, const double *x, double *y, double kr, double ki,
+                           const double *xi, double *partial) {
+  const dim3 grid((unsigned)rowcode_blocks(D)), block(KSG_PC_ROWS);
+#define KSG_RC(NW) hipLaunchKernelGGL((k_spmv_rowcode<RES, NW>), grid, block, 0, st, (const uint64_t *)D.pc_words, \
+                   (const int32_t *)D.pc_off, (const double *)D.pc_val, D.nrows, D.pc_chunk, x, y, kr, ki, xi, partial)
+  if (D.pc_w <= 7) KSG_RC(1); else KSG_RC(2);
+#undef KSG_RC
+}
+
 /* One launch of the tile kernel over the block D: xh != NULL selects the variant whose column
  * indices from nx on are slots of the packed array xh, D.nvt the one-byte value indices. */
 template <int RES>
@@ -580,6 +671,87 @@ static int csr_to_device(ksg_csr_dev *D, int64_t nrows, const int64_t *rowptr, c
   return KSG_OK;
 }
 
+/* Fraction of (row, offset) pairs whose x entry lies in a 256-row block that another XCD works
+ * on, when C consecutive blocks share an XCD (block i of a group of 8*C goes to XCD i / C). */
+static double cross_xcd_cost(const std::vector<int32_t> &offs, int C) {
+  const int64_t per = 8 * (int64_t)C;
+  double cost = 0.0;
+  for (size_t t = 0; t < offs.size(); t++) {
+    const int64_t o = offs[t];
+    if (o == 0) continue;
+    const int64_t ao = o < 0 ? -o : o;
+    /* a shift by ao rows moves a fraction f of a block's rows d+1 blocks on and the rest d blocks */
+    const int64_t d = ao / KSG_PC_ROWS;
+    const double f = (double)(ao % KSG_PC_ROWS) / KSG_PC_ROWS;
+    for (int part = 0; part < 2; part++) {
+      const int64_t dd = d + part;
+      const double wgt = part ? f : 1.0 - f;
+      if (wgt == 0.0) continue;
+      int64_t diff = 0;
+      for (int64_t i = 0; i < per; i++) if ((i / C) != (((i + dd) % per) / C)) diff++;
+      cost += wgt * (double)diff / (double)per;
+    }
+  }
+  return cost;
+}
+
+/* Builds the row-code form of a block if it has one: no packed columns, rows of at most 15
+ * entries with little padding, at most 256 distinct (column - row - shift, value) pairs. */
+static int rowcode_to_device(ksg_csr_dev *D, int64_t nrows, const int64_t *rowptr, const int32_t *colidx, const double *val,
+                             int64_t ncols) {
+  D->pc_w = 0;
+  const char *env = getenv("KSG_SPMV_ROWCODE");
+  if (env && env[0] == '0') return KSG_OK;
+  const int64_t nnz = rowptr[nrows];
+  if (nrows < 4096 || nnz < 4096) return KSG_OK;
+  int64_t w = 0;
+  for (int64_t r = 0; r < nrows; r++) w = std::max(w, rowptr[r + 1] - rowptr[r]);
+  if (w > 15 || (double)w * (double)nrows > 1.25 * (double)nnz) return KSG_OK;
+  const int nw = w <= 7 ? 1 : 2;
+  std::vector<uint64_t> words((size_t)nw * (size_t)nrows, 0);
+  std::vector<int32_t> otab;
+  std::vector<double> vtab;
+  struct slot { int64_t off; uint64_t bits; int code; };
+  std::vector<slot> ht(2048);
+  for (auto &e : ht) e.code = -1;
+  for (int64_t r = 0; r < nrows; r++) {
+    words[(size_t)r] |= (uint64_t)(rowptr[r + 1] - rowptr[r]) << 56;
+    for (int64_t p = rowptr[r], k = 0; p < rowptr[r + 1]; p++, k++) {
+      const int64_t off = (int64_t)colidx[p] - r;
+      uint64_t bits;
+      memcpy(&bits, &val[p], 8);
+      unsigned h = (unsigned)((((uint64_t)off * 0x9E3779B97F4A7C15ull) ^ (bits * 0xC2B2AE3D27D4EB4Full)) >> 53);
+      while (ht[h].code >= 0 && (ht[h].off != off || ht[h].bits != bits)) h = (h + 1) & 2047;
+      if (ht[h].code < 0) {
+        if (otab.size() == 256) return KSG_OK;               /* too many pairs: the tile kernel keeps the block */
+        ht[h].off = off; ht[h].bits = bits; ht[h].code = (int)otab.size();
+        otab.push_back((int32_t)off);
+        vtab.push_back(val[p]);
+      }
+      if (k < 7) words[(size_t)r] |= (uint64_t)ht[h].code << (8 * k);
+      else words[(size_t)nrows + (size_t)r] |= (uint64_t)ht[h].code << (8 * (k - 7));
+    }
+  }
+  (void)ncols;
+  /* consecutive blocks per XCD: the smallest chunk with the least x shared across XCDs */
+  int best = 1;
+  double bestc = cross_xcd_cost(otab, 1);
+  for (int C = 2; C <= 32; C *= 2) {
+    const double cst = cross_xcd_cost(otab, C);
+    if (cst < bestc - 1e-9) { bestc = cst; best = C; }
+  }
+  env = getenv("KSG_SPMV_ROWCODE_CHUNK");
+  if (env && atoi(env) > 0) best = atoi(env);
+  otab.resize(256, 0);
+  vtab.resize(256, 0.0);
+  KSG_CHK(upload(&D->pc_words, words.data(), words.size()));
+  KSG_CHK(upload(&D->pc_off, otab.data(), otab.size()));
+  KSG_CHK(upload(&D->pc_val, vtab.data(), vtab.size()));
+  D->pc_chunk = best;
+  D->pc_w = (int)w;
+  return KSG_OK;
+}
+
 /* Uploads one block whose column indices address a vector of `ncols` entries, after deciding
  * on the packing of its most referenced columns. */
 static int block_to_device(ksg_ctx c, ksg_csr_dev *D, int64_t ncols, int64_t nrows, const int64_t *rowptr, const int32_t *colidx,
@@ -599,7 +771,9 @@ static int block_to_device(ksg_ctx c, ksg_csr_dev *D, int64_t ncols, int64_t nro
     hipError_t e = hipMalloc(d_xhot, (size_t)*nhot * sizeof(double));
     if (e != hipSuccess) KSG_FAIL(KSG_ERR_MEM, "matrix upload: %zu bytes: %s", (size_t)*nhot * sizeof(double), hipGetErrorString(e));
   }
-  return csr_to_device(D, nrows, rowptr, *nhot ? relabeled.data() : colidx, val, has_diag ? colidx : NULL, dshift);
+  KSG_CHK(csr_to_device(D, nrows, rowptr, *nhot ? relabeled.data() : colidx, val, has_diag ? colidx : NULL, dshift));
+  if (has_diag && !*nhot && ncols == nrows) KSG_CHK(rowcode_to_device(D, nrows, rowptr, colidx, val, ncols));    /* x and y indexed alike */
+  return KSG_OK;
 }
 
 static int diag_to_device(ksg_mat A, int64_t nrows, const int64_t *rowptr, const int32_t *colidx, const double *val) {
@@ -620,6 +794,9 @@ static void csr_free(ksg_csr_dev *D) {
   if (D->vidx) hipFree(D->vidx);
   if (D->vtab) hipFree(D->vtab);
   if (D->dvals) hipFree(D->dvals);
+  if (D->pc_words) hipFree(D->pc_words);
+  if (D->pc_off) hipFree(D->pc_off);
+  if (D->pc_val) hipFree(D->pc_val);
   memset(D, 0, sizeof(*D));
 }
 
@@ -988,7 +1165,9 @@ static int mat_mult_raw(ksg_mat A, const double *x, double *y) {
     if (A->nsend)
       hipLaunchKernelGGL(k_gather, dim3(ksg_grid_for(A->nsend)), dim3(KSG_BLOCK), 0, c->comm_stream, x, A->d_send_idx, A->d_send, A->nsend);
   }
-  if (A->diag.ntiles) {
+  if (A->diag.pc_w) {
+    launch_rowcode<0>(c->stream, A->diag, x, y, 0.0, 0.0, NULL, NULL);
+  } else if (A->diag.ntiles) {
     if (A->nhot) hipLaunchKernelGGL(k_gather, dim3(ksg_grid_for(A->nhot)), dim3(KSG_BLOCK), 0, c->stream, x, A->d_hot_idx, A->d_xhot, A->nhot);
     launch_tiles<0>(c->stream, A->diag, x, y, 0.0, 0.0, NULL, NULL, A->nhot ? A->d_xhot : NULL, (int32_t)A->nc, NULL);
   } else if (A->n) {
@@ -1018,6 +1197,7 @@ static int mat_mult_raw(ksg_mat A, const double *x, double *y) {
  * its own entry stream, row tables and the read-modify-write of the rows it touches; the halo adds
  * the pack kernel (index, read, write) and the received entries. */
 static double block_stream_bytes(const ksg_csr_dev &D) {
+  if (D.pc_w) return (D.pc_w <= 7 ? 8.0 : 16.0) * (double)D.nrows + 3072.0;  /* the rows' code words */
   return (D.nvt ? 5.0 : 12.0) * (double)D.nnz + (D.nvt == 2 ? 8.0 * (double)D.nrows : 0.0) +
          2.0 * (double)(D.nrows + D.ntiles) + 12.0 * (double)(D.ntiles + 1);
 }
@@ -1043,7 +1223,14 @@ extern "C" int ksg_mat_traffic_model(ksg_mat A, double *executed, double *csr_mo
 
 extern "C" int ksg_mat_describe(ksg_mat A, char *buf, size_t len) {
   if (!A || !buf || !len) KSG_FAIL(KSG_ERR_ARG, "ksg_mat_describe: NULL argument");
-  int k = snprintf(buf, len, "row tiles of <= %d entries / %d rows: %lld one lane per row, %lld several lanes per row, %lld single long rows; "
+  int k;
+  if (A->diag.pc_w)
+    k = snprintf(buf, len, "row codes: one lane per row, one byte per entry naming its (column - row, value) pair out of at most 256, "
+                 "%d bytes of codes per row (rows of up to %d entries), %d consecutive 256-row blocks per XCD; values: in the pair table; "
+                 "packed hot columns: 0; ghost entries received per product: %lld", A->diag.pc_w <= 7 ? 8 : 16, A->diag.pc_w,
+                 A->diag.pc_chunk, (long long)A->nghost);
+  else
+  k = snprintf(buf, len, "row tiles of <= %d entries / %d rows: %lld one lane per row, %lld several lanes per row, %lld single long rows; "
            "2-byte row offsets; values: %s; packed hot columns: %lld; ghost entries received per product: %lld",
            KSG_TILE_NNZ, KSG_TILE_ROWS, (long long)A->diag.n_stream, (long long)A->diag.n_group, (long long)A->diag.n_long,
            A->diag.nvt == 2 ? "1-byte indices into a 255-entry table off the diagonal, the diagonal as a dense vector" :
@@ -1079,11 +1266,14 @@ extern "C" int ksg_mat_residual_norm(ksg_mat A, double kr, double ki, const doub
   KSG_CHK(ksg_op_begin(c, KSG_EV_MATMULT));
   int nb = 0;
   if (!halo) {
-    nb = (int)A->diag.ntiles;
+    nb = A->diag.pc_w ? (int)rowcode_blocks(A->diag) : (int)A->diag.ntiles;
     if (nb) {
       KSG_CHK(ksg_ensure_partial(c, (size_t)nb));
-      if (A->nhot) hipLaunchKernelGGL(k_gather, dim3(ksg_grid_for(A->nhot)), dim3(KSG_BLOCK), 0, c->stream, x, A->d_hot_idx, A->d_xhot, A->nhot);
-      launch_tiles<1>(c->stream, A->diag, x, NULL, kr, ki, xi, c->d_partial, A->nhot ? A->d_xhot : NULL, (int32_t)A->nc, NULL);
+      if (A->diag.pc_w) launch_rowcode<1>(c->stream, A->diag, x, NULL, kr, ki, xi, c->d_partial);
+      else {
+        if (A->nhot) hipLaunchKernelGGL(k_gather, dim3(ksg_grid_for(A->nhot)), dim3(KSG_BLOCK), 0, c->stream, x, A->d_hot_idx, A->d_xhot, A->nhot);
+        launch_tiles<1>(c->stream, A->diag, x, NULL, kr, ki, xi, c->d_partial, A->nhot ? A->d_xhot : NULL, (int32_t)A->nc, NULL);
+      }
     }
   } else {
     KSG_CHK(mat_mult_raw(A, x, work));

@@ -342,3 +342,65 @@ def test_value_table_with_dense_diagonal(gpu_ctx, hot):
         o.destroy()
     for p in (xd, yd, x2d, y2d, z2d):
         ctx.vec_free(p)
+
+
+@pytest.mark.parametrize("gen", ["lap1d", "lap2d", "lap3d", "band"])
+def test_row_code_kernel_equals_tile_kernel(gpu_ctx, gen):
+    """Stencils and other banded operators with few distinct (column - row, value) pairs are
+    multiplied by the row-code kernel (one byte per entry, coalesced x loads); the result is bit
+    for bit the tile kernel's and the sequential CSR loop's, whatever the XCD chunking; the
+    store-free residual agrees to rounding; operators without that form keep the tile kernel."""
+    import os
+    from slepc_amd import ksgpu, matgen as mg
+    ctx = gpu_ctx
+    rng = np.random.default_rng(21)
+    if gen == "band":
+        n = 20011
+        offs = np.array([-700, -7, -1, 0, 2, 9, 513])
+        pool = np.array([0.5, -1.25, 3.0, -0.0, 7.5])
+        rows, cols, vals = [], [], []
+        for r in range(n):
+            keep = offs[(r + offs >= 0) & (r + offs < n) & (rng.random(offs.size) < 0.92)]
+            rows += [r] * keep.size
+            cols += list(r + keep)
+            vals += list(pool[(r + keep) % pool.size])
+        counts = np.bincount(rows, minlength=n)
+        rp = np.concatenate(([0], np.cumsum(counts))).astype(np.int64)
+        ci, va = np.array(cols, dtype=np.int32), np.array(vals)
+    else:
+        rp, ci, va = {"lap1d": lambda: mg.laplacian1d(50021), "lap2d": lambda: mg.laplacian2d(301, 217),
+                      "lap3d": lambda: mg.laplacian3d(41, 37, 29)}[gen]()
+    n = len(rp) - 1
+    x = rng.standard_normal(n)
+    xd, yd = ctx.vec_alloc(n), ctx.vec_alloc(n)
+    ctx.upload(xd, x)
+    results = {}
+    for key, env in (("tiles", {"KSG_SPMV_ROWCODE": "0"}), ("codes", {}), ("codes_c8", {"KSG_SPMV_ROWCODE_CHUNK": "8"}),
+                     ("codes_c1", {"KSG_SPMV_ROWCODE_CHUNK": "1"})):
+        for k in ("KSG_SPMV_ROWCODE", "KSG_SPMV_ROWCODE_CHUNK"):
+            os.environ.pop(k, None)
+        os.environ.update(env)
+        A = ksgpu.DeviceCSR(ctx, rp, ci, va)
+        for k in env:
+            os.environ.pop(k, None)
+        assert ("row codes" in A.describe()) == (key != "tiles"), A.describe()
+        ctx.upload(yd, np.full(n, np.nan))
+        A.mult(xd, yd)
+        results[key] = (ctx.download(yd, n), A.residual_norm(1.5, 0.0, xd), A.traffic_model())
+        r2, c2, v2 = A.get_csr()
+        assert np.array_equal(c2, ci) and np.array_equal(v2.view(np.uint64), va.view(np.uint64))
+        A.destroy()
+    ref = og.csr_matvec_fast(rp, ci, va, x, np.zeros(n))
+    for key in ("codes", "codes_c8", "codes_c1"):
+        assert np.array_equal(results[key][0], ref)
+        assert abs(results[key][1] - results["tiles"][1]) <= 1e-13 * results["tiles"][1]
+        assert results[key][2][0] < results["tiles"][2][0]             # fewer bytes by the model, the same CSR figure
+        assert results[key][2][1] == results["tiles"][2][1]
+    if info_grouped := (np.abs(results["tiles"][0] - ref).max() > 0):
+        assert np.abs(results["tiles"][0] - ref).max() <= 1e-13 * np.abs(ref).max()
+    # a nonsymmetric chain with hundreds of distinct values has no row-code form
+    M = ksgpu.DeviceCSR(ctx, *mg.markov(120))
+    assert "row tiles" in M.describe()
+    M.destroy()
+    ctx.vec_free(xd)
+    ctx.vec_free(yd)
