@@ -424,7 +424,8 @@ def main():
                   key=lambda e: st[e]["ms"], default=None)
         roofline = None
         if dom:
-            kname = {"dotvec": "k_dotw", "multvec": "k_multvec_dot", "matmult": "k_spmv_tiles"}[dom]
+            kname = {"dotvec": "k_dotw", "multvec": "k_multvec_dot",
+                     "matmult": "k_spmv_rowcode" if spmv_variant.startswith("row codes") else "k_spmv_tiles"}[dom]
             ach = st[dom]["bytes"] / st[dom]["ms"] / 1e6
             per_launch = st[dom]["bytes"] / st[dom]["calls"]
             roofline = {"bound": "hbm", "kernel": kname,

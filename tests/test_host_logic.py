@@ -501,11 +501,13 @@ def test_pmc_traffic_file_layout():
     with open(os.path.join(root, "profiles", "pmc_traffic.json")) as f:
         pmc = json.load(f)
     assert pmc["workload"].startswith("ex2 2-D 5-point Laplacian 4096x4096")
-    for k in ("k_multvec_dot", "k_dotw", "k_spmv_tiles"):
-        # the SpMV moves less than the CSR model it is charged with (one-byte value indices and
-        # two-byte row offsets on this operator); the BV kernels move what the model says
-        lo = 0.4 if k == "k_spmv_tiles" else 0.9
-        assert lo < pmc["kernels"][k]["traffic_over_algorithmic"] < 1.2 and pmc["kernels"][k]["launches"] > 0
+    spmv = "k_spmv_rowcode" if "k_spmv_rowcode" in pmc["kernels"] else "k_spmv_tiles"
+    for k in ("k_multvec_dot", "k_dotw", spmv):
+        # the BV kernels move what the model says; the SpMV is charged with the bytes its variant
+        # streams, x counted once, and re-reads some x lines on top (the counters' factor two for
+        # wide streams overstates its narrow loads besides)
+        lo, hi = (0.4, 2.5) if k == spmv else (0.9, 1.2)
+        assert lo < pmc["kernels"][k]["traffic_over_algorithmic"] < hi and pmc["kernels"][k]["launches"] > 0
 
 
 def test_eps_target_changed_between_solves(be):

@@ -88,6 +88,8 @@ def main():
             line = json.loads(open(sys.argv[4]).read().strip().splitlines()[-1])
             names = {"dotvec": "k_dotw", "multvec": "k_multvec_dot", "matmult": "k_spmv_tiles",
                      "multinplace": "k_multinplace", "scale": "k_scale_cols"}
+            if "k_spmv_rowcode" in fetch:               # the operator has the row-code form: that kernel multiplies
+                names["matmult"] = "k_spmv_rowcode"
             for ev, kn in names.items():
                 if ev in line["kernels"]:
                     model[kn] = line["kernels"][ev]["GB"] * 1e9
