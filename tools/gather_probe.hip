@@ -47,6 +47,34 @@ __global__ __launch_bounds__(256) void k_gather(const int *__restrict__ idx, int
   if (acc == 1.2345e-300) out[0] = acc;      // keep the loads alive
 }
 
+// The index stream cut into 8 parts, part g consumed only by workgroups with blockIdx % 8 == g
+// (the workgroups of one XCD under round-robin dispatch): with the table laid out so that part
+// g's indices fall into its own eighth of the table, every XCD's L2 caches a different eighth.
+template <int U>
+__global__ __launch_bounds__(256) void k_gather_parts(const int *__restrict__ idx, int64_t npart, const double *__restrict__ x,
+                                                      double *__restrict__ out) {
+  const int g = blockIdx.x & 7;
+  const int64_t b = blockIdx.x >> 3, nb = gridDim.x >> 3;
+  const int *ip = idx + (int64_t)g * npart;
+  double acc = 0.0;
+  const int64_t stride = nb * 256 * U;
+  for (int64_t base = b * 256 * U + threadIdx.x; base < npart; base += stride) {
+    int ci[U];
+    double xv[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) { const int64_t p = base + (int64_t)u * 256; ci[u] = p < npart ? __builtin_nontemporal_load(ip + p) : 0; }
+#pragma unroll
+    for (int u = 0; u < U; u++) fence_i(ci[u]);
+#pragma unroll
+    for (int u = 0; u < U; u++) xv[u] = x[ci[u]];
+#pragma unroll
+    for (int u = 0; u < U; u++) fence_d(xv[u]);
+#pragma unroll
+    for (int u = 0; u < U; u++) acc += xv[u];
+  }
+  if (acc == 1.2345e-300) out[0] = acc;
+}
+
 static uint64_t rng_state = 88172645463325252ull;
 static inline uint64_t rnd() { rng_state ^= rng_state << 13; rng_state ^= rng_state >> 7; rng_state ^= rng_state << 17; return rng_state; }
 
@@ -110,6 +138,45 @@ int main(int argc, char **argv) {
       printf("%-34s %10.1f %10.1f %10.1f %10.1f\n", name, rate[0], rate[1], rate[2], rate[3]);
       fflush(stdout);
     }
+  }
+  // power-law stream, table ordered by popularity, then dealt to 8 groups by rank (rank r -> group r % 8,
+  // slot r / 8 of the group's eighth of the table): all workgroups on everything, against XCD g on group g only
+  printf("%-34s %10s %10s\n", "powerlaw dealt to 8 groups", "all XCDs", "XCD=group");
+  for (int64_t tab : {(int64_t)8388608, (int64_t)67108864}) {
+    int bits = 0; while (((int64_t)1 << bits) < tab) bits++;
+    std::vector<int> rank((size_t)tab);
+    std::vector<int64_t> start(bits + 2, 0);
+    for (int64_t v = 0; v < tab; v++) start[__builtin_popcountll(v) + 1]++;
+    for (int b = 0; b <= bits; b++) start[b + 1] += start[b];
+    for (int64_t v = 0; v < tab; v++) rank[(size_t)v] = (int)start[__builtin_popcountll(v)]++;
+    const int64_t npart = n / 8;
+    std::vector<int64_t> fill(8, 0);
+    std::vector<int> hp((size_t)n, 0);
+    int64_t placed = 0;
+    while (placed < 8 * npart) {
+      int v = 0; uint64_t r = 0;
+      for (int b = 0; b < bits; b++) { if (b % 10 == 0) r = rnd(); v = (v << 1) | ((r & 63) < 15 ? 1 : 0); r >>= 6; }
+      const int rk = rank[(size_t)v], g = rk & 7;
+      if (fill[g] >= npart) continue;
+      hp[(size_t)(g * npart + fill[g]++)] = (int)(g * (tab / 8) + (rk >> 3));
+      placed++;
+    }
+    CHECK(hipMemcpy(d_idx, hp.data(), n * sizeof(int), hipMemcpyHostToDevice));
+    double rate[2] = {0, 0};
+    for (int v = 0; v < 2; v++)
+      for (int rep = 0; rep < 3; rep++) {
+        CHECK(hipEventRecord(e0, 0));
+        if (v == 0) hipLaunchKernelGGL((k_gather<0, 8>), dim3(2048), dim3(256), 0, 0, d_idx, 8 * npart, d_x, d_out, 0);
+        else hipLaunchKernelGGL((k_gather_parts<8>), dim3(2048), dim3(256), 0, 0, d_idx, npart, d_x, d_out);
+        CHECK(hipEventRecord(e1, 0));
+        CHECK(hipEventSynchronize(e1));
+        float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
+        if (rep) rate[v] = rate[v] > 8 * npart / (ms * 1e6) ? rate[v] : 8 * npart / (ms * 1e6);
+      }
+    char name[64];
+    snprintf(name, sizeof name, "powerlaw %7.2f MB", tab * 8 / 1048576.0);
+    printf("%-34s %10.1f %10.1f\n", name, rate[0], rate[1]);
+    fflush(stdout);
   }
   return 0;
 }
