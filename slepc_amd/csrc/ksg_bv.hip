@@ -570,6 +570,161 @@ static int mip_panel(ksg_ctx c, const double *Vin, int64_t ld, int K, const doub
 
 static inline int mip_width(int ne) { return ne <= 8 ? 8 : ne <= 16 ? 16 : ne <= 32 ? 32 : 64; }
 
+/* The same product on the matrix cores, for K <= 64 input columns, at most 64 output columns
+ * and 16-byte aligned panels.  A wave owns 64 rows.  It first requests all K input values of
+ * those rows (up to sixteen 32-byte reads per lane, all in flight together) and only then
+ * multiplies and stores, so the product can be formed in place whatever the output width, with
+ * no scratch copy.  One v_mfma_f64_16x16x4 instruction forms, for 16 output columns and 4 input
+ * columns, a 16 (output column) x 16 (row) tile of the transposed result: operand A is a block
+ * of the coefficient panel (read from LDS), operand B four input columns of 16 rows.  Which 16
+ * rows a tile stands for is free: tiles 2u and 2u + 1 take rows 32u + 2j and 32u + 2j + 1 of the
+ * wave's 64 (j = lane & 15), so that a 16-byte request per lane covers 256 contiguous bytes of
+ * each of four columns.  Measured at 16.7 M rows, 64 input columns: 2.86 / 3.51 / 4.12 ms for
+ * 32 / 48 / 64 output columns, against 2.62 / 5.57 / 6.87 ms of the vector kernel above (its
+ * two wider cases through a scratch panel): this kernel serves results wider than 32 columns.
+ * Two waves per SIMD hide each other's loads; a single wave that requests its next tile before
+ * it multiplies (twice the registers) measured 4.2 ms at 64 x 32, and 32-row tiles, whose two
+ * accumulator chains leave the matrix core waiting for its own results, 4.0 ms.
+ * Bq is the K x E row-major panel, E a multiple of 16, zero padded. */
+typedef double ksg_d4 __attribute__((ext_vector_type(4)));
+#define KSG_MIPM_KMAX 64
+/* The input values of one 64-row tile: xv[ks][t] = Vin(row of tile t, column 4 ks + kq).  NKS: slices
+ * of 4 input columns the code is unrolled for (slices past K hold zeros and are not read); FULL:
+ * all rows of the tile exist. */
+template <int NKS, bool FULL>
+__device__ __forceinline__ void mipm_load(double (&xv)[NKS][4], const double *__restrict__ Vin, int64_t ld, int K,
+                                          int64_t n, int64_t r, int kq) {
+#pragma unroll
+  for (int ks = 0; ks < NKS; ks++) {
+    const int col = 4 * ks + kq;
+    const bool cin = col < K;                          /* columns past K enter as zeros */
+    const double *p = Vin + (int64_t)(cin ? col : K - 1) * ld + r;
+    if (4 * ks < K) {                                  /* wave-uniform */
+      if (FULL) {
+        const double2 a = *reinterpret_cast<const double2 *>(p), b = *reinterpret_cast<const double2 *>(p + 32);
+        xv[ks][0] = cin ? a.x : 0.0; xv[ks][1] = cin ? a.y : 0.0;
+        xv[ks][2] = cin ? b.x : 0.0; xv[ks][3] = cin ? b.y : 0.0;
+      } else {
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+          const int dr = 16 * (t & ~1) + (t & 1);
+          xv[ks][t] = (cin && r + dr < n) ? p[dr] : 0.0;
+        }
+      }
+    } else {
+#pragma unroll
+      for (int t = 0; t < 4; t++) xv[ks][t] = 0.0;
+    }
+  }
+}
+
+/* Products and stores of one tile whose input values are in xv. */
+template <int NKS, bool FULL>
+__device__ __forceinline__ void mipm_multiply(const double (&xv)[NKS][4], const double *Bs, int E, int nct,
+                                              double *__restrict__ Vout, int64_t ldo, int ne, int64_t n,
+                                              double beta, int64_t r, int j, int kq) {
+#pragma unroll 1
+  for (int ct = 0; ct < nct; ct++) {
+    ksg_d4 acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; t++) acc[t] = (ksg_d4){0.0, 0.0, 0.0, 0.0};
+    const double *bp = Bs + kq * E + 16 * ct + j;
+#pragma unroll
+    for (int ks = 0; ks < NKS; ks++) {
+      const double a = bp[4 * ks * E];
+#pragma unroll
+      for (int t = 0; t < 4; t++) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, xv[ks][t], acc[t], 0, 0, 0);
+    }
+    /* element v of tile t: output column 16 ct + kq + 4 v, row r + 16 (t & ~1) + (t & 1) */
+#pragma unroll
+    for (int v = 0; v < 4; v++) {
+      const int oc = 16 * ct + kq + 4 * v;
+      if (oc < ne) {
+        double *o = Vout + (int64_t)oc * ldo + r;
+        if (FULL) {
+#pragma unroll
+          for (int t = 0; t < 4; t += 2) {
+            double2 w = make_double2(acc[t][v], acc[t + 1][v]);
+            if (beta != 0.0) {
+              const double2 old = *reinterpret_cast<const double2 *>(o + 16 * t);
+              w.x = fma(beta, old.x, w.x); w.y = fma(beta, old.y, w.y);
+            }
+            *reinterpret_cast<double2 *>(o + 16 * t) = w;
+          }
+        } else {
+#pragma unroll
+          for (int t = 0; t < 4; t++) {
+            const int dr = 16 * (t & ~1) + (t & 1);
+            if (r + dr < n) o[dr] = (beta != 0.0) ? fma(beta, o[dr], acc[t][v]) : acc[t][v];
+          }
+        }
+      }
+    }
+  }
+}
+
+template <int NKS>
+__global__ __launch_bounds__(256, 2) void k_mip_mfma(const double *__restrict__ Vin, int64_t ld, int K,
+                                                      const double *__restrict__ Bq, int E,
+                                                      double *__restrict__ Vout, int64_t ldo, int ne,
+                                                      int64_t n, double beta) {
+  __shared__ double Bs[KSG_MIPM_KMAX * 64];
+  for (int t = threadIdx.x; t < 4 * NKS * E; t += 256) Bs[t] = t < K * E ? Bq[t] : 0.0;
+  __syncthreads();                                     /* the only barrier: waves run on their own from here */
+  const int lane = threadIdx.x & 63;
+  const int j = lane & 15, kq = lane >> 4;
+  const int nct = E >> 4;
+  const int64_t ntiles = (n + 63) >> 6, nfull = n >> 6;
+  const int64_t nwaves = (int64_t)gridDim.x * 4;
+  double xv[NKS][4];
+  for (int64_t tile = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); tile < ntiles; tile += nwaves) {
+    /* a lane's rows: r, r + 1 (tiles 0, 1) and r + 32, r + 33 (tiles 2, 3) of the wave's 64, so that
+     * the 16 lanes of a column group read 256 contiguous bytes per request */
+    const int64_t r = (tile << 6) + 2 * j;
+    if (tile < nfull) {
+      mipm_load<NKS, true>(xv, Vin, ld, K, n, r, kq);
+      mipm_multiply<NKS, true>(xv, Bs, E, nct, Vout, ldo, ne, n, beta, r, j, kq);
+    } else {
+      mipm_load<NKS, false>(xv, Vin, ld, K, n, r, kq);
+      mipm_multiply<NKS, false>(xv, Bs, E, nct, Vout, ldo, ne, n, beta, r, j, kq);
+    }
+  }
+}
+
+static int g_mip_grid = 0;   /* workgroups of k_mip_mfma (KSG_MIP_GRID) */
+static bool mip_mfma_enabled() {
+  static int on = -1;
+  if (on < 0) {
+    const char *e = getenv("KSG_MIP_VALU");
+    on = (e && e[0] == '1') ? 0 : 1;
+    const char *g = getenv("KSG_MIP_GRID");
+    g_mip_grid = g ? atoi(g) : 0;
+    if (g_mip_grid < 1) g_mip_grid = 1024;
+  }
+  return on == 1;
+}
+static inline bool mip_mfma_fits(const double *Vin, int64_t ld, int K, const double *Vout, int64_t ldo) {
+  return K >= 1 && K <= KSG_MIPM_KMAX && aligned16(Vin) && aligned16(Vout) && (ld % 2 == 0) && (ldo % 2 == 0) &&
+         mip_mfma_enabled();
+}
+/* out(:,0:ne) = beta*out + Vin(:,0:K) * B on the matrix cores; ne <= 64, Bq the K x E panel, E = 16*ceil(ne/16) */
+static int mip_panel_mfma(ksg_ctx c, const double *Vin, int64_t ld, int K, const double *Bq, int E, double *Vout,
+                          int64_t ldo, int ne, int64_t n, double beta) {
+  const int64_t nwg = ((n + 63) / 64 + 3) / 4;
+  const dim3 grid((unsigned)(nwg > g_mip_grid ? g_mip_grid : nwg)), block(256);
+#define KSG_MIPM_CASE(NKS) \
+  hipLaunchKernelGGL((k_mip_mfma<NKS>), grid, block, 0, c->stream, Vin, ld, K, Bq, E, Vout, ldo, ne, n, beta); break;
+  switch ((K + 15) / 16) {
+    case 1:  KSG_MIPM_CASE(4)
+    case 2:  KSG_MIPM_CASE(8)
+    case 3:  KSG_MIPM_CASE(12)
+    default: KSG_MIPM_CASE(16)
+  }
+#undef KSG_MIPM_CASE
+  KSG_HIP(hipGetLastError());
+  return KSG_OK;
+}
+
 /* ------------------------------------------------------------------------ */
 /* element-wise kernels over a block of columns                               */
 /* ------------------------------------------------------------------------ */
@@ -745,7 +900,6 @@ __global__ __launch_bounds__(256) void k_gram(const double *__restrict__ Y, int6
  * row (lane >> 4) + 4 v, column lane & 15 in element v.
  * sym: X and Y are the same panel (M is symmetric): blocks and tiles below the diagonal are
  * left out and filled in by the caller. */
-typedef double ksg_d4 __attribute__((ext_vector_type(4)));
 
 /* M(i,j) = M(j,i) for i > j, M k x k column-major */
 __global__ __launch_bounds__(KSG_BLOCK) void k_mirror_upper(double *__restrict__ M, int k) {
@@ -1303,8 +1457,30 @@ template <class F>
 static int mip_general(ksg_ctx c, const double *Vin, int64_t ld, int K, int ne, F coef, double *Vout,
                        int64_t ldo, int64_t n, bool inplace_overlap, double beta = 0.0) {
   if (ne <= 0 || n <= 0) return KSG_OK;
+  if (ne > 32 && mip_mfma_fits(Vin, ld, K, Vout, ldo) && (ne <= 64 || !inplace_overlap)) {
+    /* more than 32 output columns: the matrix-core kernel, in panels of up to 64 columns; a single
+     * panel may overwrite its own input columns */
+    const int npan = (ne + 63) / 64;
+    const int E = npan == 1 ? (ne + 15) / 16 * 16 : 64;
+    KSG_CHK(ksg_ensure_q(c, (size_t)K * E * npan));
+    KSG_HIP(hipStreamSynchronize(c->stream));               /* the staging buffer may still be in use */
+    KSG_CHK(ensure_hq(c, (size_t)K * E * npan));
+    for (int pnl = 0; pnl < npan; pnl++) {
+      const int w = (ne - pnl * 64 < 64) ? ne - pnl * 64 : 64;
+      double *h = c->h_q + (size_t)pnl * K * E;
+      for (int i = 0; i < K; i++)
+        for (int e = 0; e < E; e++) h[(size_t)i * E + e] = e < w ? coef(i, pnl * 64 + e) : 0.0;
+    }
+    KSG_HIP(hipMemcpyAsync(c->d_q, c->h_q, (size_t)K * E * npan * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    for (int pnl = 0; pnl < npan; pnl++) {
+      const int w = (ne - pnl * 64 < 64) ? ne - pnl * 64 : 64;
+      KSG_CHK(mip_panel_mfma(c, Vin, ld, K, c->d_q + (size_t)pnl * K * E, E, Vout + (int64_t)pnl * 64 * ldo, ldo, w, n, beta));
+    }
+    return KSG_OK;
+  }
   if (inplace_overlap && ne > 32 && ne <= 64 && beta == 0.0) {
-    /* 33..64 output columns in place: the kernel that holds 64 outputs per row in registers
+    /* 33..64 output columns in place where the matrix-core kernel does not apply (more than 64
+     * input columns, unaligned panels): the kernel that holds 64 outputs per row in registers
      * is slow (one row per thread, 8-byte loads), so the result is formed as two panels of
      * at most 32 columns with the fast kernel: the second panel goes to scratch first (the
      * first panel's columns are among its inputs), then the first panel is written in place,

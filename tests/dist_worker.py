@@ -17,6 +17,17 @@ import numpy as np  # noqa: E402
 
 
 def main():
+    """Runs the case, then leaves the process group in order: a rank that exits with gloo's
+    worker threads still alive can die in their destructors (std::terminate) after its work is done."""
+    try:
+        run()
+    finally:
+        import torch.distributed as td
+        if td.is_available() and td.is_initialized():
+            td.destroy_process_group()
+
+
+def run():
     mode, case, out = sys.argv[1], sys.argv[2], sys.argv[3]
     hot_limit = None
     from slepc_amd import dist as kdist, kseps as K, matgen as mg

@@ -71,7 +71,11 @@ def test_multvec(gpu_ctx, n, m, l, k, alpha, beta):
 
 
 @pytest.mark.parametrize("n,m,l,k,s,e", [(1000, 5, 0, 5, 1, 3), (4097, 65, 0, 64, 0, 33), (100001, 65, 10, 64, 10, 40),
-                                          (33, 80, 0, 80, 0, 80), (2, 9, 2, 8, 3, 8), (5000, 150, 5, 140, 5, 100)])
+                                          (33, 80, 0, 80, 0, 80), (2, 9, 2, 8, 3, 8), (5000, 150, 5, 140, 5, 100),
+                                          # one launch of the matrix-core kernel, in place: 33..64 output columns,
+                                          # input widths that are no multiple of 4, row counts that leave ragged tiles
+                                          (100003, 65, 0, 64, 0, 64), (70001, 66, 1, 64, 1, 50), (4160, 40, 3, 38, 3, 38),
+                                          (131, 64, 0, 61, 0, 47), (64, 20, 0, 17, 2, 17), (1, 7, 0, 7, 0, 7)])
 @pytest.mark.parametrize("trans", [False, True])
 def test_multinplace(gpu_ctx, n, m, l, k, s, e, trans):
     G, O, rng = _mk(gpu_ctx, n, m, seed=2)

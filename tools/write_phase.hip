@@ -86,6 +86,34 @@ __global__ __launch_bounds__(256) void k_phased(const double *__restrict__ X, in
   }
 }
 
+// D: no barrier: every workgroup computes the results of its chunk of rows (R row pairs per thread, in
+// registers) and stores them in one burst when it is done
+template <int R>
+__global__ __launch_bounds__(256) void k_burst(const double *__restrict__ X, int64_t ld, int K, qarg q, double beta,
+                                               double *__restrict__ y, int64_t n) {
+  const double2 *X2 = reinterpret_cast<const double2 *>(X);
+  double2 *y2 = reinterpret_cast<double2 *>(y);
+  const int64_t npair = n >> 1;
+  const int64_t base = (int64_t)blockIdx.x * 256 * R + threadIdx.x;
+  double2 res[R];
+#pragma unroll
+  for (int i = 0; i < R; i++) {
+    const int64_t p = base + (int64_t)i * 256;
+    res[i] = make_double2(0.0, 0.0);
+    if (p < npair) {
+      const double2 yv = y2[p];
+      double2 a = row_sum(X2, ld >> 1, K, q, p);
+      res[i].x = fma(beta, yv.x, a.x); res[i].y = fma(beta, yv.y, a.y);
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < R; i++) {
+    const int64_t p = base + (int64_t)i * 256;
+    if (p < npair) y2[p] = res[i];
+  }
+}
+
 int main(int argc, char **argv) {
   const int64_t n = argc > 1 ? atoll(argv[1]) : 16777216;
   const int K = argc > 2 ? atoi(argv[2]) : 48;
@@ -117,6 +145,14 @@ int main(int argc, char **argv) {
     time(nm, bytes_rd + bytes_wr, [&] { hipLaunchKernelGGL((k_direct<1>), dim3(grid), dim3(256), 0, 0, X, ld, K, q, 1.0, y, n, sink); });
     snprintf(nm, sizeof nm, "B non-temporal store, grid %d", grid);
     time(nm, bytes_rd + bytes_wr, [&] { hipLaunchKernelGGL((k_direct<2>), dim3(grid), dim3(256), 0, 0, X, ld, K, q, 1.0, y, n, sink); });
+  }
+  {
+    const int64_t npair = n >> 1;
+    char nm[96];
+#define BURST(R) snprintf(nm, sizeof nm, "D burst of %d KiB per workgroup, no barrier", 256 * R * 16 / 1024); \
+    time(nm, bytes_rd + bytes_wr, [&] { hipLaunchKernelGGL((k_burst<R>), dim3((unsigned)((npair + 256 * R - 1) / (256 * R))), dim3(256), 0, 0, X, ld, K, q, 1.0, y, n); });
+    BURST(4) BURST(8) BURST(16) BURST(32) BURST(48)
+#undef BURST
   }
   int dev = 0, ncu = 0;
   CHECK(hipGetDevice(&dev));
