@@ -1071,7 +1071,12 @@ extern "C" int ksg_bv_create(ksg_ctx ctx, int64_t n, int64_t N, int m, ksg_bv *o
   ksg_bv bv = new (std::nothrow) ksg_bv_s();
   if (!bv) KSG_FAIL(KSG_ERR_MEM, "ksg_bv_create: out of host memory");
   bv->ctx = ctx; bv->n = n; bv->N = N; bv->m = m; bv->nc = 0; bv->l = 0; bv->k = m;
-  bv->ld = ((n + 31) / 32) * 32;
+  /* column stride: the row count rounded up to 32 doubles; from 8 M rows on to 2^20 doubles (8 MiB), so
+   * that every column starts at the same offset of the memory system's interleaving -- measured at 16.0 M
+   * rows: 100.8 ms per restart against 102.5 ms (strides rounded to 2^12 or 2^16 doubles: 104.1, 102.9) */
+  int64_t align = n >= ((int64_t)1 << 23) ? ((int64_t)1 << 20) : 32;
+  { const char *pe = getenv("KSG_BV_ALIGN"); if (pe && atoll(pe) >= 32) align = atoll(pe) / 32 * 32; }
+  bv->ld = (n + align - 1) / align * align;
   if (bv->ld == 0) bv->ld = 32;
   const size_t bytes = (size_t)bv->ld * m * sizeof(double);
   hipError_t e = hipMalloc(&bv->d, bytes);
