@@ -414,7 +414,7 @@ __global__ __launch_bounds__(KSG_BLOCK) void k_gather(const double *__restrict__
 template <int RES, int NW>
 __global__ __launch_bounds__(KSG_PC_ROWS) void k_spmv_rowcode(const uint64_t *__restrict__ words,
                                                                const int32_t *__restrict__ otab, const double *__restrict__ vtab,
-                                                               int64_t nrows, int C, const double *__restrict__ x,
+                                                               int64_t nrows, int64_t nblocks, int C, const double *__restrict__ x,
                                                                double *__restrict__ y, double kr, double ki,
                                                                const double *__restrict__ xi, double *__restrict__ partial) {
 #pragma clang fp contract(off)
@@ -424,36 +424,39 @@ __global__ __launch_bounds__(KSG_PC_ROWS) void k_spmv_rowcode(const uint64_t *__
   __shared__ double red[KSG_PC_ROWS / 64];
   so[threadIdx.x] = otab[threadIdx.x];
   sv[threadIdx.x] = vtab[threadIdx.x];
-  const int64_t b = blockIdx.x;
   const int64_t per = 8 * (int64_t)C;
-  const int64_t within = b % per;
-  const int64_t rb = (b / per) * per + (within % 8) * C + within / 8;
-  const int64_t row = rb * KSG_PC_ROWS + threadIdx.x;
-  uint64_t w[NW];
-#pragma unroll
-  for (int j = 0; j < NW; j++) w[j] = row < nrows ? __builtin_nontemporal_load(words + (int64_t)j * nrows + row) : 0;
   __syncthreads();
   double acc = 0.0;
-  if (row < nrows) {
-    const int n_ = (int)(w[0] >> 56);
-    int c[WT];
+  /* a workgroup walks the blocks b, b + grid, ...: the grid is a multiple of 8 C, so all its blocks
+   * have the same place in their group and the two tables are staged once */
+  for (int64_t b = blockIdx.x; b < nblocks; b += gridDim.x) {
+    const int64_t within = b % per;
+    const int64_t rb = (b / per) * per + (within % 8) * C + within / 8;
+    const int64_t row = rb * KSG_PC_ROWS + threadIdx.x;
+    if (row < nrows) {
+      uint64_t w[NW];
 #pragma unroll
-    for (int k = 0; k < WT; k++) c[k] = k < 7 ? (int)((w[0] >> (8 * k)) & 255) : (int)((w[NW - 1] >> (8 * (k - 7))) & 255);
-    double xv[WT];
+      for (int j = 0; j < NW; j++) w[j] = __builtin_nontemporal_load(words + (int64_t)j * nrows + row);
+      const int n_ = (int)(w[0] >> 56);
+      int c[WT];
 #pragma unroll
-    for (int k = 0; k < WT; k++) xv[k] = (k < n_) ? x[row + so[c[k]]] : 0.0;
+      for (int k = 0; k < WT; k++) c[k] = k < 7 ? (int)((w[0] >> (8 * k)) & 255) : (int)((w[NW - 1] >> (8 * (k - 7))) & 255);
+      double xv[WT];
 #pragma unroll
-    for (int k = 0; k < WT; k++) fence_d(xv[k]);
-    double s = 0.0;
+      for (int k = 0; k < WT; k++) xv[k] = (k < n_) ? x[row + so[c[k]]] : 0.0;
 #pragma unroll
-    for (int k = 0; k < WT; k++)
-      if (k < n_) { const double p = sv[c[k]] * xv[k]; s = s + p; }
-    if (RES) {
-      double r = fma(-kr, x[row], s);
-      if (xi) r = fma(ki, xi[row], r);
-      acc = r * r;
-    } else {
-      __builtin_nontemporal_store(s, &y[row]);
+      for (int k = 0; k < WT; k++) fence_d(xv[k]);
+      double s = 0.0;
+#pragma unroll
+      for (int k = 0; k < WT; k++)
+        if (k < n_) { const double p = sv[c[k]] * xv[k]; s = s + p; }
+      if (RES) {
+        double r = fma(-kr, x[row], s);
+        if (xi) r = fma(ki, xi[row], r);
+        acc = fma(r, r, acc);
+      } else {
+        __builtin_nontemporal_store(s, &y[row]);
+      }
     }
   }
   if (RES) {
@@ -473,13 +476,22 @@ static inline int64_t rowcode_blocks(const ksg_csr_dev &D) {
   const int64_t nb = (D.nrows + KSG_PC_ROWS - 1) / KSG_PC_ROWS, per = 8 * (int64_t)D.pc_chunk;
   return (nb + per - 1) / per * per;              /* whole groups: the blocks past the last row do nothing */
 }
+/* workgroups of a launch: whole groups of 8 C, at most KSG_RC_GRID (default 16384: 4096^2 0.107 -> 0.097 ms, 512^3 0.965 -> 0.924 ms per product) */
+static inline int64_t rowcode_grid(const ksg_csr_dev &D) {
+  static int64_t cap = 0;
+  if (!cap) { const char *e = getenv("KSG_RC_GRID"); cap = e ? atoll(e) : 0; if (cap < 8) cap = 16384; }
+  const int64_t nb = rowcode_blocks(D), per = 8 * (int64_t)D.pc_chunk;
+  int64_t g = cap / per * per;
+  if (g < per) g = per;
+  return nb < g ? nb : g;
+}
 
 template <int RES>
 static void launch_rowcode(hipStream_t st, const ksg_csr_dev &D, const double *x, double *y, double kr, double ki,
                            const double *xi, double *partial) {
-  const dim3 grid((unsigned)rowcode_blocks(D)), block(KSG_PC_ROWS);
+  const dim3 grid((unsigned)rowcode_grid(D)), block(KSG_PC_ROWS);
 #define KSG_RC(NW) hipLaunchKernelGGL((k_spmv_rowcode<RES, NW>), grid, block, 0, st, (const uint64_t *)D.pc_words, \
-                   (const int32_t *)D.pc_off, (const double *)D.pc_val, D.nrows, D.pc_chunk, x, y, kr, ki, xi, partial)
+                   (const int32_t *)D.pc_off, (const double *)D.pc_val, D.nrows, rowcode_blocks(D), D.pc_chunk, x, y, kr, ki, xi, partial)
   if (D.pc_w <= 7) KSG_RC(1); else KSG_RC(2);
 #undef KSG_RC
 }
@@ -1266,7 +1278,7 @@ extern "C" int ksg_mat_residual_norm(ksg_mat A, double kr, double ki, const doub
   KSG_CHK(ksg_op_begin(c, KSG_EV_MATMULT));
   int nb = 0;
   if (!halo) {
-    nb = A->diag.pc_w ? (int)rowcode_blocks(A->diag) : (int)A->diag.ntiles;
+    nb = A->diag.pc_w ? (int)rowcode_grid(A->diag) : (int)A->diag.ntiles;
     if (nb) {
       KSG_CHK(ksg_ensure_partial(c, (size_t)nb));
       if (A->diag.pc_w) launch_rowcode<1>(c->stream, A->diag, x, NULL, kr, ki, xi, c->d_partial);
