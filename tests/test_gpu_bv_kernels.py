@@ -347,6 +347,12 @@ def test_lazy_update_flush_paths(gpu_ctx):
     (1001, 9, 33, 1, 9, 2, 33, 2.0, -1.0),
     (2, 3, 2, 0, 3, 0, 2, 1.0, 0.5),
     (5000, 8, 8, 2, 2, 0, 8, 1.0, 0.0),              # no active columns of X: Y = beta*Y
+    # the matrix-core product out of place: 33..64 output columns with and without beta, ragged
+    # input widths and row tiles, and two panels of it (at most 64 input, more than 64 output columns)
+    (20011, 64, 64, 0, 64, 0, 64, 1.0, 0.0),
+    (4133, 40, 50, 3, 40, 1, 49, -1.5, 0.75),
+    (10000, 30, 150, 0, 30, 0, 150, 1.0, -1.0),
+    (65, 64, 100, 0, 61, 10, 100, 2.0, 0.0),
 ])
 def test_bv_mult_dot_block_kernels(gpu_ctx, n, mx, my, lx, kx, ly, ky, alpha, beta):
     """BVMult / BVDot through the block kernels (restart kernel out of place with beta,
