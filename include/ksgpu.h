@@ -101,6 +101,11 @@ int ksg_ctx_comm_init_callbacks(ksg_ctx ctx, int rank, int nranks, int on_device
 /* Leaves the communicator (collective, like ncclCommDestroy / MPI_Comm_free). */
 int ksg_ctx_comm_finalize(ksg_ctx ctx);
 int ksg_ctx_comm_rank(ksg_ctx ctx, int *rank, int *nranks);
+/* Collective self-test of the communicator: a sum over the ranks with a known answer and a ring
+ * exchange (every rank sends to the next and receives from the previous one) through the path the
+ * halo exchange of MatMult uses.  The reference relies on MPI being there and correct; a launcher
+ * calls this once after ksg_ctx_comm_init_* so that a transport that came up wrong fails here. */
+int ksg_ctx_comm_selftest(ksg_ctx ctx);
 
 /* --------------------------------------------------------- device vectors */
 /* The PETSc Vec operations that hot-path host code invokes on BV columns

@@ -182,6 +182,56 @@ static int exchange_device(ksg_ctx c, const double *send, const int64_t *sendoff
   return KSG_OK;
 }
 
+/* Self-test of the communicator (collective): one sum over the ranks with a known answer, and one
+ * ring exchange -- every rank sends a block to the next rank and receives the previous rank's (its
+ * own, on a single rank) -- through the same all-to-all-v path, on the communication stream, that
+ * the halo exchange of a product uses. */
+extern "C" int ksg_ctx_comm_selftest(ksg_ctx c) {
+  if (!c) KSG_FAIL(KSG_ERR_ARG, "NULL context");
+  if (c->comm_kind == KSG_COMM_NONE) return KSG_OK;
+  KSG_HIP(hipSetDevice(c->device));
+  KSG_CHK(ksg_flush_pending(c));
+  const int P = c->nranks, me = c->rank;
+  double h[4] = {(double)(me + 1), 1.0, (double)me * (double)me, -1.0};
+  KSG_CHK(ksg_comm_allreduce_host(c, h, 4, 0));
+  const double want[4] = {0.5 * P * (P + 1.0), (double)P, (P - 1.0) * P * (2.0 * P - 1.0) / 6.0, -(double)P};
+  for (int i = 0; i < 4; i++)
+    if (h[i] != want[i])
+      KSG_FAIL(KSG_ERR_COMM, "communicator self-test: sum %d over %d ranks is %.17g, expected %.17g", i, P, h[i], want[i]);
+  const int64_t nblk = 4096;
+  const int next = (me + 1) % P, prev = (me + P - 1) % P;
+  std::vector<int64_t> soff((size_t)P + 1, 0), roff((size_t)P + 1, 0);
+  for (int p = 0; p < P; p++) { soff[p + 1] = soff[p] + (p == next ? nblk : 0); roff[p + 1] = roff[p] + (p == prev ? nblk : 0); }
+  std::vector<double> hs((size_t)nblk), hr((size_t)nblk, -1.0);
+  for (int64_t i = 0; i < nblk; i++) hs[(size_t)i] = 1000.0 * me + (double)(i % 997);
+  int rc = KSG_OK;
+  if (c->comm_kind == KSG_COMM_CALLBACKS && !c->cb_on_device) {
+    rc = ksg_comm_exchange_host(c, hs.data(), soff.data(), hr.data(), roff.data());
+  } else {
+    double *ds = NULL, *dr = NULL;
+    hipError_t e = hipMalloc(&ds, (size_t)nblk * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc(&dr, (size_t)nblk * sizeof(double));
+    if (e == hipSuccess) e = hipMemcpyAsync(ds, hs.data(), (size_t)nblk * sizeof(double), hipMemcpyHostToDevice, c->comm_stream);
+    if (e == hipSuccess) e = hipMemsetAsync(dr, 0xff, (size_t)nblk * sizeof(double), c->comm_stream);
+    if (e != hipSuccess) { ksg_set_error("communicator self-test: staging failed: %s", hipGetErrorString(e)); rc = KSG_ERR_HIP; }
+    /* like ksg_comm_exchange_host: a rank whose staging failed still takes part in the collective */
+    if (ds && dr) { const int rc2 = exchange_device(c, ds, soff.data(), dr, roff.data(), c->comm_stream); if (!rc) rc = rc2; }
+    if (!rc) {
+      e = hipMemcpyAsync(hr.data(), dr, (size_t)nblk * sizeof(double), hipMemcpyDeviceToHost, c->comm_stream);
+      if (e != hipSuccess) { ksg_set_error("communicator self-test: copy failed: %s", hipGetErrorString(e)); rc = KSG_ERR_HIP; }
+    }
+    hipStreamSynchronize(c->comm_stream);
+    if (ds) hipFree(ds);
+    if (dr) hipFree(dr);
+  }
+  if (rc) return rc;
+  for (int64_t i = 0; i < nblk; i++)
+    if (hr[(size_t)i] != 1000.0 * prev + (double)(i % 997))
+      KSG_FAIL(KSG_ERR_COMM, "communicator self-test: entry %lld received from rank %d is %.17g, expected %.17g",
+               (long long)i, prev, hr[(size_t)i], 1000.0 * prev + (double)(i % 997));
+  return KSG_OK;
+}
+
 /* Halo exchange of one multiply: A->d_send has been packed on the comm stream. */
 int ksg_comm_exchange(ksg_ctx c, ksg_mat A) {
   if (c->nranks <= 1) return KSG_OK;

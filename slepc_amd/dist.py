@@ -64,7 +64,9 @@ def gloo_callbacks(dist):
 
 
 def _check_allreduce(ctx, dist, size):
-    """One reduction through the library's communicator against the known answer."""
+    """The library's own self-test (a sum and a ring exchange over the halo path), then one
+    reduction through a vector kernel against the known answer."""
+    ctx.comm_selftest()
     n = 1000
     x = ctx.vec_alloc(n)
     ctx.vec_set(x, 1.0, n)
@@ -124,5 +126,6 @@ def init_comm(ctx, transport="rccl", fallback=True):
     if transport == "gloo":
         ar, ex = gloo_callbacks(dist)
         ctx.comm_init_callbacks(rank, size, ar, ex, on_device=False)
+        ctx.comm_selftest()
         return rank, size, "gloo"
     raise ValueError("unknown transport " + transport)

@@ -54,6 +54,7 @@ SIGNATURES = {
                                               EXCHANGE_FN, C.c_void_p]),
     "ksg_ctx_comm_finalize": (C.c_int, [C.c_void_p]),
     "ksg_ctx_comm_rank": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "ksg_ctx_comm_selftest": (C.c_int, [C.c_void_p]),
     "ksg_vec_alloc": (C.c_int, [C.c_void_p, c_i64, C.POINTER(C.c_void_p)]),
     "ksg_vec_free": (C.c_int, [C.c_void_p, C.c_void_p]),
     "ksg_vec_upload": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, c_i64]),
@@ -176,6 +177,9 @@ class Context:
 
     def comm_finalize(self):
         check(self.lib.ksg_ctx_comm_finalize(self.h))
+
+    def comm_selftest(self):
+        check(self.lib.ksg_ctx_comm_selftest(self.h))
 
     def unique_id(self):
         buf = C.create_string_buffer(128)

@@ -145,6 +145,9 @@ def test_rccl_single_rank_communicator():
     q = V.dotvec(V.column(2))
     assert np.allclose(q, A.T @ A[:, 2], rtol=1e-12, atol=1e-9)
     assert abs(V.norm(1, 1) - np.linalg.norm(A[:, 1])) < 1e-10
+    # the library's self-test: a sum, and a ring exchange (here to itself) through ncclSend / ncclRecv
+    # in one group on the communication stream, the calls of the halo exchange
+    ctx.comm_selftest()
     # leaving the communicator: single-rank again, reductions stay local
     ctx.comm_finalize()
     q2 = V.dotvec(V.column(2))
