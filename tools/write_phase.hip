@@ -114,6 +114,34 @@ __global__ __launch_bounds__(256) void k_burst(const double *__restrict__ X, int
   }
 }
 
+// E: as D, but the rows are split over several launches of one round of workgroups each, so that the
+// bursts of a launch all fall at its end: the launch boundary is the barrier
+template <int R>
+__global__ __launch_bounds__(256) void k_burst_part(const double *__restrict__ X, int64_t ld, int K, qarg q, double beta,
+                                                    double *__restrict__ y, int64_t n, int64_t pair0) {
+  const double2 *X2 = reinterpret_cast<const double2 *>(X);
+  double2 *y2 = reinterpret_cast<double2 *>(y);
+  const int64_t npair = n >> 1;
+  const int64_t base = pair0 + (int64_t)blockIdx.x * 256 * R + threadIdx.x;
+  double2 res[R];
+#pragma unroll
+  for (int i = 0; i < R; i++) {
+    const int64_t p = base + (int64_t)i * 256;
+    res[i] = make_double2(0.0, 0.0);
+    if (p < npair) {
+      const double2 yv = y2[p];
+      double2 a = row_sum(X2, ld >> 1, K, q, p);
+      res[i].x = fma(beta, yv.x, a.x); res[i].y = fma(beta, yv.y, a.y);
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < R; i++) {
+    const int64_t p = base + (int64_t)i * 256;
+    if (p < npair) y2[p] = res[i];
+  }
+}
+
 int main(int argc, char **argv) {
   const int64_t n = argc > 1 ? atoll(argv[1]) : 16777216;
   const int K = argc > 2 ? atoi(argv[2]) : 48;
@@ -157,6 +185,19 @@ int main(int argc, char **argv) {
   int dev = 0, ncu = 0;
   CHECK(hipGetDevice(&dev));
   CHECK(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
+  {
+    const int64_t npair = n >> 1;
+    char nm[128];
+#define PART(R) { int per_cu = 0; CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_burst_part<R>, 256, 0)); \
+    for (int use = per_cu; use >= 1; use = (use > 2 ? use - 1 : use - 1)) { \
+      const int64_t G = (int64_t)ncu * use, per = G * 256 * R; const int L = (int)((npair + per - 1) / per); \
+      snprintf(nm, sizeof nm, "E %d launches of %d workgroups/CU (max %d), %d KiB bursts", L, use, per_cu, 256 * R * 16 / 1024); \
+      time(nm, bytes_rd + bytes_wr, [&] { for (int l = 0; l < L; l++) { const int64_t left = npair - (int64_t)l * per; \
+        const unsigned g = (unsigned)((left < per ? left : per) + 256 * R - 1) / (256 * R); \
+        hipLaunchKernelGGL((k_burst_part<R>), dim3(g), dim3(256), 0, 0, X, ld, K, q, 1.0, y, n, (int64_t)l * per); } }); } }
+    PART(2) PART(4) PART(8) PART(16)
+#undef PART
+  }
   auto coop = [&](auto kern, int R, const char *label) {
     int per_cu = 0;
     CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 256, 0));
