@@ -431,7 +431,8 @@ static int launch_multvec(ksg_ctx c, const double *X, int64_t ld, int k, const d
 /* One thread owns R rows and all ne <= E output columns of them: it streams its
  * K input values once, multiplies by the coefficient panel held in LDS (read as
  * wave-uniform broadcasts) and only then stores, so the update is in place with
- * no scratch copy of the basis.  Bq is the K x E panel, row-major, zero padded. */
+ * no scratch copy of the basis.  Bq is the K x E panel, row-major, zero padded.  Vin and Vout may
+ * be the same columns: neither is declared restrict. */
 #define KSG_MIP_LDS 4096   /* doubles of the panel resident in LDS at a time */
 /* 1: in the two-rows-per-thread body the coefficients come straight from the device copy of the
  * panel with wave-uniform (scalar) loads and enter the multiply-adds as scalar operands; the
@@ -446,9 +447,9 @@ static int launch_multvec(ksg_ctx c, const double *X, int64_t ld, int k, const d
 #endif
 
 template <int E, int R>
-__global__ __launch_bounds__(KSG_BLOCK) void k_multinplace(const double *__restrict__ Vin, int64_t ld, int K,
+__global__ __launch_bounds__(KSG_BLOCK) void k_multinplace(const double *Vin, int64_t ld, int K,
                                                             const double *__restrict__ Bq,
-                                                            double *__restrict__ Vout, int64_t ldo, int ne,
+                                                            double *Vout, int64_t ldo, int ne,
                                                             int64_t n, double beta) {
   __shared__ double Bs[KSG_MIP_LDS];
   constexpr int KT = KSG_MIP_LDS / E;            /* panel rows per LDS fill */
@@ -592,7 +593,7 @@ typedef double ksg_d4 __attribute__((ext_vector_type(4)));
  * of 4 input columns the code is unrolled for (slices past K hold zeros and are not read); FULL:
  * all rows of the tile exist. */
 template <int NKS, bool FULL>
-__device__ __forceinline__ void mipm_load(double (&xv)[NKS][4], const double *__restrict__ Vin, int64_t ld, int K,
+__device__ __forceinline__ void mipm_load(double (&xv)[NKS][4], const double *Vin, int64_t ld, int K,
                                           int64_t n, int64_t r, int kq) {
 #pragma unroll
   for (int ks = 0; ks < NKS; ks++) {
@@ -621,7 +622,7 @@ __device__ __forceinline__ void mipm_load(double (&xv)[NKS][4], const double *__
 /* Products and stores of one tile whose input values are in xv. */
 template <int NKS, bool FULL>
 __device__ __forceinline__ void mipm_multiply(const double (&xv)[NKS][4], const double *Bs, int E, int nct,
-                                              double *__restrict__ Vout, int64_t ldo, int ne, int64_t n,
+                                              double *Vout, int64_t ldo, int ne, int64_t n,
                                               double beta, int64_t r, int j, int kq) {
 #pragma unroll 1
   for (int ct = 0; ct < nct; ct++) {
@@ -664,9 +665,9 @@ __device__ __forceinline__ void mipm_multiply(const double (&xv)[NKS][4], const 
 }
 
 template <int NKS>
-__global__ __launch_bounds__(256, 2) void k_mip_mfma(const double *__restrict__ Vin, int64_t ld, int K,
+__global__ __launch_bounds__(256, 2) void k_mip_mfma(const double *Vin, int64_t ld, int K,
                                                       const double *__restrict__ Bq, int E,
-                                                      double *__restrict__ Vout, int64_t ldo, int ne,
+                                                      double *Vout, int64_t ldo, int ne,
                                                       int64_t n, double beta) {
   __shared__ double Bs[KSG_MIPM_KMAX * 64];
   for (int t = threadIdx.x; t < 4 * NKS * E; t += 256) Bs[t] = t < K * E ? Bq[t] : 0.0;
