@@ -746,8 +746,8 @@ __global__ __launch_bounds__(KSG_BLOCK) void k_set_cols(double *__restrict__ X, 
   for (int64_t p = (int64_t)blockIdx.x * KSG_BLOCK + threadIdx.x; p < n; p += stride) x[p] = alpha;
 }
 
-/* y = beta*y + alpha*x over a block of columns (BVAXPY_BLAS_Private, bvblas.c:179) */
-__global__ __launch_bounds__(KSG_BLOCK) void k_axpby_cols(double *__restrict__ Y, int64_t ldy, const double *__restrict__ X,
+/* y = beta*y + alpha*x over a block of columns (BVAXPY_BLAS_Private, bvblas.c:179); X may be Y */
+__global__ __launch_bounds__(KSG_BLOCK) void k_axpby_cols(double *Y, int64_t ldy, const double *X,
                                                            int64_t ldx, int64_t n, double alpha, double beta) {
   double *y = Y + (int64_t)blockIdx.y * ldy;
   const double *x = X + (int64_t)blockIdx.y * ldx;
