@@ -78,6 +78,7 @@ struct ksg_ctx_s {
   ksg_pending pend;
   int lazy_update;           /* 0: never defer the store of a Gram-Schmidt update */
   int hot_cols;              /* most x entries a new operator may keep packed (0: none) */
+  int col_groups;            /* column groups of a new power-law operator: 0 = chosen by size, 1 = none, >= 2 forced */
   /* communicator */
   int comm_kind, rank, nranks, cb_on_device;
   void *rccl_comm;
@@ -127,13 +128,29 @@ struct ksg_csr_dev {
   double *pc_val;    /* 256 values */
 };
 
+/* One column group of a power-law operator: the entries whose column lies in
+ * [col_first, col_first + ncols), as a CSR over only the rows that have such entries, columns
+ * relative to col_first (packed hot columns: ncols + slot).  Group 0 lives in ksg_mat_s::diag
+ * over all rows. */
+struct ksg_colgroup {
+  ksg_csr_dev blk;
+  int64_t col_first, ncols, nrows;
+  int32_t *d_rows;           /* local row of every row of blk                  */
+  int64_t nhot;
+  std::vector<int32_t> hot_cols;
+  int32_t *d_hot_idx;
+  double *d_xhot;
+};
+
 struct ksg_mat_s {
   ksg_ctx ctx;
   int64_t n, N, row0, nnz;
   int64_t nc, NC, col0;      /* column layout: x has nc local entries, columns [col0,col0+nc) are local */
   std::vector<int64_t> cstarts;  /* first column of every rank, nranks+1 (empty with one rank) */
   std::vector<int32_t> ghosts;   /* global column of every ghost-buffer slot */
-  ksg_csr_dev diag;          /* columns local (col - col0); entries of a packed column: nc + its slot */
+  ksg_csr_dev diag;          /* columns local (col - col0); entries of a packed column: diag_ncols + its slot */
+  int64_t diag_ncols;        /* nc, or the width of the first column group when there are several */
+  std::vector<ksg_colgroup> cgs;   /* the column groups after the first (one rank, power-law operators) */
   /* packed copy of the x entries of the most referenced columns (power-law operators) */
   int64_t nhot;
   std::vector<int32_t> hot_cols; /* local column of every slot                  */

@@ -629,9 +629,13 @@ static bool build_value_table(int64_t nnz, const double *val, const uint8_t *ski
 
 /* diag_cols: for a block that holds the operator's diagonal, the column index every entry had
  * before the packed columns were relabelled (row r's diagonal entry is the one in column
- * r + dshift); NULL for a block without a diagonal (ghost blocks). */
+ * r + dshift); NULL for a block without a diagonal (ghost blocks).  row_ids: for a block over a
+ * subset of the rows (a column group), the row each of its rows stands for; row i's diagonal entry
+ * is then the one in column row_ids[i] + dshift, and the dense diagonal is indexed by the block's
+ * columns (dv_len of them) instead of its rows. */
 static int csr_to_device(ksg_csr_dev *D, int64_t nrows, const int64_t *rowptr, const int32_t *colidx,
-                         const double *val, const int32_t *diag_cols = NULL, int64_t dshift = 0) {
+                         const double *val, const int32_t *diag_cols = NULL, int64_t dshift = 0,
+                         const int32_t *row_ids = NULL, int64_t dv_len = 0) {
   D->nrows = nrows;
   D->nnz = rowptr[nrows];
   std::vector<int32_t> tiles;
@@ -653,17 +657,18 @@ static int csr_to_device(ksg_csr_dev *D, int64_t nrows, const int64_t *rowptr, c
     if (build_value_table(D->nnz, val, NULL, 256, tab, idx)) D->nvt = 1;
     else if (diag_cols && dshift > -(int64_t)INT32_MAX && dshift < (int64_t)INT32_MAX) {
       std::vector<uint8_t> isdiag((size_t)D->nnz, 0);
-      std::vector<double> dv((size_t)nrows, 0.0);
+      std::vector<double> dv((size_t)(row_ids ? dv_len : nrows), 0.0);
       bool one_per_row = true;
       for (int64_t r = 0; r < nrows && one_per_row; r++) {
         int seen = 0;
+        const int64_t want = (row_ids ? (int64_t)row_ids[r] : r) + dshift;
         for (int64_t p = rowptr[r]; p < rowptr[r + 1]; p++)
-          if ((int64_t)diag_cols[p] == r + dshift) { isdiag[(size_t)p] = 1; dv[(size_t)r] = val[p]; seen++; }
+          if ((int64_t)diag_cols[p] == want) { isdiag[(size_t)p] = 1; dv[(size_t)(row_ids ? want : r)] = val[p]; seen++; }
         if (seen > 1) one_per_row = false;              /* duplicate entries: leave the matrix as it is */
       }
       if (one_per_row && build_value_table(D->nnz, val, isdiag.data(), 255, tab, idx)) {
         KSG_CHK(upload(&D->dvals, dv.data(), dv.size()));
-        D->dshift = (int32_t)dshift;
+        D->dshift = row_ids ? 0 : (int32_t)dshift;      /* the kernel reads dvals[column - dshift] */
         D->nvt = 2;
       }
     }
@@ -768,7 +773,7 @@ static int rowcode_to_device(ksg_csr_dev *D, int64_t nrows, const int64_t *rowpt
  * on the packing of its most referenced columns. */
 static int block_to_device(ksg_ctx c, ksg_csr_dev *D, int64_t ncols, int64_t nrows, const int64_t *rowptr, const int32_t *colidx,
                            const double *val, std::vector<int32_t> &hot_cols, int64_t *nhot, int32_t **d_hot_idx, double **d_xhot,
-                           bool has_diag = false, int64_t dshift = 0) {
+                           bool has_diag = false, int64_t dshift = 0, const int32_t *row_ids = NULL) {
   std::vector<int32_t> relabeled;
   choose_hot_columns(ncols, rowptr[nrows], colidx, c->hot_cols, hot_cols, relabeled);
   *nhot = (int64_t)hot_cols.size();
@@ -776,24 +781,96 @@ static int block_to_device(ksg_ctx c, ksg_csr_dev *D, int64_t ncols, int64_t nro
     /* a diagonal entry keeps its own column: the kernel finds its value by that column, and the
      * x entry it multiplies sits next to those of the neighbouring rows anyway */
     if (has_diag)
-      for (int64_t r = 0; r < nrows; r++)
+      for (int64_t r = 0; r < nrows; r++) {
+        const int64_t want = (row_ids ? (int64_t)row_ids[r] : r) + dshift;
         for (int64_t p = rowptr[r]; p < rowptr[r + 1]; p++)
-          if ((int64_t)colidx[p] == r + dshift) relabeled[(size_t)p] = colidx[p];
+          if ((int64_t)colidx[p] == want) relabeled[(size_t)p] = colidx[p];
+      }
     KSG_CHK(upload(d_hot_idx, hot_cols.data(), hot_cols.size()));
     hipError_t e = hipMalloc(d_xhot, (size_t)*nhot * sizeof(double));
     if (e != hipSuccess) KSG_FAIL(KSG_ERR_MEM, "matrix upload: %zu bytes: %s", (size_t)*nhot * sizeof(double), hipGetErrorString(e));
   }
-  KSG_CHK(csr_to_device(D, nrows, rowptr, *nhot ? relabeled.data() : colidx, val, has_diag ? colidx : NULL, dshift));
-  if (has_diag && !*nhot && ncols == nrows) KSG_CHK(rowcode_to_device(D, nrows, rowptr, colidx, val, ncols));    /* x and y indexed alike */
+  KSG_CHK(csr_to_device(D, nrows, rowptr, *nhot ? relabeled.data() : colidx, val, has_diag ? colidx : NULL, dshift, row_ids, ncols));
+  if (has_diag && !*nhot && ncols == nrows && !row_ids) KSG_CHK(rowcode_to_device(D, nrows, rowptr, colidx, val, ncols));    /* x and y indexed alike */
   return KSG_OK;
+}
+
+/* Power-law test of the packing (choose_hot_columns): columns referenced at least four times as
+ * often as the average hold 15 % or more of the entries. */
+static bool is_power_law(int64_t ncols, int64_t nnz, const int32_t *colidx) {
+  if (ncols <= 0 || nnz <= 0) return false;
+  std::vector<int32_t> cnt((size_t)ncols, 0);
+  for (int64_t p = 0; p < nnz; p++) cnt[colidx[p]]++;
+  const int64_t thresh = std::max<int64_t>(8, 4 * ((nnz + ncols - 1) / ncols));
+  int64_t covered = 0;
+  for (int64_t j = 0; j < ncols; j++) if (cnt[j] >= thresh) covered += cnt[j];
+  return covered * 100 >= nnz * 15;
+}
+
+/* Number of column groups the local block of a new operator gets (1: none). */
+static int column_groups_for(ksg_ctx c, int64_t ncols, int64_t nnz, const int32_t *colidx) {
+  if (c->nranks > 1 || c->col_groups == 1 || ncols < 64) return 1;
+  int G = c->col_groups;
+  if (G == 0) {
+    /* at most 128 MiB of x per group, from 256 MiB on.  R-MAT scale 26 (x = 512 MiB): 10.83 ms whole,
+     * 9.74 / 8.92 / 8.98 / 8.97 ms in 2 / 4 / 6 / 8 groups, 9.39 in 16; scale 24 (128 MiB): 2.09 ms
+     * whole, 2.06 / 2.09 / 2.15 in 2 / 4 / 8 -- nothing to gain below */
+    const int64_t slice = ((int64_t)128 << 20) / 8;
+    if (ncols < 2 * slice) return 1;
+    G = (int)((ncols + slice - 1) / slice);
+  }
+  if ((int64_t)G > ncols / 32) G = (int)(ncols / 32);
+  if (G < 2 || !is_power_law(ncols, nnz, colidx)) return 1;
+  return G;
 }
 
 static int diag_to_device(ksg_mat A, int64_t nrows, const int64_t *rowptr, const int32_t *colidx, const double *val) {
   /* the diagonal of a square operator lies in this block: row r (global row0 + r) has it in the
    * local column row0 + r - col0 */
   const bool square = A->N == A->NC;
-  return block_to_device(A->ctx, &A->diag, A->nc, nrows, rowptr, colidx, val, A->hot_cols, &A->nhot, &A->d_hot_idx, &A->d_xhot,
-                         square, A->row0 - A->col0);
+  ksg_ctx c = A->ctx;
+  A->diag_ncols = A->nc;
+  const int G = column_groups_for(c, A->nc, rowptr[nrows], colidx);
+  if (G <= 1)
+    return block_to_device(c, &A->diag, A->nc, nrows, rowptr, colidx, val, A->hot_cols, &A->nhot, &A->d_hot_idx, &A->d_xhot,
+                           square, A->row0 - A->col0);
+  /* column groups: boundaries on multiples of 32 columns; group 0 over all rows (it stores y),
+   * the others over the rows they touch */
+  const int64_t width = ((A->nc + G - 1) / G + 31) / 32 * 32;
+  const int64_t dsh = A->row0 - A->col0;
+  A->cgs.clear();
+  for (int g = 0; g < G; g++) {
+    const int64_t lo = (int64_t)g * width, hi = std::min<int64_t>(A->nc, lo + width);
+    if (lo >= hi) break;
+    std::vector<int64_t> rp;
+    std::vector<int32_t> ci, rows;
+    std::vector<double> va;
+    rp.push_back(0);
+    for (int64_t r = 0; r < nrows; r++) {
+      const size_t before = ci.size();
+      for (int64_t p = rowptr[r]; p < rowptr[r + 1]; p++)
+        if ((int64_t)colidx[p] >= lo && (int64_t)colidx[p] < hi) { ci.push_back((int32_t)(colidx[p] - lo)); va.push_back(val[p]); }
+      if (g == 0 || ci.size() > before) { rp.push_back((int64_t)ci.size()); if (g) rows.push_back((int32_t)r); }
+    }
+    if (g == 0) {
+      A->diag_ncols = hi - lo;
+      /* rows 0..nrows-1 themselves: the diagonal of row r is local column r + dsh of the group */
+      KSG_CHK(block_to_device(c, &A->diag, hi - lo, nrows, rp.data(), ci.data(), va.data(), A->hot_cols, &A->nhot, &A->d_hot_idx,
+                              &A->d_xhot, square, dsh));
+      A->diag.pc_w = 0;                                  /* a column group never takes the row-code form */
+      continue;
+    }
+    if (rows.empty()) continue;
+    A->cgs.emplace_back();
+    ksg_colgroup &cg = A->cgs.back();
+    memset(&cg.blk, 0, sizeof(cg.blk));
+    cg.col_first = lo; cg.ncols = hi - lo; cg.nrows = (int64_t)rows.size();
+    cg.d_rows = NULL; cg.nhot = 0; cg.d_hot_idx = NULL; cg.d_xhot = NULL;
+    KSG_CHK(upload(&cg.d_rows, rows.data(), rows.size()));
+    KSG_CHK(block_to_device(c, &cg.blk, cg.ncols, cg.nrows, rp.data(), ci.data(), va.data(), cg.hot_cols, &cg.nhot, &cg.d_hot_idx,
+                            &cg.d_xhot, square, dsh - lo, rows.data()));
+  }
+  return KSG_OK;
 }
 
 static void csr_free(ksg_csr_dev *D) {
@@ -861,6 +938,7 @@ static int mat_create(ksg_ctx c, int64_t n, int64_t N, int64_t row0, int64_t nc,
   A->ctx = c; A->n = n; A->N = N; A->row0 = row0; A->nnz = rowptr[n];
   A->nc = nc; A->NC = NC; A->col0 = col0;
   memset(&A->diag, 0, sizeof(A->diag));
+  A->diag_ncols = nc;
   A->no_rows = 0; A->o_rows = NULL; A->o_nnz = 0;
   memset(&A->ghost, 0, sizeof(A->ghost));
   A->g_nhot = 0; A->d_g_hot_idx = NULL; A->d_g_xhot = NULL;
@@ -1012,12 +1090,45 @@ static int mat_to_host(ksg_mat A, std::vector<int64_t> &rp, std::vector<int32_t>
     KSG_CHK(download(drp, A->diag.rowptr, (size_t)A->n + 1));
     KSG_CHK(download(dci, A->diag.colidx, (size_t)A->diag.nnz));
     KSG_CHK(download(dva, A->diag.val, (size_t)A->diag.nnz));
-    if (A->nhot) for (size_t p = 0; p < dci.size(); p++) if ((int64_t)dci[p] >= A->nc) dci[p] = A->hot_cols[(size_t)((int64_t)dci[p] - A->nc)];
+    if (A->nhot) for (size_t p = 0; p < dci.size(); p++) if ((int64_t)dci[p] >= A->diag_ncols) dci[p] = A->hot_cols[(size_t)((int64_t)dci[p] - A->diag_ncols)];
   } else {
     drp.assign((size_t)A->n + 1, 0);
   }
-  if (c->nranks == 1) {
+  if (c->nranks == 1 && A->cgs.empty()) {
     rp.swap(drp); ci.swap(dci); va.swap(dva);
+    return KSG_OK;
+  }
+  if (c->nranks == 1) {
+    /* column groups: a row's entries are those of group 0, 1, ... in turn (ascending columns) */
+    const size_t G = A->cgs.size();
+    std::vector<std::vector<int64_t>> grp(G);
+    std::vector<std::vector<int32_t>> gci(G), grows(G);
+    std::vector<std::vector<double>> gva(G);
+    rp.assign((size_t)A->n + 1, 0);
+    for (int64_t i = 0; i < A->n; i++) rp[i + 1] = drp[i + 1] - drp[i];
+    for (size_t g = 0; g < G; g++) {
+      const ksg_colgroup &cg = A->cgs[g];
+      KSG_CHK(download(grows[g], cg.d_rows, (size_t)cg.nrows));
+      KSG_CHK(download(grp[g], cg.blk.rowptr, (size_t)cg.nrows + 1));
+      KSG_CHK(download(gci[g], cg.blk.colidx, (size_t)cg.blk.nnz));
+      KSG_CHK(download(gva[g], cg.blk.val, (size_t)cg.blk.nnz));
+      for (size_t p = 0; p < gci[g].size(); p++) {
+        int64_t col = gci[g][p];
+        if (col >= cg.ncols) col = cg.hot_cols[(size_t)(col - cg.ncols)];
+        gci[g][p] = (int32_t)(col + cg.col_first);
+      }
+      for (int64_t i = 0; i < cg.nrows; i++) rp[grows[g][i] + 1] += grp[g][i + 1] - grp[g][i];
+    }
+    for (int64_t i = 0; i < A->n; i++) rp[i + 1] += rp[i];
+    ci.resize((size_t)rp[A->n]); va.resize((size_t)rp[A->n]);
+    std::vector<int64_t> pos(rp.begin(), rp.end() - 1);
+    for (int64_t i = 0; i < A->n; i++)
+      for (int64_t p = drp[i]; p < drp[i + 1]; p++) { ci[(size_t)pos[i]] = dci[p]; va[(size_t)pos[i]] = dva[p]; pos[i]++; }
+    for (size_t g = 0; g < G; g++)
+      for (int64_t i = 0; i < A->cgs[g].nrows; i++) {
+        const int64_t r = grows[g][i];
+        for (int64_t p = grp[g][i]; p < grp[g][i + 1]; p++) { ci[(size_t)pos[r]] = gci[g][p]; va[(size_t)pos[r]] = gva[g][p]; pos[r]++; }
+      }
     return KSG_OK;
   }
   std::vector<int32_t> orows, oci;
@@ -1130,6 +1241,13 @@ extern "C" int ksg_mat_destroy(ksg_mat A) {
   hipStreamSynchronize(A->ctx->stream);
   csr_free(&A->diag);
   csr_free(&A->ghost);
+  for (ksg_colgroup &cg : A->cgs) {
+    csr_free(&cg.blk);
+    if (cg.d_rows) hipFree(cg.d_rows);
+    if (cg.d_hot_idx) hipFree(cg.d_hot_idx);
+    if (cg.d_xhot) hipFree(cg.d_xhot);
+  }
+  A->cgs.clear();
   if (A->o_rows) hipFree(A->o_rows);
   if (A->d_g_hot_idx) hipFree(A->d_g_hot_idx);
   if (A->d_g_xhot) hipFree(A->d_g_xhot);
@@ -1156,6 +1274,7 @@ extern "C" int ksg_mat_sizes(ksg_mat A, int64_t *n, int64_t *N, int64_t *row0, i
 extern "C" int ksg_mat_hot_columns(ksg_mat A, int64_t *nhot) {
   if (!A || !nhot) KSG_FAIL(KSG_ERR_ARG, "ksg_mat_hot_columns: NULL argument");
   *nhot = A->nhot;
+  for (const ksg_colgroup &cg : A->cgs) *nhot += cg.nhot;
   return KSG_OK;
 }
 
@@ -1181,9 +1300,16 @@ static int mat_mult_raw(ksg_mat A, const double *x, double *y) {
     launch_rowcode<0>(c->stream, A->diag, x, y, 0.0, 0.0, NULL, NULL);
   } else if (A->diag.ntiles) {
     if (A->nhot) hipLaunchKernelGGL(k_gather, dim3(ksg_grid_for(A->nhot)), dim3(KSG_BLOCK), 0, c->stream, x, A->d_hot_idx, A->d_xhot, A->nhot);
-    launch_tiles<0>(c->stream, A->diag, x, y, 0.0, 0.0, NULL, NULL, A->nhot ? A->d_xhot : NULL, (int32_t)A->nc, NULL);
+    launch_tiles<0>(c->stream, A->diag, x, y, 0.0, 0.0, NULL, NULL, A->nhot ? A->d_xhot : NULL, (int32_t)A->diag_ncols, NULL);
   } else if (A->n) {
     KSG_HIP(hipMemsetAsync(y, 0, (size_t)A->n * sizeof(double), c->stream));     /* no local columns at all */
+  }
+  /* the other column groups, one after the other, adding into the rows they touch: while a group
+   * runs, all gathers fall into its slice of x */
+  for (const ksg_colgroup &cg : A->cgs) {
+    const double *xg = x + cg.col_first;
+    if (cg.nhot) hipLaunchKernelGGL(k_gather, dim3(ksg_grid_for(cg.nhot)), dim3(KSG_BLOCK), 0, c->stream, xg, cg.d_hot_idx, cg.d_xhot, cg.nhot);
+    launch_tiles<2>(c->stream, cg.blk, xg, y, 0.0, 0.0, NULL, NULL, cg.nhot ? cg.d_xhot : NULL, (int32_t)cg.ncols, cg.d_rows);
   }
   KSG_HIP(hipGetLastError());
   if (halo) {
@@ -1215,6 +1341,8 @@ static double block_stream_bytes(const ksg_csr_dev &D) {
 }
 static inline double spmv_bytes(ksg_mat A) {
   double b = block_stream_bytes(A->diag) + 8.0 * (double)A->nc + 8.0 * (double)A->n + 20.0 * (double)A->nhot;
+  for (const ksg_colgroup &cg : A->cgs)       /* entry stream, row list, read-modify-write of the rows touched, packing */
+    b += block_stream_bytes(cg.blk) + 20.0 * (double)cg.nrows + 20.0 * (double)cg.nhot;
   if (A->ctx->nranks > 1)
     b += (A->no_rows ? block_stream_bytes(A->ghost) : 0.0) + 20.0 * (double)A->no_rows + 20.0 * (double)A->g_nhot +
          8.0 * (double)A->nghost + 20.0 * (double)A->nsend;
@@ -1247,6 +1375,12 @@ extern "C" int ksg_mat_describe(ksg_mat A, char *buf, size_t len) {
            KSG_TILE_NNZ, KSG_TILE_ROWS, (long long)A->diag.n_stream, (long long)A->diag.n_group, (long long)A->diag.n_long,
            A->diag.nvt == 2 ? "1-byte indices into a 255-entry table off the diagonal, the diagonal as a dense vector" :
            A->diag.nvt ? "1-byte indices into a 256-entry table" : "8-byte stream", (long long)A->nhot, (long long)A->nghost);
+  if (!A->cgs.empty() && k > 0 && (size_t)k < len) {
+    long long rows = 0, ent = 0, hot = 0;
+    for (const ksg_colgroup &cg : A->cgs) { rows += cg.nrows; ent += cg.blk.nnz; hot += cg.nhot; }
+    k += snprintf(buf + k, len - (size_t)k, "; %d column groups of <= %lld columns multiplied one after the other (groups after the first: %lld entries in "
+                  "%lld row pieces, %lld packed)", (int)A->cgs.size() + 1, (long long)A->diag_ncols, ent, rows, hot);
+  }
   if (A->ctx->nranks > 1 && k > 0 && (size_t)k < len)
     snprintf(buf + k, len - (size_t)k, "; ghost block: %lld entries in %lld rows through the same tile kernel (%lld/%lld/%lld tiles, %lld packed)",
              (long long)A->o_nnz, (long long)A->no_rows, (long long)A->ghost.n_stream, (long long)A->ghost.n_group, (long long)A->ghost.n_long,
@@ -1273,8 +1407,8 @@ extern "C" int ksg_mat_residual_norm(ksg_mat A, double kr, double ki, const doub
   if (A->n && !x) KSG_FAIL(KSG_ERR_ARG, "ksg_mat_residual_norm: NULL vector");
   if (A->n != A->nc || A->N != A->NC) KSG_FAIL(KSG_ERR_ARG, "ksg_mat_residual_norm: the operator must be square");
   ksg_ctx c = A->ctx;
-  const bool halo = c->nranks > 1;
-  if (halo && A->n && (!work || work == x || work == xi)) KSG_FAIL(KSG_ERR_ARG, "ksg_mat_residual_norm: a separate work vector is needed with several ranks");
+  const bool halo = c->nranks > 1 || !A->cgs.empty();     /* the product cannot be fused with the norm */
+  if (halo && A->n && (!work || work == x || work == xi)) KSG_FAIL(KSG_ERR_ARG, "ksg_mat_residual_norm: a separate work vector is needed with several ranks or column groups");
   KSG_CHK(ksg_op_begin(c, KSG_EV_MATMULT));
   int nb = 0;
   if (!halo) {
@@ -1284,7 +1418,7 @@ extern "C" int ksg_mat_residual_norm(ksg_mat A, double kr, double ki, const doub
       if (A->diag.pc_w) launch_rowcode<1>(c->stream, A->diag, x, NULL, kr, ki, xi, c->d_partial);
       else {
         if (A->nhot) hipLaunchKernelGGL(k_gather, dim3(ksg_grid_for(A->nhot)), dim3(KSG_BLOCK), 0, c->stream, x, A->d_hot_idx, A->d_xhot, A->nhot);
-        launch_tiles<1>(c->stream, A->diag, x, NULL, kr, ki, xi, c->d_partial, A->nhot ? A->d_xhot : NULL, (int32_t)A->nc, NULL);
+        launch_tiles<1>(c->stream, A->diag, x, NULL, kr, ki, xi, c->d_partial, A->nhot ? A->d_xhot : NULL, (int32_t)A->diag_ncols, NULL);
       }
     }
   } else {
@@ -1317,7 +1451,7 @@ extern "C" int ksg_bv_matmult(ksg_bv V, ksg_mat A, ksg_bv W) {
   KSG_CHK(ksg_op_begin(c, KSG_EV_MATMULT));
   const double *X = V->d + (int64_t)(V->nc + V->l) * V->ld;
   double *Y = W->d + (int64_t)(W->nc + W->l) * W->ld;
-  if (c->nranks == 1 && nc > 1 && A->diag.ntiles && !A->nhot) {
+  if (c->nranks == 1 && nc > 1 && A->diag.ntiles && !A->nhot && A->cgs.empty()) {
     /* one pass over the matrix for all the columns */
     hipLaunchKernelGGL(k_spmm_tiles<8>, dim3((unsigned)A->diag.ntiles), dim3(KSG_BLOCK), 0, c->stream, A->diag.tiles,
                        A->diag.tile_p, A->diag.rowptr, A->diag.colidx, A->diag.val, X, V->ld, Y, W->ld, nc);

@@ -344,6 +344,70 @@ def test_value_table_with_dense_diagonal(gpu_ctx, hot):
         ctx.vec_free(p)
 
 
+@pytest.mark.parametrize("groups,hot,shifted", [(2, 0, False), (5, 1024, False), (8, 256, True), (64, 0, True)])
+def test_column_groups(gpu_ctx, groups, hot, shifted):
+    """A power-law operator held as groups of consecutive columns (KSG_OPT_COL_GROUPS) that are
+    multiplied one after the other: the product agrees with the whole operator's to rounding (a
+    row's sum is formed group by group), the entries read back and the transpose are exactly the
+    input's, the residual norm and the block product go through the same groups; an operator that
+    is not power-law is left whole."""
+    from scipy.sparse import csr_matrix
+    from slepc_amd import ksgpu, matgen as mg
+    ctx = gpu_ctx
+    rp, ci, va = mg.rmat_laplacian(14, 8, seed=11)
+    n = len(rp) - 1
+    rng = np.random.default_rng(5)
+    if shifted:                                            # every diagonal value its own: the dense-diagonal value table
+        va = va.copy()
+        va[ci == np.repeat(np.arange(n), np.diff(rp))] += rng.random(n)
+    ctx.set_option(ksgpu.OPT_HOT_COLS, hot)
+    ctx.set_option(ksgpu.OPT_COL_GROUPS, 1)
+    A0 = ksgpu.DeviceCSR(ctx, rp, ci, va)
+    ctx.set_option(ksgpu.OPT_COL_GROUPS, groups)
+    A1 = ksgpu.DeviceCSR(ctx, rp, ci, va)
+    L = ksgpu.DeviceCSR(ctx, *mg.laplacian2d(70, 70))     # a stencil stays whole whatever is asked for
+    ctx.set_option(ksgpu.OPT_COL_GROUPS, 0)
+    ctx.set_option(ksgpu.OPT_HOT_COLS, 1048576)
+    assert "column groups" not in A0.describe() and "column groups" not in L.describe()
+    assert "%d column groups" % groups in A1.describe(), A1.describe()
+    L.destroy()
+    M = csr_matrix((va, ci, rp), shape=(n, n))
+    xd, yd, zd, wd = (ctx.vec_alloc(n) for _ in range(4))
+    for trial in range(2):                                 # the second product sees new x (the packed entries are refreshed)
+        x = rng.standard_normal(n)
+        ctx.upload(xd, x)
+        ctx.upload(zd, np.full(n, np.nan))
+        A0.mult(xd, yd)
+        A1.mult(xd, zd)
+        y0, y1 = ctx.download(yd, n), ctx.download(zd, n)
+        ref = M @ x
+        scale = np.abs(M) @ np.abs(x)
+        assert np.all(np.abs(y1 - ref) <= 1e-14 * scale) and np.all(np.abs(y1 - y0) <= 1e-14 * scale)
+    r1, c1, v1 = A1.get_csr()
+    assert np.array_equal(r1, rp) and np.array_equal(c1, ci) and np.array_equal(v1, va)
+    T0, T1 = A0.transpose(), A1.transpose()
+    for a, b in zip(T0.get_csr(), T1.get_csr()):
+        assert np.array_equal(a, b)
+    want = np.linalg.norm(ref - 1.75 * x)
+    assert abs(A1.residual_norm(1.75, 0.0, xd, None, wd) - want) <= 1e-13 * want
+    with pytest.raises(ksgpu.KsgError):
+        A1.residual_norm(1.75, 0.0, xd)                    # the groups need a work vector
+    m = 3
+    V, W = ksgpu.DeviceBV(ctx, n, m), ksgpu.DeviceBV(ctx, n, m)
+    Va = rng.standard_normal((n, m))
+    V.from_numpy(Va)
+    V.matmult(A1, W)
+    Wa = W.to_numpy()
+    for j in range(m):
+        assert np.all(np.abs(Wa[:, j] - M @ Va[:, j]) <= 1e-14 * (np.abs(M) @ np.abs(Va[:, j])))
+    ex, cm = A1.traffic_model()
+    assert ex > 0 and cm > 0
+    for o in (A0, A1, T0, T1, V, W):
+        o.destroy()
+    for p_ in (xd, yd, zd, wd):
+        ctx.vec_free(p_)
+
+
 @pytest.mark.parametrize("gen", ["lap1d", "lap2d", "lap3d", "band"])
 def test_row_code_kernel_equals_tile_kernel(gpu_ctx, gen):
     """Stencils and other banded operators with few distinct (column - row, value) pairs are

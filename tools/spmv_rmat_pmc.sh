@@ -40,10 +40,11 @@ for f in sorted(glob.glob(out + "/*counter_collection.csv")):
                 acc[k][row["Counter_Name"]].append(float(row["Counter_Value"]))
 with open(out + "/summary.txt", "w") as o:
     o.write(open(out + "/plain.txt").read())
-    o.write("\ncounters per launch (mean over the launches of each pass), R-MAT scale %s\n" % scale)
+    o.write("\ncounters per launch (mean over the launches of each pass) and per product (6 products per pass: an operator in\n"
+            "column groups launches the kernel once per group), R-MAT scale %s\n" % scale)
     for k in acc:
         for c, v in sorted(acc[k].items()):
-            o.write("%-14s %-36s %16.0f  (%d launches)\n" % (k, c, sum(v) / len(v), len(v)))
+            o.write("%-14s %-36s %16.0f  (%d launches)  %16.0f per product\n" % (k, c, sum(v) / len(v), len(v), sum(v) / 6.0))
 print(open(out + "/summary.txt").read())
 PY
 rm -f $OUT/*counter_collection.csv $OUT/*agent_info.csv
