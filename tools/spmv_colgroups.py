@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """SpMV time on an R-MAT graph Laplacian against the number of column groups the operator is held
 in (KSG_OPT_COL_GROUPS; 1 = the whole operator in one block).
-Usage: spmv_colgroups.py [scale=24] [groups=1,2,4,8] [limit of packed columns per group=1048576,...]"""
+Usage: spmv_colgroups.py [scale=24] [groups=1,2,4,8] [limit of packed columns per group=1048576,...]
+KSG_RANK_OF=r/P: only the rows that rank r of P owns under the entry-balanced split, as a rectangular
+operator over all columns -- the shape of one rank's work in a P-rank run (its ghost entries included)."""
 import os
 import sys
 import time
@@ -16,18 +18,28 @@ def main():
     groups = [int(v) for v in (sys.argv[2] if len(sys.argv) > 2 else "1,2,4,8").split(",")]
     hots = [int(v) for v in (sys.argv[3] if len(sys.argv) > 3 else "1048576").split(",")]
     t0 = time.perf_counter()
-    rp, ci, va = matgen.rmat_laplacian(scale)
+    NC = 1 << scale
+    cols = None
+    if os.environ.get("KSG_RANK_OF"):
+        r, P = (int(v) for v in os.environ["KSG_RANK_OF"].split("/"))
+        starts = matgen.balanced_row_blocks(matgen.rmat_row_weights(scale), P, 0.0)
+        rp, ci, va = matgen.rmat_laplacian(scale, row0=int(starts[r]), row1=int(starts[r + 1]))
+        cols = (NC, NC, 0)
+        va = np.full_like(va, -1.0)          # a ghost block holds off-diagonal entries only: one value
+        print("rows %d..%d of rank %d of %d" % (starts[r], starts[r + 1], r, P))
+    else:
+        rp, ci, va = matgen.rmat_laplacian(scale)
     n = len(rp) - 1
     print("scale %d: n=%d nnz=%d, generated in %.0f s" % (scale, n, rp[-1], time.perf_counter() - t0), flush=True)
     ctx = ksgpu.Context(0)
-    x, y = ctx.vec_alloc(n), ctx.vec_alloc(n)
-    ctx.vec_fill_hash(x, n, 0, 5)
+    x, y = ctx.vec_alloc(NC), ctx.vec_alloc(n)
+    ctx.vec_fill_hash(x, NC, 0, 5)
     y0 = None
     for g, hot in [(g, h) for g in groups for h in hots]:
         ctx.set_option(ksgpu.OPT_COL_GROUPS, g)
         ctx.set_option(ksgpu.OPT_HOT_COLS, hot)
         t0 = time.perf_counter()
-        A = ksgpu.DeviceCSR(ctx, rp, ci, va)
+        A = ksgpu.DeviceCSR(ctx, rp, ci, va, cols=cols)
         tc = time.perf_counter() - t0
         A.mult(x, y)
         ctx.sync()
