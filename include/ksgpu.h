@@ -86,9 +86,18 @@ void *ksg_ctx_stream(ksg_ctx ctx);
  * multiplies the groups one after the other (the first stores y, the others add into the rows
  * they touch), so that at any time the gathers fall into one slice of x whose most referenced
  * part the L2s can hold.  A row's sum is then formed group by group: the same products added
- * in another order. */
+ * in another order.
+ * KSG_OPT_BINS (default 0 = by size; 1 = never; 2 = always): a power-law operator created
+ * afterwards on one rank (x of 64 MiB or more when chosen by size) keeps the entries of its well
+ * filled (row block, column block) cells in a binned form: one pass looks x up in LDS slices and
+ * writes the products in the order of the row blocks, a second pass sums them per row block in
+ * LDS and adds the diagonal term; the remaining entries stay a CSR over the rows they touch and
+ * are added afterwards.  The gathers from a large x, one memory request each, become two streams.
+ * Takes precedence over the column groups.  A row's sum is formed from its binned entries by
+ * column block, its diagonal entry, and its remaining entries: the same products added in another
+ * order. */
 enum { KSG_OPT_FUSE_DOTS = 1, KSG_OPT_DOT_GRID = 2, KSG_OPT_MV_GRID = 3, KSG_OPT_LAZY_UPDATE = 4, KSG_OPT_HOT_COLS = 5,
-       KSG_OPT_COL_GROUPS = 6 };
+       KSG_OPT_COL_GROUPS = 6, KSG_OPT_BINS = 7 };
 int ksg_ctx_set_option(ksg_ctx ctx, int option, int value);
 const char *ksg_last_error(void);
 
@@ -271,6 +280,16 @@ int ksg_mat_info(ksg_mat A, int64_t info[4]);
 int ksg_mat_traffic_model(ksg_mat A, double *executed, double *csr_model);
 /* One line of text naming the kernel variant and data layout the operator's products use. */
 int ksg_mat_describe(ksg_mat A, char *buf, size_t len);
+/* Host-side check of the binned layout (KSG_OPT_BINS), no device needed and no counterpart in the
+ * reference: y = A x for the CSR block given (has_diag: row r's entry in column r + dshift is the
+ * operator's diagonal), formed as the library forms it -- the binned part and the diagonal through
+ * the same walk of the same arrays as the two kernels, then the remaining entries row by row in
+ * storage order.  info = {binned entries, runs, row blocks, value mode (0 one value, 1 one-byte
+ * indices, 2 eight-byte values), entries left in the CSR, 1 if the diagonal is folded into the
+ * reduce pass}; info[0] == 0: fewer than half of the entries fall into well filled cells and the
+ * block would stay a plain CSR. */
+int ksg_bins_host_check(int64_t nrows, int64_t ncols, const int64_t *rowptr, const int32_t *colidx, const double *val,
+                        int has_diag, int64_t dshift, const double *x, double *y, int64_t info[6]);
 /* number of columns whose x entries the operator keeps packed (KSG_OPT_HOT_COLS), 0 if none */
 int ksg_mat_hot_columns(ksg_mat A, int64_t *nhot);
 

@@ -1,0 +1,721 @@
+/* Binned product for power-law operators: y = B x + d .* x for the part B of a CSR block whose
+ * entries fall into well filled (row block, column block) cells, and the block's diagonal d.
+ *
+ * A gather x[col] of a power-law operator whose x is far larger than the caches costs one
+ * request beyond L2 per entry, and that path serves a fixed number of requests per second
+ * whatever their size.  The binned form turns those gathers into two streaming passes:
+ *
+ *   expand : the columns are cut into blocks of W; a workgroup holds one block's slice of x in
+ *            LDS and streams the entries of those columns (2 bytes of column within the block
+ *            per entry), looks x up in LDS and writes the product where the second pass wants
+ *            it.  The entries of one (row block, column block) cell form a run that is
+ *            consecutive in both orders, so the writes are runs, not scatters; every run is
+ *            filled up with zero products to whole 64-byte pieces and written with non-temporal
+ *            stores (a partly written piece costs the memory system a read of the rest).
+ *   reduce : the rows are cut into blocks of at most H rows and E entries; one wave holds a
+ *            block's partial sums in LDS, streams the block's products (8 bytes) and row
+ *            numbers within the block (2 bytes), adds them up with LDS atomics (one wave per
+ *            block: the order of the additions is fixed), adds the diagonal term and stores y.
+ *            A row longer than E is cut into pieces, each summed by a wave of its own in
+ *            registers; the sums of the pieces are added to the row afterwards, in their order.
+ *
+ * Only cells with at least T entries are binned; what is left (the entries of sparse cells) is a
+ * CSR over the rows it touches, which the tile kernel adds afterwards.  A row's sum is then: its
+ * binned entries by column block, its diagonal entry, its remaining entries in storage order --
+ * the same products as the reference's CSR loop (MatMult_SeqAIJ behind
+ * src/sys/classes/st/impls/shift/shift.c:38) in another order, the same order in every product.
+ *
+ * Tuning variables, read when an operator is created: KSG_BINS_W (columns per column block, a
+ * power of two up to 16384 = 128 KiB of LDS), KSG_BINS_H (rows per row block, up to 8192),
+ * KSG_BINS_E (entries per row block), KSG_BINS_T (fewest entries of a binned cell),
+ * KSG_BINS_TASK_GROUPS (groups of 64 entries per expand workgroup), KSG_BINS_THREADS (threads
+ * of an expand workgroup). */
+#include <algorithm>
+#include <numeric>
+#include <stdlib.h>
+
+#include "ksg_internal.h"
+
+#define BINS_P1_THREADS 1024    /* most threads of an expand workgroup (launch bound); KSG_BINS_THREADS sets the actual number */
+#ifndef BINS_P1_UNROLL
+#define BINS_P1_UNROLL  8
+#endif
+#ifndef BINS_P2_UNROLL
+#define BINS_P2_UNROLL  16
+#endif
+
+/* One step of a wave of the expand pass: BINS_P1_UNROLL groups of 64 entries from group g on.
+ * FULL: all of them lie before g1 (no guards).  VM = 0: every binned entry has the same value
+ * `vc`; 1: one-byte indices into vtab; 2: the 8-byte values themselves. */
+template <int VM, bool FULL>
+__device__ __forceinline__ void bins_expand_step(int64_t g, int64_t g1, int lane, uint64_t below, const double *xs,
+                                                 const uint16_t *__restrict__ col16, const uint8_t *__restrict__ vidx,
+                                                 const double *__restrict__ vtab, const double *__restrict__ val, double vc,
+                                                 const uint32_t *__restrict__ gfirst, const int64_t *__restrict__ D,
+                                                 double *__restrict__ xe) {
+  uint32_t u[BINS_P1_UNROLL], gf[BINS_P1_UNROLL], vi[BINS_P1_UNROLL];
+  double v[BINS_P1_UNROLL], a[BINS_P1_UNROLL];
+  int64_t d[BINS_P1_UNROLL];
+#pragma unroll
+  for (int j = 0; j < BINS_P1_UNROLL; j++) {
+    u[j] = 0; gf[j] = 0; vi[j] = 0; v[j] = vc;
+    if (FULL || g + j < g1) {
+      const int64_t p = (g + j) * 64 + lane;
+      u[j] = __builtin_nontemporal_load(col16 + p);
+      gf[j] = gfirst[g + j];
+      if (VM == 1) vi[j] = __builtin_nontemporal_load(vidx + p);
+      if (VM == 2) v[j] = __builtin_nontemporal_load(val + p);
+    }
+  }
+  /* a lane's run: the run of the group's first entry plus the run starts among the lanes up to it */
+#pragma unroll
+  for (int j = 0; j < BINS_P1_UNROLL; j++) {
+    d[j] = 0;
+    if (FULL || g + j < g1) {                                   /* uniform over the wave */
+      const uint64_t flags = __ballot((u[j] >> 15) != 0);
+      d[j] = D[(int64_t)gf[j] + __popcll(flags & below)];
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < BINS_P1_UNROLL; j++) {
+    a[j] = xs[u[j] & 0x7fffu];
+    if (VM == 1) a[j] *= vtab[vi[j]];
+    else a[j] *= v[j];
+  }
+#pragma unroll
+  for (int j = 0; j < BINS_P1_UNROLL; j++)
+    if (FULL || g + j < g1) __builtin_nontemporal_store(a[j], &xe[(g + j) * 64 + lane + d[j]]);
+}
+
+template <int VM>
+__global__ __launch_bounds__(BINS_P1_THREADS) void k_bins_expand(const int64_t *__restrict__ tasks,
+                                                                  const uint16_t *__restrict__ col16,
+                                                                  const uint8_t *__restrict__ vidx,
+                                                                  const double *__restrict__ vtab,
+                                                                  const double *__restrict__ val, double vc,
+                                                                  const uint32_t *__restrict__ gfirst,
+                                                                  const int64_t *__restrict__ D,
+                                                                  const double *__restrict__ x, int64_t ncols,
+                                                                  double *__restrict__ xe, int W) {
+  extern __shared__ double xs[];
+  const int64_t cb = tasks[3 * (int64_t)blockIdx.x];
+  const int64_t g0 = tasks[3 * (int64_t)blockIdx.x + 1], g1 = tasks[3 * (int64_t)blockIdx.x + 2];
+  const int64_t cbase = cb * W;
+  /* the slice of x: all of a thread's loads in flight together (the last slice may be short:
+   * the loads are clamped to the last column, what lies beyond is never looked up) */
+  const int nthreads = blockDim.x;
+  for (int i0 = 0; i0 < W; i0 += 8 * nthreads) {
+    double t[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      const int64_t col = cbase + i0 + j * nthreads + threadIdx.x;
+      t[j] = x[col < ncols ? col : ncols - 1];
+    }
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      const int i = i0 + j * nthreads + threadIdx.x;
+      if (i < W) xs[i] = t[j];
+    }
+  }
+  if (threadIdx.x == 0) xs[W] = 0.0;                      /* the column of the entries that fill a run up to whole cache lines */
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int NW = nthreads / 64;
+  const uint64_t below = ((2ull << lane) - 1ull) & ~1ull;          /* lanes 1..lane */
+  for (int64_t g = g0 + (int64_t)wave * BINS_P1_UNROLL; g < g1; g += (int64_t)NW * BINS_P1_UNROLL) {
+    if (g + BINS_P1_UNROLL <= g1) bins_expand_step<VM, true>(g, g1, lane, below, xs, col16, vidx, vtab, val, vc, gfirst, D, xe);
+    else bins_expand_step<VM, false>(g, g1, lane, below, xs, col16, vidx, vtab, val, vc, gfirst, D, xe);
+  }
+}
+
+/* One wave per row block: y[r] = sum of the block's products of row r + dv[r] * x[r + dshift].
+ * A block whose first row lies at or beyond nrows is a piece of a long row: it has one row, and
+ * its sum goes to part[r0 - nrows] (k_bins_long_rows adds the pieces to y afterwards). */
+__global__ __launch_bounds__(64) void k_bins_reduce(const int64_t *__restrict__ binp0, const int64_t *__restrict__ binp1,
+                                                    const int32_t *__restrict__ bin_r0, const int32_t *__restrict__ bin_nr,
+                                                    const uint16_t *__restrict__ rowloc, const double *__restrict__ xe,
+                                                    const double *__restrict__ dv, const double *__restrict__ x, int64_t dshift,
+                                                    double *__restrict__ y, int64_t nrows, double *__restrict__ part) {
+  extern __shared__ double acc[];
+  const int64_t b = blockIdx.x;
+  const int64_t p0 = binp0[b], p1 = binp1[b];
+  const int r0 = bin_r0[b], nr = bin_nr[b];
+  const int lane = threadIdx.x;
+  if (r0 >= nrows) {
+    /* one row: every lane sums its share in registers, the wave adds the 64 sums in a fixed order */
+    double t[4] = {0.0, 0.0, 0.0, 0.0};
+    int64_t p = p0 + lane;
+    for (; p + 64 * 3 < p1; p += 64 * 4) {
+      double v[4];
+#pragma unroll
+      for (int j = 0; j < 4; j++) v[j] = __builtin_nontemporal_load(xe + p + 64 * j);
+#pragma unroll
+      for (int j = 0; j < 4; j++) t[j] += v[j];
+    }
+    for (; p < p1; p += 64) t[0] += xe[p];
+    double s = (t[0] + t[1]) + (t[2] + t[3]);
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+    if (lane == 0) part[r0 - nrows] = s;
+    return;
+  }
+  for (int i = lane; i < nr; i += 64) acc[i] = 0.0;
+  int64_t p = p0 + lane;
+  for (; p + 64 * (BINS_P2_UNROLL - 1) < p1; p += 64 * BINS_P2_UNROLL) {
+    uint16_t r[BINS_P2_UNROLL];
+    double v[BINS_P2_UNROLL];
+#pragma unroll
+    for (int j = 0; j < BINS_P2_UNROLL; j++) {
+      r[j] = __builtin_nontemporal_load(rowloc + p + 64 * j);
+      v[j] = __builtin_nontemporal_load(xe + p + 64 * j);
+    }
+#pragma unroll
+    for (int j = 0; j < BINS_P2_UNROLL; j++) atomicAdd(&acc[r[j]], v[j]);
+  }
+  for (; p < p1; p += 64) atomicAdd(&acc[rowloc[p]], xe[p]);
+  /* the wave's own LDS operations complete in order: no barrier between its adds and its reads */
+  for (int i0 = 0; i0 < nr; i0 += 64 * 8) {
+    double dd[8], xx[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      const int i = i0 + 64 * j + lane;
+      dd[j] = 0.0; xx[j] = 0.0;
+      if (dv && i < nr) { dd[j] = dv[r0 + i]; xx[j] = x[r0 + i + dshift]; }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      const int i = i0 + 64 * j + lane;
+      if (i < nr) y[r0 + i] = dv ? fma(dd[j], xx[j], acc[i]) : acc[i];
+    }
+  }
+}
+
+/* y[row] += the sums of the row's pieces, in their order (one thread per long row) */
+__global__ __launch_bounds__(KSG_BLOCK) void k_bins_long_rows(const int32_t *__restrict__ rows, const int32_t *__restrict__ first,
+                                                              int nlong, const double *__restrict__ part, double *__restrict__ y) {
+  const int j = blockIdx.x * KSG_BLOCK + threadIdx.x;
+  if (j >= nlong) return;
+  double s = 0.0;
+  for (int k = first[j]; k < first[j + 1]; k++) s += part[k];
+  y[rows[j]] += s;
+}
+
+template <class T>
+static int bins_upload(T **dst, const T *src, size_t count) {
+  *dst = NULL;
+  hipError_t e = hipMalloc((void **)dst, (count ? count : 1) * sizeof(T));
+  if (e != hipSuccess) KSG_FAIL(KSG_ERR_MEM, "binned operator upload: %zu bytes: %s", count * sizeof(T), hipGetErrorString(e));
+  if (count) KSG_HIP(hipMemcpy(*dst, src, count * sizeof(T), hipMemcpyHostToDevice));
+  return KSG_OK;
+}
+
+static int env_int(const char *name, int dflt) {
+  const char *e = getenv(name);
+  return e && atoi(e) > 0 ? atoi(e) : dflt;
+}
+
+/* A run: `real` entries of one (unit, column block) cell, filled up with zero products to `cnt`, a
+ * multiple of BINS_RUN_ALIGN: every run then starts on a 64-byte boundary of the product array and
+ * covers whole 64-byte pieces.  Measured (tools/bins_stream_probe.hip, runs of 64 products scattered
+ * over 2 GiB): runs that start 24 bytes off a line 1.07 ms against 0.61 ms for aligned ones; with
+ * non-temporal stores whole 64-byte pieces are enough (0.58-0.67 ms), with plain stores a half
+ * written 128-byte line still costs (0.77-0.87 ms). */
+#ifndef BINS_RUN_ALIGN
+#define BINS_RUN_ALIGN 8
+#endif
+struct bins_seg { int32_t c, cnt, real; int64_t pos2, pos1; };
+
+void ksg_bins_free(ksg_bins *B) {
+  if (B->col16) hipFree(B->col16);
+  if (B->vidx) hipFree(B->vidx);
+  if (B->vtab) hipFree(B->vtab);
+  if (B->val) hipFree(B->val);
+  if (B->gfirst) hipFree(B->gfirst);
+  if (B->D) hipFree(B->D);
+  if (B->tasks) hipFree(B->tasks);
+  if (B->rowloc) hipFree(B->rowloc);
+  if (B->binp0) hipFree(B->binp0);
+  if (B->binp1) hipFree(B->binp1);
+  if (B->bin_r0) hipFree(B->bin_r0);
+  if (B->bin_nr) hipFree(B->bin_nr);
+  if (B->dv) hipFree(B->dv);
+  if (B->long_rows) hipFree(B->long_rows);
+  if (B->long_first) hipFree(B->long_first);
+  if (B->piece_row) hipFree(B->piece_row);
+  if (B->part) hipFree(B->part);
+  if (B->xe) hipFree(B->xe);
+  memset(B, 0, sizeof(*B));
+}
+
+/* The binned part on the host, array for array what the device holds. */
+struct bins_host {
+  int64_t nent = 0, nreal = 0, nent1 = 0, nseg = 0, nbins = 0, ntasks = 0, nrows = 0, dshift = 0;
+  int W = 0, H = 0, vmode = 2;
+  bool fold_diag = false;
+  double vconst = 0.0;
+  std::vector<uint16_t> col16, rowloc;
+  std::vector<uint8_t> vidx;
+  std::vector<double> vtab, val, dv;
+  std::vector<uint32_t> gfirst;
+  std::vector<int64_t> D, tasks, binp0, binp1;
+  std::vector<int32_t> r0s, nrs;
+  std::vector<int32_t> long_rows, long_first, piece_row;   /* rows cut into pieces; their pieces long_first[j] .. long_first[j+1]; row of every piece */
+};
+
+/* a unit of the reduce pass: rows r0 .. r0+nr of the block (those longer than E skipped), or, with
+ * e0 >= 0, the entries e0 .. e1 of the long row r0 (piece number `piece`) */
+struct bins_block { int32_t r0, nr, piece; int64_t e0, e1; };
+
+/* Splits the block (nrows x ncols CSR) into its binned part *B (with the diagonal, when every row
+ * has exactly one entry in column r + dshift and has_diag says that this is the operator's
+ * diagonal) and the rest, returned as a CSR over the rows it touches: row i of lrp/lci/lva is row
+ * lrows[i] of the block.  When fewer than half of the entries can be binned nothing is built
+ * (B->nent == 0, the vectors stay empty). */
+static void bins_build_host(bins_host *B, int64_t nrows, int64_t ncols, const int64_t *rowptr, const int32_t *colidx,
+                            const double *val, bool has_diag, int64_t dshift, std::vector<int32_t> &lrows, std::vector<int64_t> &lrp,
+                            std::vector<int32_t> &lci, std::vector<double> &lva) {
+  *B = bins_host();
+  lrows.clear(); lrp.clear(); lci.clear(); lva.clear();
+  /* R-MAT scale 26 (1.13e9 entries): 7.05 ms per product with H = 2048, 7.11 with 4096, 7.21 with 8192 (E = 131072); T = 6: 7.26;
+   * scale 24: W = 16384 1.61 ms, 8192 1.63, 4096 1.69 (profiles/r02_spmv_rmat_binned.txt) */
+  int W = env_int("KSG_BINS_W", 16384), H = env_int("KSG_BINS_H", 2048);
+  const int64_t E = env_int("KSG_BINS_E", 65536);
+  const int T = env_int("KSG_BINS_T", 4);
+  int wshift = 0;
+  while ((1 << wshift) < W) wshift++;
+  W = 1 << wshift;
+  if (W > 16384) W = 16384, wshift = 14;                   /* 128 KiB of x in LDS */
+  if (W < 64) W = 64, wshift = 6;
+  if (H > 8192) H = 8192;                                  /* 64 KiB of sums in LDS */
+  if (H < 64) H = 64;
+  const int64_t nnz = rowptr[nrows];
+  const int64_t NC = (ncols + W - 1) >> wshift;
+  if (nnz == 0 || nrows == 0 || NC > (int64_t)INT32_MAX || nrows > (int64_t)INT32_MAX / 2) return;
+
+  /* the diagonal is folded into the reduce pass only when every row has it exactly once */
+  bool fold = has_diag;
+  for (int64_t r = 0; r < nrows && fold; r++) {
+    int seen = 0;
+    for (int64_t p = rowptr[r]; p < rowptr[r + 1]; p++) if ((int64_t)colidx[p] == r + dshift) seen++;
+    if (seen != 1) fold = false;
+  }
+
+  /* row blocks: consecutive rows, at most H rows and E entries.  A row longer than E belongs to a
+   * block (which stores its diagonal term) but its entries are cut into pieces of at most E, each
+   * a unit of its own whose sum is added to the row afterwards. */
+  std::vector<bins_block> blocks;
+  for (int64_t r = 0; r < nrows;) {
+    const int64_t start = r;
+    int64_t ent = 0;
+    while (r < nrows && r - start < H) {
+      int64_t l = rowptr[r + 1] - rowptr[r];
+      if (l > E) l = 0;
+      if (ent + l > E && r > start) break;
+      ent += l; r++;
+    }
+    blocks.push_back({(int32_t)start, (int32_t)(r - start), -1, -1, -1});
+  }
+  B->long_first.push_back(0);
+  for (int64_t r = 0; r < nrows; r++) {
+    const int64_t l = rowptr[r + 1] - rowptr[r];
+    if (l <= E) continue;
+    const int64_t np = (l + E - 1) / E;
+    for (int64_t k = 0; k < np; k++) {
+      blocks.push_back({(int32_t)r, 1, (int32_t)B->piece_row.size(), rowptr[r] + k * l / np, rowptr[r] + (k + 1) * l / np});
+      B->piece_row.push_back((int32_t)r);
+    }
+    B->long_rows.push_back((int32_t)r);
+    B->long_first.push_back((int32_t)B->piece_row.size());
+  }
+  const int64_t NB = (int64_t)blocks.size();
+
+  /* cells: per unit the entries per column block; cells of at least T entries (any cell of a
+   * piece) are binned, laid out unit by unit, within a unit by column block */
+  std::vector<bins_seg> S;
+  std::vector<int64_t> segb((size_t)NB + 1, 0);            /* runs of unit b: S[segb[b] .. segb[b+1]) */
+  std::vector<int64_t> bp0((size_t)NB), bp1((size_t)NB);
+  {
+    std::vector<int32_t> cnt((size_t)NC, 0), touched;
+    int64_t pos2 = 0, nreal = 0;
+    for (int64_t b = 0; b < NB; b++) {
+      const bins_block &k = blocks[(size_t)b];
+      touched.clear();
+      bp0[b] = pos2;
+      for (int64_t r = k.r0; r < (int64_t)k.r0 + k.nr; r++) {
+        int64_t pa = rowptr[r], pb = rowptr[r + 1];
+        if (k.e0 >= 0) { pa = k.e0; pb = k.e1; }
+        else if (pb - pa > E) continue;
+        for (int64_t p = pa; p < pb; p++) {
+          if (fold && (int64_t)colidx[p] == r + dshift) continue;
+          const int32_t cb = colidx[p] >> wshift;
+          if (cnt[cb]++ == 0) touched.push_back(cb);
+        }
+      }
+      std::sort(touched.begin(), touched.end());
+      for (int32_t cb : touched) {
+        if (cnt[cb] >= T || k.e0 >= 0) {
+          const int32_t padded = (cnt[cb] + BINS_RUN_ALIGN - 1) / BINS_RUN_ALIGN * BINS_RUN_ALIGN;
+          S.push_back({cb, padded, cnt[cb], pos2, 0}); pos2 += padded; nreal += cnt[cb];
+        }
+        cnt[cb] = 0;
+      }
+      segb[b + 1] = (int64_t)S.size();
+      bp1[b] = pos2;
+    }
+    B->nent = pos2; B->nreal = nreal;
+  }
+  if (B->nreal * 2 < nnz || S.size() >= (size_t)UINT32_MAX - (size_t)NC) { *B = bins_host(); return; }
+  B->W = W; B->H = H; B->nrows = nrows; B->fold_diag = fold; B->dshift = dshift;
+
+  /* the expand order: by column block, within it by unit; every column block's stream is padded
+   * to whole groups of 64 entries (the padding forms a run of its own whose products land in 64
+   * spare slots behind the last product) */
+  const int64_t nseg = (int64_t)S.size();
+  std::vector<int64_t> centries((size_t)NC, 0), csegs((size_t)NC, 0);
+  for (int64_t i = 0; i < nseg; i++) { centries[S[i].c] += S[i].cnt; csegs[S[i].c]++; }
+  std::vector<int64_t> cpos((size_t)NC + 1, 0), cseg((size_t)NC + 1, 0);
+  for (int64_t cb = 0; cb < NC; cb++) {
+    const int64_t pad = (64 - centries[cb] % 64) % 64;
+    cpos[cb + 1] = cpos[cb] + centries[cb] + pad;
+    cseg[cb + 1] = cseg[cb] + csegs[cb] + (pad ? 1 : 0);
+  }
+  const int64_t nent1 = cpos[NC], nseg1 = cseg[NC], ngroups = nent1 / 64;
+  std::vector<int64_t> &D = B->D;
+  D.resize((size_t)nseg1);
+  std::vector<int64_t> P1((size_t)nseg1 + 1);
+  {
+    std::vector<int64_t> fseg(cseg.begin(), cseg.end() - 1), fpos(cpos.begin(), cpos.end() - 1);
+    for (int64_t i = 0; i < nseg; i++) {
+      const int32_t cb = S[i].c;
+      const int64_t j = fseg[cb]++, p1 = fpos[cb];
+      fpos[cb] += S[i].cnt;
+      S[i].pos1 = p1;
+      D[j] = S[i].pos2 - p1;
+      P1[j] = p1;
+    }
+    for (int64_t cb = 0; cb < NC; cb++)
+      if (fpos[cb] < cpos[cb + 1]) { const int64_t j = fseg[cb]++; D[j] = B->nent - fpos[cb]; P1[j] = fpos[cb]; }
+    P1[nseg1] = nent1;
+  }
+  std::vector<uint32_t> &gfirst = B->gfirst;
+  gfirst.resize((size_t)ngroups);
+  for (int64_t j = 0; j < nseg1; j++)
+    for (int64_t g = (P1[j] + 63) / 64; g * 64 < P1[j + 1]; g++) gfirst[g] = (uint32_t)j;
+  { std::vector<int64_t>().swap(P1); }
+
+  /* the entries themselves: columns and values in the expand order, rows in the reduce order, the
+   * diagonal as a dense vector; what is not binned goes to the CSR of the remaining entries (the
+   * row blocks come first and in row order, so that CSR is in row order too) */
+  std::vector<uint16_t> &col16 = B->col16, &rowloc = B->rowloc;
+  std::vector<double> &val1 = B->val;
+  col16.assign((size_t)nent1, 0); rowloc.resize((size_t)B->nent);
+  val1.assign((size_t)nent1, 0.0);
+  if (fold) B->dv.assign((size_t)nrows, 0.0);
+  for (int64_t cb = 0; cb < NC; cb++) {
+    const int64_t p = cpos[cb] + centries[cb];
+    if (p < cpos[cb + 1]) col16[(size_t)p] = 0x8000u;       /* first padding entry opens the padding run */
+  }
+  lci.reserve((size_t)(nnz - B->nreal)); lva.reserve((size_t)(nnz - B->nreal));
+  std::vector<uint8_t> pad((size_t)nent1, 0);             /* entries that stand for nothing: the fill of the runs and of the groups */
+  for (int64_t cb = 0; cb < NC; cb++)
+    for (int64_t p = cpos[cb] + centries[cb]; p < cpos[cb + 1]; p++) pad[(size_t)p] = 1;
+  lrp.push_back(0);
+  {
+    std::vector<int64_t> segid((size_t)NC, -1);
+    std::vector<int32_t> fill((size_t)NC, 0);
+    for (int64_t b = 0; b < NB; b++) {
+      const bins_block &k = blocks[(size_t)b];
+      for (int64_t i = segb[b]; i < segb[b + 1]; i++) { segid[S[i].c] = i; fill[S[i].c] = 0; }
+      for (int64_t r = k.r0; r < (int64_t)k.r0 + k.nr; r++) {
+        int64_t pa = rowptr[r], pb = rowptr[r + 1];
+        const bool longrow = k.e0 < 0 && pb - pa > E;       /* its entries are binned with its pieces */
+        if (k.e0 >= 0) { pa = k.e0; pb = k.e1; }
+        const size_t before = lci.size();
+        for (int64_t p = pa; p < pb; p++) {
+          if (fold && (int64_t)colidx[p] == r + dshift) { if (k.e0 < 0) B->dv[(size_t)r] = val[p]; continue; }
+          if (longrow) continue;
+          const int32_t cb = colidx[p] >> wshift;
+          const int64_t i = segid[cb];
+          if (i < 0) { lci.push_back(colidx[p]); lva.push_back(val[p]); continue; }
+          const int32_t f = fill[cb]++;
+          col16[(size_t)(S[i].pos1 + f)] = (uint16_t)((colidx[p] & (W - 1)) | (f == 0 ? 0x8000 : 0));
+          val1[(size_t)(S[i].pos1 + f)] = val[p];
+          rowloc[(size_t)(S[i].pos2 + f)] = (uint16_t)(r - k.r0);
+        }
+        if (lci.size() > before) { lrows.push_back((int32_t)r); lrp.push_back((int64_t)lci.size()); }
+      }
+      for (int64_t i = segb[b]; i < segb[b + 1]; i++) {
+        segid[S[i].c] = -1;
+        for (int32_t f = S[i].real; f < S[i].cnt; f++) {     /* the fill: column W (x = 0 there), any row of the unit */
+          col16[(size_t)(S[i].pos1 + f)] = (uint16_t)W;
+          pad[(size_t)(S[i].pos1 + f)] = 1;
+          rowloc[(size_t)(S[i].pos2 + f)] = (uint16_t)((f - S[i].real) % k.nr);
+        }
+      }
+    }
+  }
+  { std::vector<bins_seg>().swap(S); }
+
+  /* every unit stores its rows of y (or its piece's sum); the units with the most products are
+   * started first */
+  {
+    std::vector<int64_t> order((size_t)NB);
+    std::iota(order.begin(), order.end(), (int64_t)0);
+    std::stable_sort(order.begin(), order.end(), [&](int64_t a, int64_t b) { return bp1[a] - bp0[a] > bp1[b] - bp0[b]; });
+    B->binp0.resize((size_t)NB); B->binp1.resize((size_t)NB); B->r0s.resize((size_t)NB); B->nrs.resize((size_t)NB);
+    for (int64_t i = 0; i < NB; i++) {
+      const bins_block &k = blocks[(size_t)order[(size_t)i]];
+      B->binp0[(size_t)i] = bp0[order[(size_t)i]]; B->binp1[(size_t)i] = bp1[order[(size_t)i]];
+      B->r0s[(size_t)i] = k.e0 >= 0 ? (int32_t)(nrows + k.piece) : k.r0;
+      B->nrs[(size_t)i] = k.nr;
+    }
+    B->nbins = NB;
+  }
+
+  /* values: one, at most 256, or as they are (the padding entries take no part) */
+  std::vector<double> &tab = B->vtab;
+  std::vector<uint8_t> &vidx = B->vidx;
+  B->vmode = 2;
+  {
+    if (ksg_build_value_table(nent1, val1.data(), pad.data(), 256, tab, vidx)) {
+      int distinct = 0;
+      for (int64_t p = 0; p < nent1; p++) if (!pad[(size_t)p]) distinct = std::max(distinct, (int)vidx[(size_t)p] + 1);
+      if (distinct == 1) { B->vmode = 0; B->vconst = tab[0]; }
+      else B->vmode = 1;
+    }
+    if (B->vmode != 1) { std::vector<uint8_t>().swap(vidx); tab.clear(); }
+    if (B->vmode != 2) std::vector<double>().swap(val1);
+  }
+
+  /* expand tasks: a column block's groups in pieces of at most TG groups, the longest first */
+  const int64_t TG = env_int("KSG_BINS_TASK_GROUPS", 2048);
+  {
+    std::vector<int64_t> t3;
+    for (int64_t cb = 0; cb < NC; cb++)
+      for (int64_t g = cpos[cb] / 64; g < cpos[cb + 1] / 64; g += TG) {
+        t3.push_back(cb); t3.push_back(g); t3.push_back(std::min(g + TG, cpos[cb + 1] / 64));
+      }
+    const int64_t nt = (int64_t)t3.size() / 3;
+    std::vector<int64_t> order((size_t)nt);
+    std::iota(order.begin(), order.end(), (int64_t)0);
+    std::stable_sort(order.begin(), order.end(), [&](int64_t a, int64_t b) { return t3[3 * a + 2] - t3[3 * a + 1] > t3[3 * b + 2] - t3[3 * b + 1]; });
+    B->tasks.resize(t3.size());
+    for (int64_t i = 0; i < nt; i++)
+      for (int k = 0; k < 3; k++) B->tasks[(size_t)(3 * i + k)] = t3[(size_t)(3 * order[(size_t)i] + k)];
+    B->ntasks = nt;
+  }
+  B->nent1 = nent1; B->nseg = nseg1;
+}
+
+/* y = B x + d .* x on the host, walking the arrays the way the two kernels do (the lanes of a
+ * group find their run from the group's first run and the run flags below them; one sum per row
+ * block in the order of the product stream). */
+static void bins_emulate(const bins_host &B, const double *x, int64_t ncols, double *y) {
+  if (!B.nent) return;
+  std::vector<double> xe((size_t)B.nent + 64, 0.0), xs((size_t)B.W + 1, 0.0), acc((size_t)B.H);
+  for (int64_t t = 0; t < B.ntasks; t++) {
+    const int64_t cb = B.tasks[3 * t];
+    for (int i = 0; i < B.W; i++) xs[i] = cb * B.W + i < ncols ? x[cb * B.W + i] : 0.0;
+    for (int64_t g = B.tasks[3 * t + 1]; g < B.tasks[3 * t + 2]; g++) {
+      uint64_t flags = 0;
+      for (int l = 0; l < 64; l++) if (B.col16[(size_t)(g * 64 + l)] & 0x8000u) flags |= 1ull << l;
+      for (int l = 0; l < 64; l++) {
+        const int64_t p = g * 64 + l;
+        const uint64_t below = l == 63 ? ~1ull : (((2ull << l) - 1ull) & ~1ull);
+        const int64_t d = B.D[(size_t)((int64_t)B.gfirst[(size_t)g] + __builtin_popcountll(flags & below))];
+        double a = xs[B.col16[(size_t)p] & 0x7fffu];
+        a *= B.vmode == 0 ? B.vconst : B.vmode == 1 ? B.vtab[B.vidx[(size_t)p]] : B.val[(size_t)p];
+        xe[(size_t)(p + d)] = a;
+      }
+    }
+  }
+  std::vector<double> part(B.piece_row.size() + 1, 0.0);
+  for (int64_t b = 0; b < B.nbins; b++) {
+    const int64_t r0 = B.r0s[(size_t)b];
+    if (r0 >= B.nrows) {                                   /* a piece of a long row: 64 lane sums of 4 partial sums each, then the wave's tree */
+      double t[64][4];
+      for (int l = 0; l < 64; l++) for (int j = 0; j < 4; j++) t[l][j] = 0.0;
+      const int64_t p0 = B.binp0[(size_t)b], p1 = B.binp1[(size_t)b];
+      for (int l = 0; l < 64; l++) {
+        int64_t p = p0 + l;
+        for (; p + 64 * 3 < p1; p += 64 * 4) for (int j = 0; j < 4; j++) t[l][j] += xe[(size_t)(p + 64 * j)];
+        for (; p < p1; p += 64) t[l][0] += xe[(size_t)p];
+      }
+      double sl[128];
+      for (int l = 0; l < 64; l++) { sl[l] = (t[l][0] + t[l][1]) + (t[l][2] + t[l][3]); sl[64 + l] = 0.0; }
+      for (int off = 32; off > 0; off >>= 1) for (int l = 0; l < 64; l++) sl[l] += l + off < 64 ? sl[l + off] : sl[l];
+      part[(size_t)(r0 - B.nrows)] = sl[0];
+      continue;
+    }
+    for (int i = 0; i < B.nrs[(size_t)b]; i++) acc[i] = 0.0;
+    for (int64_t p = B.binp0[(size_t)b]; p < B.binp1[(size_t)b]; p++) acc[B.rowloc[(size_t)p]] += xe[(size_t)p];
+    for (int i = 0; i < B.nrs[(size_t)b]; i++)
+      y[r0 + i] = B.fold_diag ? fma(B.dv[(size_t)(r0 + i)], x[r0 + i + B.dshift], acc[i]) : acc[i];
+  }
+  for (size_t j = 0; j < B.long_rows.size(); j++) {
+    double sum = 0.0;
+    for (int k = B.long_first[j]; k < B.long_first[j + 1]; k++) sum += part[(size_t)k];
+    y[B.long_rows[j]] += sum;
+  }
+}
+
+/* Host-side check of the binned layout, no device needed: y = A x for the CSR block given, formed
+ * as the library forms it (the binned part and the diagonal through the same walk of the same arrays
+ * as the kernels, then the remaining entries row by row in storage order); info = {binned entries,
+ * runs, row blocks, value mode (0 one value, 1 one-byte indices, 2 eight-byte values), entries left
+ * in the CSR, 1 if the diagonal is folded into the reduce pass}.  The tuning variables
+ * KSG_BINS_W/H/E/T apply as in ksg_mat_create_csr. */
+extern "C" int ksg_bins_host_check(int64_t nrows, int64_t ncols, const int64_t *rowptr, const int32_t *colidx, const double *val,
+                                   int has_diag, int64_t dshift, const double *x, double *y, int64_t info[6]) {
+  if (!rowptr || !x || !y || nrows < 0 || ncols < 0 || (rowptr[nrows] && (!colidx || !val)))
+    KSG_FAIL(KSG_ERR_ARG, "ksg_bins_host_check: bad arguments");
+  bins_host B;
+  std::vector<int32_t> lrows, lci;
+  std::vector<int64_t> lrp;
+  std::vector<double> lva;
+  bins_build_host(&B, nrows, ncols, rowptr, colidx, val, has_diag != 0, dshift, lrows, lrp, lci, lva);
+  if (!B.nent) {
+    for (int64_t r = 0; r < nrows; r++) {
+      double s = 0.0;
+      for (int64_t p = rowptr[r]; p < rowptr[r + 1]; p++) s += val[p] * x[colidx[p]];
+      y[r] = s;
+    }
+  } else {
+    bins_emulate(B, x, ncols, y);
+    for (size_t i = 0; i < lrows.size(); i++) {
+      double s = 0.0;
+      for (int64_t p = lrp[i]; p < lrp[i + 1]; p++) s += lva[(size_t)p] * x[lci[(size_t)p]];
+      y[lrows[i]] += s;
+    }
+  }
+  if (info) {
+    info[0] = B.nreal; info[1] = B.nseg; info[2] = B.nbins; info[3] = B.vmode;
+    info[4] = B.nent ? (int64_t)lci.size() : rowptr[nrows]; info[5] = B.fold_diag ? 1 : 0;
+  }
+  return KSG_OK;
+}
+
+/* The same split, with the binned part uploaded as *B. */
+int ksg_bins_build(ksg_ctx c, ksg_bins *B, int64_t nrows, int64_t ncols, const int64_t *rowptr, const int32_t *colidx,
+                   const double *val, bool has_diag, int64_t dshift, std::vector<int32_t> &lrows, std::vector<int64_t> &lrp,
+                   std::vector<int32_t> &lci, std::vector<double> &lva) {
+  memset(B, 0, sizeof(*B));
+  bins_host Hb;
+  bins_build_host(&Hb, nrows, ncols, rowptr, colidx, val, has_diag, dshift, lrows, lrp, lci, lva);
+  if (!Hb.nent) return KSG_OK;
+  B->threads = env_int("KSG_BINS_THREADS", 1024) / 64 * 64;
+  if (B->threads < 64) B->threads = 64;
+  if (B->threads > BINS_P1_THREADS) B->threads = BINS_P1_THREADS;
+  B->nent = Hb.nent; B->nreal = Hb.nreal; B->nent1 = Hb.nent1; B->nseg = Hb.nseg; B->nbins = Hb.nbins; B->ntasks = Hb.ntasks;
+  B->nrows = Hb.nrows; B->dshift = Hb.dshift; B->W = Hb.W; B->H = Hb.H; B->vmode = Hb.vmode; B->vconst = Hb.vconst;
+  KSG_HIP(hipSetDevice(c->device));
+  KSG_CHK(bins_upload(&B->col16, Hb.col16.data(), Hb.col16.size()));
+  if (B->vmode == 1) { KSG_CHK(bins_upload(&B->vidx, Hb.vidx.data(), Hb.vidx.size())); KSG_CHK(bins_upload(&B->vtab, Hb.vtab.data(), Hb.vtab.size())); }
+  if (B->vmode == 2) KSG_CHK(bins_upload(&B->val, Hb.val.data(), Hb.val.size()));
+  KSG_CHK(bins_upload(&B->gfirst, Hb.gfirst.data(), Hb.gfirst.size()));
+  KSG_CHK(bins_upload(&B->D, Hb.D.data(), Hb.D.size()));
+  KSG_CHK(bins_upload(&B->tasks, Hb.tasks.data(), Hb.tasks.size()));
+  KSG_CHK(bins_upload(&B->rowloc, Hb.rowloc.data(), Hb.rowloc.size()));
+  KSG_CHK(bins_upload(&B->binp0, Hb.binp0.data(), Hb.binp0.size()));
+  KSG_CHK(bins_upload(&B->binp1, Hb.binp1.data(), Hb.binp1.size()));
+  KSG_CHK(bins_upload(&B->bin_r0, Hb.r0s.data(), Hb.r0s.size()));
+  KSG_CHK(bins_upload(&B->bin_nr, Hb.nrs.data(), Hb.nrs.size()));
+  if (Hb.fold_diag) KSG_CHK(bins_upload(&B->dv, Hb.dv.data(), Hb.dv.size()));
+  B->nlong = (int64_t)Hb.long_rows.size(); B->npieces = (int64_t)Hb.piece_row.size();
+  if (B->nlong) {
+    KSG_CHK(bins_upload(&B->long_rows, Hb.long_rows.data(), Hb.long_rows.size()));
+    KSG_CHK(bins_upload(&B->long_first, Hb.long_first.data(), Hb.long_first.size()));
+    KSG_CHK(bins_upload(&B->piece_row, Hb.piece_row.data(), Hb.piece_row.size()));
+    hipError_t e2 = hipMalloc((void **)&B->part, (size_t)B->npieces * sizeof(double));
+    if (e2 != hipSuccess) KSG_FAIL(KSG_ERR_MEM, "binned operator: sums of the pieces of long rows: %s", hipGetErrorString(e2));
+  }
+  hipError_t e = hipMalloc((void **)&B->xe, (size_t)(B->nent + 64) * sizeof(double));
+  if (e != hipSuccess) KSG_FAIL(KSG_ERR_MEM, "binned operator: %zu bytes of products: %s", (size_t)(B->nent + 64) * sizeof(double), hipGetErrorString(e));
+  /* the expand kernel's slice of x may exceed the 64 KiB a kernel gets without asking */
+  const int lds = (B->W + 1) * (int)sizeof(double);
+  KSG_HIP(hipFuncSetAttribute((const void *)k_bins_expand<0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+  KSG_HIP(hipFuncSetAttribute((const void *)k_bins_expand<1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+  KSG_HIP(hipFuncSetAttribute((const void *)k_bins_expand<2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+  return KSG_OK;
+}
+
+/* y = B x + d .* x on `st` (every row of the block is stored). */
+int ksg_bins_mult(const ksg_bins *B, const double *x, int64_t ncols, double *y, hipStream_t st) {
+  if (!B->nent) return KSG_OK;
+  const size_t lds1 = ((size_t)B->W + 1) * sizeof(double), lds2 = (size_t)B->H * sizeof(double);
+  const dim3 g1((unsigned)B->ntasks), b1((unsigned)B->threads);
+  if (B->vmode == 0)
+    hipLaunchKernelGGL(k_bins_expand<0>, g1, b1, lds1, st, B->tasks, B->col16, B->vidx, B->vtab, B->val, B->vconst, B->gfirst, B->D, x, ncols, B->xe, B->W);
+  else if (B->vmode == 1)
+    hipLaunchKernelGGL(k_bins_expand<1>, g1, b1, lds1, st, B->tasks, B->col16, B->vidx, B->vtab, B->val, 1.0, B->gfirst, B->D, x, ncols, B->xe, B->W);
+  else
+    hipLaunchKernelGGL(k_bins_expand<2>, g1, b1, lds1, st, B->tasks, B->col16, B->vidx, B->vtab, B->val, 1.0, B->gfirst, B->D, x, ncols, B->xe, B->W);
+  hipLaunchKernelGGL(k_bins_reduce, dim3((unsigned)B->nbins), dim3(64), lds2, st, B->binp0, B->binp1, B->bin_r0, B->bin_nr, B->rowloc, B->xe,
+                     B->dv, x, B->dshift, y, B->nrows, B->part);
+  if (B->nlong)
+    hipLaunchKernelGGL(k_bins_long_rows, dim3((unsigned)((B->nlong + KSG_BLOCK - 1) / KSG_BLOCK)), dim3(KSG_BLOCK), 0, st, B->long_rows,
+                       B->long_first, (int)B->nlong, B->part, y);
+  KSG_HIP(hipGetLastError());
+  return KSG_OK;
+}
+
+/* Bytes one binned product moves: expand reads the 2-byte columns (+ value bytes), one offset
+ * per run, 4 bytes per group of 64 and the slice of x per task, and writes the products; reduce
+ * reads products and 2-byte rows, the diagonal and x at the rows, and writes y. */
+double ksg_bins_bytes(const ksg_bins *B) {
+  if (!B->nent) return 0.0;
+  const double vb = B->vmode == 2 ? 8.0 : B->vmode == 1 ? 1.0 : 0.0;
+  return (2.0 + vb) * (double)B->nent1 + 8.0 * (double)B->nseg + 4.0 * (double)(B->nent1 / 64) +
+         (8.0 * B->W + 24.0) * (double)B->ntasks + 8.0 * (double)B->nent +
+         10.0 * (double)B->nent + 24.0 * (double)B->nbins + (B->dv ? 24.0 : 8.0) * (double)B->nrows;
+}
+
+/* The binned entries and the folded diagonal back on the host as (row, column, value) triplets,
+ * in no particular order. */
+int ksg_bins_to_host(const ksg_bins *B, std::vector<int32_t> &rows, std::vector<int32_t> &cols, std::vector<double> &vals) {
+  rows.clear(); cols.clear(); vals.clear();
+  if (!B->nent) return KSG_OK;
+  std::vector<uint16_t> col16((size_t)B->nent1), rowloc((size_t)B->nent);
+  std::vector<uint32_t> gfirst((size_t)(B->nent1 / 64));
+  std::vector<int64_t> D((size_t)B->nseg), tasks((size_t)B->ntasks * 3), binp0((size_t)B->nbins);
+  std::vector<int32_t> r0s((size_t)B->nbins);
+  std::vector<uint8_t> vidx;
+  std::vector<double> tab, val1, dv;
+#define DL(dst, src) KSG_HIP(hipMemcpy((dst).data(), (src), (dst).size() * sizeof((dst)[0]), hipMemcpyDeviceToHost))
+  DL(col16, B->col16); DL(rowloc, B->rowloc); DL(gfirst, B->gfirst); DL(D, B->D); DL(tasks, B->tasks);
+  DL(binp0, B->binp0); DL(r0s, B->bin_r0);
+  if (B->vmode == 1) { vidx.resize((size_t)B->nent1); tab.resize(256); DL(vidx, B->vidx); DL(tab, B->vtab); }
+  if (B->vmode == 2) { val1.resize((size_t)B->nent1); DL(val1, B->val); }
+  if (B->dv) { dv.resize((size_t)B->nrows); DL(dv, B->dv); }
+  std::vector<int32_t> piece_row((size_t)B->npieces);
+  if (B->npieces) DL(piece_row, B->piece_row);
+#undef DL
+  /* the row blocks that hold products, by their first product */
+  std::vector<int64_t> binp1((size_t)B->nbins);
+  KSG_HIP(hipMemcpy(binp1.data(), B->binp1, binp1.size() * sizeof(int64_t), hipMemcpyDeviceToHost));
+  std::vector<int64_t> order;
+  for (int64_t b = 0; b < B->nbins; b++) if (binp1[(size_t)b] > binp0[(size_t)b]) order.push_back(b);
+  std::sort(order.begin(), order.end(), [&](int64_t a, int64_t b) { return binp0[(size_t)a] < binp0[(size_t)b]; });
+  std::vector<int64_t> starts(order.size());
+  for (size_t i = 0; i < order.size(); i++) starts[i] = binp0[(size_t)order[i]];
+  rows.reserve((size_t)(B->nent + (B->dv ? B->nrows : 0))); cols.reserve(rows.capacity()); vals.reserve(rows.capacity());
+  for (int64_t t = 0; t < B->ntasks; t++) {
+    const int64_t cb = tasks[3 * t];
+    for (int64_t g = tasks[3 * t + 1]; g < tasks[3 * t + 2]; g++) {
+      int64_t seg = gfirst[(size_t)g];
+      for (int l = 0; l < 64; l++) {
+        const int64_t p = g * 64 + l;
+        if (l && (col16[(size_t)p] & 0x8000u)) seg++;
+        const int64_t q = p + D[(size_t)seg];
+        if (q >= B->nent || (col16[(size_t)p] & 0x7fffu) == (unsigned)B->W) continue;   /* fill of a group or of a run */
+        /* the block that holds product q */
+        const int64_t i = (int64_t)(std::upper_bound(starts.begin(), starts.end(), q) - starts.begin()) - 1;
+        const int64_t r0 = r0s[(size_t)order[(size_t)i]];
+        rows.push_back(r0 >= B->nrows ? piece_row[(size_t)(r0 - B->nrows)] : (int32_t)(r0 + rowloc[(size_t)q]));
+        cols.push_back((int32_t)(cb * B->W + (col16[(size_t)p] & 0x7fffu)));
+        vals.push_back(B->vmode == 0 ? B->vconst : B->vmode == 1 ? tab[vidx[(size_t)p]] : val1[(size_t)p]);
+      }
+    }
+  }
+  for (int64_t r = 0; r < (B->dv ? B->nrows : 0); r++) { rows.push_back((int32_t)r); cols.push_back((int32_t)(r + B->dshift)); vals.push_back(dv[(size_t)r]); }
+  return KSG_OK;
+}

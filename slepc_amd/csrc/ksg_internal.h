@@ -79,6 +79,7 @@ struct ksg_ctx_s {
   int lazy_update;           /* 0: never defer the store of a Gram-Schmidt update */
   int hot_cols;              /* most x entries a new operator may keep packed (0: none) */
   int col_groups;            /* column groups of a new power-law operator: 0 = chosen by size, 1 = none, >= 2 forced */
+  int bins;                  /* binned form of a new power-law operator: 0 = chosen by size, 1 = never, 2 = always */
   /* communicator */
   int comm_kind, rank, nranks, cb_on_device;
   void *rccl_comm;
@@ -142,6 +143,39 @@ struct ksg_colgroup {
   double *d_xhot;
 };
 
+/* The binned part of a power-law block (ksg_bins.hip): entries of well filled (row block, column
+ * block) cells, held in the order the expand pass streams them (by column block) and, for their
+ * rows, in the order the reduce pass streams the products (by row block). */
+struct ksg_bins {
+  int64_t nent;              /* products of the binned part, the fill of the runs included; 0: the block has no binned part */
+  int64_t nreal;             /* matrix entries among them                                       */
+  int64_t nent1;             /* entries of the expand stream, padding included (a multiple of 64) */
+  int64_t nseg;              /* runs of the expand stream that are consecutive in the reduce order */
+  int64_t nbins;             /* row blocks (all of them: the reduce pass stores every row of y)  */
+  int64_t ntasks;            /* workgroups of the expand pass                                    */
+  int64_t nrows;             /* rows of the block                                                */
+  int64_t dshift;            /* column of row r's diagonal entry minus r (dv != NULL)            */
+  int W, H;                  /* columns per column block, most rows per row block                */
+  int threads;               /* threads of an expand workgroup                                   */
+  int vmode;                 /* 0: one value (vconst), 1: one-byte indices into vtab, 2: 8-byte values */
+  double vconst;
+  uint16_t *col16;           /* nent1: column within the column block; bit 15: first entry of a run */
+  uint8_t *vidx;             /* nent1 (vmode 1)                                                  */
+  double *vtab;              /* 256 (vmode 1)                                                    */
+  double *val;               /* nent1 (vmode 2)                                                  */
+  uint32_t *gfirst;          /* per group of 64 entries: the run its first entry belongs to      */
+  int64_t *D;                /* per run: position in the reduce order minus position in the expand order */
+  int64_t *tasks;            /* 3 per task: column block, first group, end group                 */
+  uint16_t *rowloc;          /* nent: row within the row block, in the reduce order              */
+  int64_t *binp0, *binp1;    /* nbins each: the products of a row block, in the reduce order; the blocks with the most products first */
+  int32_t *bin_r0, *bin_nr;  /* first row and row count of every row block                       */
+  int64_t nlong, npieces;    /* rows longer than a unit of the reduce pass may be, and the pieces they are cut into */
+  int32_t *long_rows, *long_first, *piece_row;   /* those rows; their pieces long_first[j] .. long_first[j+1]; the row of every piece */
+  double *part;              /* npieces sums, added to their rows after the reduce pass             */
+  double *dv;                /* nrows: the block's diagonal, folded into the reduce pass (NULL: the block has none, or not one per row) */
+  double *xe;                /* nent + 64 products                                               */
+};
+
 struct ksg_mat_s {
   ksg_ctx ctx;
   int64_t n, N, row0, nnz;
@@ -151,6 +185,7 @@ struct ksg_mat_s {
   ksg_csr_dev diag;          /* columns local (col - col0); entries of a packed column: diag_ncols + its slot */
   int64_t diag_ncols;        /* nc, or the width of the first column group when there are several */
   std::vector<ksg_colgroup> cgs;   /* the column groups after the first (one rank, power-law operators) */
+  ksg_bins bins;             /* the binned part of the local block (one rank, power-law operators); diag then holds the rest */
   /* packed copy of the x entries of the most referenced columns (power-law operators) */
   int64_t nhot;
   std::vector<int32_t> hot_cols; /* local column of every slot                  */
@@ -189,6 +224,18 @@ int ksg_comm_exchange(ksg_ctx ctx, ksg_mat A);
 int ksg_comm_allreduce_host(ksg_ctx ctx, double *h_buf, int count, int op);
 int ksg_comm_exchange_host(ksg_ctx ctx, const double *send, const int64_t *sendoff,
                            double *recv, const int64_t *recvoff);
+
+/* binned part of a power-law block (ksg_bins.hip) */
+int ksg_bins_build(ksg_ctx c, ksg_bins *B, int64_t nrows, int64_t ncols, const int64_t *rowptr, const int32_t *colidx,
+                   const double *val, bool has_diag, int64_t dshift, std::vector<int32_t> &lrows, std::vector<int64_t> &lrp,
+                   std::vector<int32_t> &lci, std::vector<double> &lva);
+int ksg_bins_mult(const ksg_bins *B, const double *x, int64_t ncols, double *y, hipStream_t st);
+double ksg_bins_bytes(const ksg_bins *B);
+int ksg_bins_to_host(const ksg_bins *B, std::vector<int32_t> &rows, std::vector<int32_t> &cols, std::vector<double> &vals);
+void ksg_bins_free(ksg_bins *B);
+/* indices of the entries' values in a table of their distinct bit patterns (ksg_spmv.hip) */
+bool ksg_build_value_table(int64_t nnz, const double *val, const uint8_t *skip, size_t limit, std::vector<double> &tab,
+                           std::vector<uint8_t> &idx);
 
 /* workspace helpers */
 int ksg_scratch_bind(ksg_ctx ctx);                /* ksg_bv.hip; the context's device must be current */

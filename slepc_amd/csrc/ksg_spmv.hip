@@ -597,8 +597,8 @@ static void choose_hot_columns(int64_t ncols, int64_t nnz, const int32_t *colidx
 
 /* Indices of the entries' values in a table of their distinct bit patterns (at most `limit`);
  * entries with skip[p] set are left out (their index becomes 255).  false: too many values. */
-static bool build_value_table(int64_t nnz, const double *val, const uint8_t *skip, size_t limit, std::vector<double> &tab,
-                              std::vector<uint8_t> &idx) {
+bool ksg_build_value_table(int64_t nnz, const double *val, const uint8_t *skip, size_t limit, std::vector<double> &tab,
+                           std::vector<uint8_t> &idx) {
   tab.clear();
   idx.assign((size_t)nnz, 255);
   /* values are told apart by their bits; open addressing over 1024 slots, at most 256 in use */
@@ -654,7 +654,7 @@ static int csr_to_device(ksg_csr_dev *D, int64_t nrows, const int64_t *rowptr, c
   if (D->nnz >= 4096) {
     std::vector<double> tab;
     std::vector<uint8_t> idx;
-    if (build_value_table(D->nnz, val, NULL, 256, tab, idx)) D->nvt = 1;
+    if (ksg_build_value_table(D->nnz, val, NULL, 256, tab, idx)) D->nvt = 1;
     else if (diag_cols && dshift > -(int64_t)INT32_MAX && dshift < (int64_t)INT32_MAX) {
       std::vector<uint8_t> isdiag((size_t)D->nnz, 0);
       std::vector<double> dv((size_t)(row_ids ? dv_len : nrows), 0.0);
@@ -666,7 +666,7 @@ static int csr_to_device(ksg_csr_dev *D, int64_t nrows, const int64_t *rowptr, c
           if ((int64_t)diag_cols[p] == want) { isdiag[(size_t)p] = 1; dv[(size_t)(row_ids ? want : r)] = val[p]; seen++; }
         if (seen > 1) one_per_row = false;              /* duplicate entries: leave the matrix as it is */
       }
-      if (one_per_row && build_value_table(D->nnz, val, isdiag.data(), 255, tab, idx)) {
+      if (one_per_row && ksg_build_value_table(D->nnz, val, isdiag.data(), 255, tab, idx)) {
         KSG_CHK(upload(&D->dvals, dv.data(), dv.size()));
         D->dshift = row_ids ? 0 : (int32_t)dshift;      /* the kernel reads dvals[column - dshift] */
         D->nvt = 2;
@@ -824,12 +824,47 @@ static int column_groups_for(ksg_ctx c, int64_t ncols, int64_t nnz, const int32_
   return G;
 }
 
+/* Whether the local block of a new operator gets a binned part (KSG_OPT_BINS): one rank, a
+ * power-law operator (the test of the packing), and by default an x of 64 MiB or more (R-MAT scale 22: 0.50 ms
+ * per product either way; scale 23: 0.98 ms as a CSR, 0.82 ms binned;
+ * scale 24: 2.09 ms per product as a CSR, 1.61 ms binned; scale 26: 8.92 ms in column groups,
+ * 7.05 ms binned). */
+static bool bins_wanted(ksg_ctx c, int64_t ncols, int64_t nnz, const int32_t *colidx) {
+  if (c->nranks > 1 || c->bins == 1 || ncols < 4096 || ncols > (int64_t)INT32_MAX) return false;
+  if (c->bins == 0 && ncols < ((int64_t)64 << 20) / 8) return false;
+  return is_power_law(ncols, nnz, colidx);
+}
+
 static int diag_to_device(ksg_mat A, int64_t nrows, const int64_t *rowptr, const int32_t *colidx, const double *val) {
   /* the diagonal of a square operator lies in this block: row r (global row0 + r) has it in the
    * local column row0 + r - col0 */
   const bool square = A->N == A->NC;
   ksg_ctx c = A->ctx;
   A->diag_ncols = A->nc;
+  if (bins_wanted(c, A->nc, rowptr[nrows], colidx)) {
+    /* well filled (row block, column block) cells and the diagonal go to the binned form, which
+     * stores y; what is left is a CSR over the rows it touches, held like a column group over all
+     * columns and added afterwards.  A->diag stays empty. */
+    std::vector<int32_t> lrows, lci;
+    std::vector<int64_t> lrp;
+    std::vector<double> lva;
+    KSG_CHK(ksg_bins_build(c, &A->bins, nrows, A->nc, rowptr, colidx, val, square, A->row0 - A->col0, lrows, lrp, lci, lva));
+    if (A->bins.nent) {
+      A->cgs.clear();
+      if (!lrows.empty()) {
+        A->cgs.emplace_back();
+        ksg_colgroup &cg = A->cgs.back();
+        memset(&cg.blk, 0, sizeof(cg.blk));
+        cg.col_first = 0; cg.ncols = A->nc; cg.nrows = (int64_t)lrows.size();
+        cg.d_rows = NULL; cg.nhot = 0; cg.d_hot_idx = NULL; cg.d_xhot = NULL;
+        KSG_CHK(upload(&cg.d_rows, lrows.data(), lrows.size()));
+        /* entries of a diagonal that could not be folded are ordinary entries here */
+        KSG_CHK(block_to_device(c, &cg.blk, cg.ncols, cg.nrows, lrp.data(), lci.data(), lva.data(), cg.hot_cols, &cg.nhot, &cg.d_hot_idx,
+                                &cg.d_xhot, false, 0, lrows.data()));
+      }
+      return KSG_OK;
+    }
+  }
   const int G = column_groups_for(c, A->nc, rowptr[nrows], colidx);
   if (G <= 1)
     return block_to_device(c, &A->diag, A->nc, nrows, rowptr, colidx, val, A->hot_cols, &A->nhot, &A->d_hot_idx, &A->d_xhot,
@@ -941,6 +976,7 @@ static int mat_create(ksg_ctx c, int64_t n, int64_t N, int64_t row0, int64_t nc,
   A->diag_ncols = nc;
   A->no_rows = 0; A->o_rows = NULL; A->o_nnz = 0;
   memset(&A->ghost, 0, sizeof(A->ghost));
+  memset(&A->bins, 0, sizeof(A->bins));
   A->g_nhot = 0; A->d_g_hot_idx = NULL; A->d_g_xhot = NULL;
   A->nghost = A->nsend = 0;
   A->d_ghost = A->d_send = A->h_ghost = A->h_send = NULL; A->d_send_idx = NULL;
@@ -1077,6 +1113,36 @@ static int download(std::vector<T> &dst, const T *src, size_t count) {
   return KSG_OK;
 }
 
+/* Adds the entries of the binned part (and its folded diagonal) to the rows in rp/ci/va, every
+ * row that gains entries in ascending column order. */
+static int bins_merge_host(ksg_mat A, std::vector<int64_t> &rp, std::vector<int32_t> &ci, std::vector<double> &va) {
+  if (!A->bins.nent) return KSG_OK;
+  std::vector<int32_t> br, bc;
+  std::vector<double> bv;
+  KSG_CHK(ksg_bins_to_host(&A->bins, br, bc, bv));
+  std::vector<int64_t> nrp((size_t)A->n + 1, 0);
+  for (int64_t i = 0; i < A->n; i++) nrp[i + 1] = rp[i + 1] - rp[i];
+  for (size_t e = 0; e < br.size(); e++) nrp[(size_t)br[e] + 1]++;
+  for (int64_t i = 0; i < A->n; i++) nrp[i + 1] += nrp[i];
+  std::vector<int32_t> nci((size_t)nrp[A->n]);
+  std::vector<double> nva((size_t)nrp[A->n]);
+  std::vector<int64_t> pos(nrp.begin(), nrp.end() - 1);
+  for (int64_t i = 0; i < A->n; i++)
+    for (int64_t p = rp[i]; p < rp[i + 1]; p++) { nci[(size_t)pos[i]] = ci[(size_t)p]; nva[(size_t)pos[i]] = va[(size_t)p]; pos[i]++; }
+  for (size_t e = 0; e < br.size(); e++) { const int64_t q = pos[br[e]]++; nci[(size_t)q] = bc[e]; nva[(size_t)q] = bv[e]; }
+  std::vector<std::pair<int32_t, double>> row;
+  for (int64_t i = 0; i < A->n; i++) {
+    const int64_t a = nrp[i], b = nrp[i + 1];
+    if (b - a == rp[i + 1] - rp[i]) continue;              /* nothing binned in this row */
+    row.clear();
+    for (int64_t p = a; p < b; p++) row.push_back({nci[(size_t)p], nva[(size_t)p]});
+    std::stable_sort(row.begin(), row.end(), [](const std::pair<int32_t, double> &u, const std::pair<int32_t, double> &v) { return u.first < v.first; });
+    for (int64_t p = a; p < b; p++) { nci[(size_t)p] = row[(size_t)(p - a)].first; nva[(size_t)p] = row[(size_t)(p - a)].second; }
+  }
+  rp.swap(nrp); ci.swap(nci); va.swap(nva);
+  return KSG_OK;
+}
+
 /* the local rows back on the host with global column indices (the two blocks of a
  * distributed matrix merged again, every row in ascending column order when it was given so) */
 static int mat_to_host(ksg_mat A, std::vector<int64_t> &rp, std::vector<int32_t> &ci, std::vector<double> &va) {
@@ -1096,7 +1162,7 @@ static int mat_to_host(ksg_mat A, std::vector<int64_t> &rp, std::vector<int32_t>
   }
   if (c->nranks == 1 && A->cgs.empty()) {
     rp.swap(drp); ci.swap(dci); va.swap(dva);
-    return KSG_OK;
+    return bins_merge_host(A, rp, ci, va);
   }
   if (c->nranks == 1) {
     /* column groups: a row's entries are those of group 0, 1, ... in turn (ascending columns) */
@@ -1129,7 +1195,7 @@ static int mat_to_host(ksg_mat A, std::vector<int64_t> &rp, std::vector<int32_t>
         const int64_t r = grows[g][i];
         for (int64_t p = grp[g][i]; p < grp[g][i + 1]; p++) { ci[(size_t)pos[r]] = gci[g][p]; va[(size_t)pos[r]] = gva[g][p]; pos[r]++; }
       }
-    return KSG_OK;
+    return bins_merge_host(A, rp, ci, va);
   }
   std::vector<int32_t> orows, oci;
   std::vector<int64_t> orp;
@@ -1248,6 +1314,7 @@ extern "C" int ksg_mat_destroy(ksg_mat A) {
     if (cg.d_xhot) hipFree(cg.d_xhot);
   }
   A->cgs.clear();
+  ksg_bins_free(&A->bins);
   if (A->o_rows) hipFree(A->o_rows);
   if (A->d_g_hot_idx) hipFree(A->d_g_hot_idx);
   if (A->d_g_xhot) hipFree(A->d_g_xhot);
@@ -1296,7 +1363,10 @@ static int mat_mult_raw(ksg_mat A, const double *x, double *y) {
     if (A->nsend)
       hipLaunchKernelGGL(k_gather, dim3(ksg_grid_for(A->nsend)), dim3(KSG_BLOCK), 0, c->comm_stream, x, A->d_send_idx, A->d_send, A->nsend);
   }
-  if (A->diag.pc_w) {
+  if (A->bins.nent) {
+    /* the binned part and the diagonal store y; the remaining entries are added below */
+    KSG_CHK(ksg_bins_mult(&A->bins, x, A->nc, y, c->stream));
+  } else if (A->diag.pc_w) {
     launch_rowcode<0>(c->stream, A->diag, x, y, 0.0, 0.0, NULL, NULL);
   } else if (A->diag.ntiles) {
     if (A->nhot) hipLaunchKernelGGL(k_gather, dim3(ksg_grid_for(A->nhot)), dim3(KSG_BLOCK), 0, c->stream, x, A->d_hot_idx, A->d_xhot, A->nhot);
@@ -1343,6 +1413,7 @@ static inline double spmv_bytes(ksg_mat A) {
   double b = block_stream_bytes(A->diag) + 8.0 * (double)A->nc + 8.0 * (double)A->n + 20.0 * (double)A->nhot;
   for (const ksg_colgroup &cg : A->cgs)       /* entry stream, row list, read-modify-write of the rows touched, packing */
     b += block_stream_bytes(cg.blk) + 20.0 * (double)cg.nrows + 20.0 * (double)cg.nhot;
+  b += ksg_bins_bytes(&A->bins);
   if (A->ctx->nranks > 1)
     b += (A->no_rows ? block_stream_bytes(A->ghost) : 0.0) + 20.0 * (double)A->no_rows + 20.0 * (double)A->g_nhot +
          8.0 * (double)A->nghost + 20.0 * (double)A->nsend;
@@ -1375,7 +1446,16 @@ extern "C" int ksg_mat_describe(ksg_mat A, char *buf, size_t len) {
            KSG_TILE_NNZ, KSG_TILE_ROWS, (long long)A->diag.n_stream, (long long)A->diag.n_group, (long long)A->diag.n_long,
            A->diag.nvt == 2 ? "1-byte indices into a 255-entry table off the diagonal, the diagonal as a dense vector" :
            A->diag.nvt ? "1-byte indices into a 256-entry table" : "8-byte stream", (long long)A->nhot, (long long)A->nghost);
-  if (!A->cgs.empty() && k > 0 && (size_t)k < len) {
+  if (A->bins.nent && k > 0 && (size_t)k < len) {
+    long long rows = 0, ent = 0, hot = 0;
+    for (const ksg_colgroup &cg : A->cgs) { rows += cg.nrows; ent += cg.blk.nnz; hot += cg.nhot; }
+    k = snprintf(buf, len, "binned part: %lld of %lld entries in cells of %d-column blocks x row blocks of <= %d rows (%lld runs, %lld row blocks, "
+                 "values: %s), expanded through LDS slices of x and summed per row block in LDS%s; remaining entries: %lld in %lld rows through "
+                 "the tile kernel (row tiles of <= %d entries, %lld packed hot columns), added afterwards",
+                 (long long)A->bins.nreal, (long long)A->nnz, A->bins.W, A->bins.H, (long long)A->bins.nseg, (long long)A->bins.nbins,
+                 A->bins.vmode == 0 ? "one" : A->bins.vmode == 1 ? "1-byte indices" : "8-byte stream",
+                 A->bins.dv ? ", the diagonal as a dense vector in the same pass" : "", ent, rows, KSG_TILE_NNZ, hot);
+  } else if (!A->cgs.empty() && k > 0 && (size_t)k < len) {
     long long rows = 0, ent = 0, hot = 0;
     for (const ksg_colgroup &cg : A->cgs) { rows += cg.nrows; ent += cg.blk.nnz; hot += cg.nhot; }
     k += snprintf(buf + k, len - (size_t)k, "; %d column groups of <= %lld columns multiplied one after the other (groups after the first: %lld entries in "
@@ -1407,8 +1487,8 @@ extern "C" int ksg_mat_residual_norm(ksg_mat A, double kr, double ki, const doub
   if (A->n && !x) KSG_FAIL(KSG_ERR_ARG, "ksg_mat_residual_norm: NULL vector");
   if (A->n != A->nc || A->N != A->NC) KSG_FAIL(KSG_ERR_ARG, "ksg_mat_residual_norm: the operator must be square");
   ksg_ctx c = A->ctx;
-  const bool halo = c->nranks > 1 || !A->cgs.empty();     /* the product cannot be fused with the norm */
-  if (halo && A->n && (!work || work == x || work == xi)) KSG_FAIL(KSG_ERR_ARG, "ksg_mat_residual_norm: a separate work vector is needed with several ranks or column groups");
+  const bool halo = c->nranks > 1 || !A->cgs.empty() || A->bins.nent;     /* the product cannot be fused with the norm */
+  if (halo && A->n && (!work || work == x || work == xi)) KSG_FAIL(KSG_ERR_ARG, "ksg_mat_residual_norm: a separate work vector is needed with several ranks, column groups or a binned part");
   KSG_CHK(ksg_op_begin(c, KSG_EV_MATMULT));
   int nb = 0;
   if (!halo) {
@@ -1451,7 +1531,7 @@ extern "C" int ksg_bv_matmult(ksg_bv V, ksg_mat A, ksg_bv W) {
   KSG_CHK(ksg_op_begin(c, KSG_EV_MATMULT));
   const double *X = V->d + (int64_t)(V->nc + V->l) * V->ld;
   double *Y = W->d + (int64_t)(W->nc + W->l) * W->ld;
-  if (c->nranks == 1 && nc > 1 && A->diag.ntiles && !A->nhot && A->cgs.empty()) {
+  if (c->nranks == 1 && nc > 1 && A->diag.ntiles && !A->nhot && A->cgs.empty() && !A->bins.nent) {
     /* one pass over the matrix for all the columns */
     hipLaunchKernelGGL(k_spmm_tiles<8>, dim3((unsigned)A->diag.ntiles), dim3(KSG_BLOCK), 0, c->stream, A->diag.tiles,
                        A->diag.tile_p, A->diag.rowptr, A->diag.colidx, A->diag.val, X, V->ld, Y, W->ld, nc);

@@ -111,6 +111,8 @@ SIGNATURES = {
     "ksg_mat_info": (C.c_int, [C.c_void_p, C.POINTER(c_i64)]),
     "ksg_mat_traffic_model": (C.c_int, [C.c_void_p, c_dp, c_dp]),
     "ksg_mat_describe": (C.c_int, [C.c_void_p, C.c_char_p, C.c_size_t]),
+    "ksg_bins_host_check": (C.c_int, [c_i64, c_i64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, c_i64, C.c_void_p, C.c_void_p,
+                                      C.POINTER(c_i64)]),
     "ksg_stats_enable_timing": (C.c_int, [C.c_void_p, C.c_int]),
     "ksg_stats_get": (C.c_int, [C.c_void_p, C.POINTER(Stats)]),
     "ksg_stats_reset": (C.c_int, [C.c_void_p]),
@@ -150,6 +152,24 @@ OPT_MV_GRID = 3
 OPT_LAZY_UPDATE = 4
 OPT_HOT_COLS = 5
 OPT_COL_GROUPS = 6
+OPT_BINS = 7
+
+
+def bins_host_check(rowptr, colidx, val, x, ncols=None, has_diag=True, dshift=0):
+    """y = A x formed on the host the way the binned product forms it (no device needed), and
+    {binned entries, runs, row blocks, value mode, entries left in the CSR}."""
+    import numpy as np
+    lib = load()
+    rp = np.ascontiguousarray(rowptr, dtype=np.int64)
+    ci = np.ascontiguousarray(colidx, dtype=np.int32)
+    va = np.ascontiguousarray(val, dtype=np.float64)
+    xx = np.ascontiguousarray(x, dtype=np.float64)
+    n = len(rp) - 1
+    y = np.empty(n)
+    info = (c_i64 * 6)()
+    check(lib.ksg_bins_host_check(n, len(xx) if ncols is None else ncols, rp.ctypes.data, ci.ctypes.data, va.ctypes.data,
+                                  1 if has_diag else 0, dshift, xx.ctypes.data, y.ctypes.data, info))
+    return y, dict(zip(("binned", "runs", "row_blocks", "value_mode", "csr_entries", "diagonal_folded"), (int(v) for v in info)))
 
 
 class Context:

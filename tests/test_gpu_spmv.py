@@ -408,6 +408,106 @@ def test_column_groups(gpu_ctx, groups, hot, shifted):
         ctx.vec_free(p_)
 
 
+@pytest.mark.parametrize("W,H,E,T,values", [(1024, 256, 4096, 2, "laplacian"), (64, 64, 1 << 20, 1, "laplacian"),
+                                             (16384, 2048, 65536, 4, "laplacian"), (2048, 512, 8192, 3, "few"),
+                                             (512, 128, 2048, 2, "any"), (4096, 100, 700, 2, "zeros"),
+                                             (256, 8192, 300, 5, "nodiag"), (8192, 1024, 500, 4, "any")])
+def test_binned_product(gpu_ctx, W, H, E, T, values):
+    """A power-law operator whose well filled (row block, column block) cells are held in the binned
+    form (KSG_OPT_BINS): the product agrees with the plain operator's and the sequential CSR loop's
+    to rounding (a row's sum is formed from its CSR entries first, its binned entries after), for one
+    value, few values (one-byte indices) and arbitrary values, with explicit zeros among the entries,
+    with rows longer than a row block may be (cut into pieces) and with a diagonal that is not
+    complete (its entries are then ordinary entries); the entries read back and the transpose are exactly the input's; residual norm and block product
+    go through the same path; the second product gives the same bits as the first; an operator that
+    is not power-law is left as it is."""
+    import os
+    from scipy.sparse import csr_matrix
+    from slepc_amd import ksgpu, matgen as mg
+    ctx = gpu_ctx
+    rp, ci, va = mg.rmat_laplacian(14, 8, seed=11)
+    n = len(rp) - 1
+    rng = np.random.default_rng(7)
+    offd = ci != np.repeat(np.arange(n), np.diff(rp))
+    va = va.copy()
+    if values == "few":
+        va[offd] = rng.choice(np.array([-1.0, -0.5, 2.25, 1e-3]), size=int(offd.sum()))
+    elif values == "any":
+        va[offd] = rng.standard_normal(int(offd.sum()))
+    elif values == "zeros":
+        va[offd] = rng.choice(np.array([-1.0, 0.0]), size=int(offd.sum()))
+    elif values == "nodiag":                               # rows 3 and 700 lose their diagonal entry
+        keep = np.ones(len(ci), dtype=bool)
+        for r in (3, 700):
+            keep[rp[r]:rp[r + 1]] = ci[rp[r]:rp[r + 1]] != r
+        rows = np.repeat(np.arange(n), np.diff(rp))[keep]
+        rp = np.concatenate([[0], np.cumsum(np.bincount(rows, minlength=n))]).astype(np.int64)
+        ci, va = ci[keep], va[keep]
+    env = {"KSG_BINS_W": W, "KSG_BINS_H": H, "KSG_BINS_E": E, "KSG_BINS_T": T, "KSG_BINS_TASK_GROUPS": 16}
+    old = {k: os.environ.get(k) for k in env}
+    try:
+        os.environ.update({k: str(v) for k, v in env.items()})
+        ctx.set_option(ksgpu.OPT_COL_GROUPS, 1)
+        ctx.set_option(ksgpu.OPT_BINS, 1)
+        A0 = ksgpu.DeviceCSR(ctx, rp, ci, va)
+        ctx.set_option(ksgpu.OPT_BINS, 2)
+        A1 = ksgpu.DeviceCSR(ctx, rp, ci, va)
+        L = ksgpu.DeviceCSR(ctx, *mg.laplacian2d(70, 70))
+    finally:
+        ctx.set_option(ksgpu.OPT_BINS, 0)
+        ctx.set_option(ksgpu.OPT_COL_GROUPS, 0)
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    assert "binned part" not in A0.describe() and "binned part" not in L.describe()
+    assert "binned part" in A1.describe(), A1.describe()
+    want_values = {"laplacian": "values: one", "few": "1-byte indices", "zeros": "1-byte indices", "any": "8-byte stream",
+                   "nodiag": "1-byte indices"}[values]       # -1 and the degrees of the binned diagonal entries: few values
+    assert want_values in A1.describe().split("binned part")[1], A1.describe()
+    assert ("the diagonal as a dense vector" in A1.describe()) == (values != "nodiag")
+    L.destroy()
+    M = csr_matrix((va, ci, rp), shape=(n, n))
+    xd, yd, zd, wd = (ctx.vec_alloc(n) for _ in range(4))
+    for trial in range(2):
+        x = rng.standard_normal(n)
+        ctx.upload(xd, x)
+        ctx.upload(zd, np.full(n, np.nan))
+        A0.mult(xd, yd)
+        A1.mult(xd, zd)
+        y0, y1 = ctx.download(yd, n), ctx.download(zd, n)
+        ref = M @ x
+        scale = np.abs(M) @ np.abs(x) + 1e-300
+        assert np.all(np.abs(y1 - ref) <= 1e-14 * scale) and np.all(np.abs(y1 - y0) <= 1e-14 * scale)
+        ctx.upload(zd, np.full(n, np.nan))
+        A1.mult(xd, zd)
+        assert np.array_equal(ctx.download(zd, n), y1)        # the additions come in a fixed order
+    r1, c1, v1 = A1.get_csr()
+    assert np.array_equal(r1, rp) and np.array_equal(c1, ci) and np.array_equal(v1, va)
+    T0, T1 = A0.transpose(), A1.transpose()
+    for a, b in zip(T0.get_csr(), T1.get_csr()):
+        assert np.array_equal(a, b)
+    want = np.linalg.norm(ref - 1.75 * x)
+    assert abs(A1.residual_norm(1.75, 0.0, xd, None, wd) - want) <= 1e-13 * want
+    with pytest.raises(ksgpu.KsgError):
+        A1.residual_norm(1.75, 0.0, xd)                    # the binned part needs a work vector
+    m = 3
+    V, Wb = ksgpu.DeviceBV(ctx, n, m), ksgpu.DeviceBV(ctx, n, m)
+    Va = rng.standard_normal((n, m))
+    V.from_numpy(Va)
+    V.matmult(A1, Wb)
+    Wa = Wb.to_numpy()
+    for j in range(m):
+        assert np.all(np.abs(Wa[:, j] - M @ Va[:, j]) <= 1e-14 * (np.abs(M) @ np.abs(Va[:, j]) + 1e-300))
+    ex, cm = A1.traffic_model()
+    assert ex > 0 and cm > 0
+    for o in (A0, A1, T0, T1, V, Wb):
+        o.destroy()
+    for p_ in (xd, yd, zd, wd):
+        ctx.vec_free(p_)
+
+
 @pytest.mark.parametrize("gen", ["lap1d", "lap2d", "lap3d", "band"])
 def test_row_code_kernel_equals_tile_kernel(gpu_ctx, gen):
     """Stencils and other banded operators with few distinct (column - row, value) pairs are
