@@ -145,6 +145,13 @@ __global__ __launch_bounds__(64) void k_bins_reduce(const int64_t *__restrict__ 
     /* one row: every lane sums its share in registers, the wave adds the 64 sums in a fixed order */
     double t[4] = {0.0, 0.0, 0.0, 0.0};
     int64_t p = p0 + lane;
+    for (; p + 64 * 15 < p1; p += 64 * 16) {               /* sixteen loads in flight; the same four sums as the loop below */
+      double v[16];
+#pragma unroll
+      for (int j = 0; j < 16; j++) v[j] = __builtin_nontemporal_load(xe + p + 64 * j);
+#pragma unroll
+      for (int j = 0; j < 16; j++) t[j & 3] += v[j];
+    }
     for (; p + 64 * 3 < p1; p += 64 * 4) {
       double v[4];
 #pragma unroll

@@ -247,6 +247,47 @@ def test_eps_parity_with_oracle(be, name):
         assert np.abs(s * gr - xr).max() < 1e-5
 
 
+def test_eps_on_binned_operator(be):
+    """The R-MAT solve of CASES with the operator held in the binned form (KSG_OPT_BINS forced, small
+    blocks so that the 8192-row graph has many cells, long rows cut into pieces): eigenvalues, error
+    estimates and vectors against the oracle as for the plain operator."""
+    import os
+    from slepc_amd import ksgpu
+    gen, herm, kw = CASES["rmat_13"]
+    csr = gen()
+    n = len(csr[0]) - 1
+    v0 = oeps.splitmix64_uniform(np.arange(n, dtype=np.uint64))
+    env = {"KSG_BINS_W": "1024", "KSG_BINS_H": "256", "KSG_BINS_E": "2048", "KSG_BINS_T": "2"}
+    old = {k: os.environ.get(k) for k in env}
+    try:
+        os.environ.update(env)
+        be.ctx.set_option(ksgpu.OPT_BINS, 2)
+        probe = ksgpu.DeviceCSR(be.ctx, *csr)
+        assert "binned part" in probe.describe()
+        probe.destroy()
+        r = common.solve_eps(be, csr, hermitian=True, v0=v0, want_vectors=True, **kw)
+    finally:
+        be.ctx.set_option(ksgpu.OPT_BINS, 0)
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    A = csr_matrix((csr[2], csr[1], csr[0]))
+
+    def mv(x, y):
+        y[:] = A @ x
+    e = oeps.EPS(mv, n, hermitian=True, v0=v0, **kw).solve()
+    assert r["reason"] == K.EPS_CONVERGED_TOL and r["nconv"] >= kw["nev"] and e.nconv >= kw["nev"]
+    for i in range(kw["nev"]):
+        lam = e.get_eigenvalue(i)
+        assert abs(r["values"][i][0] - lam[0]) <= 1e-10 * abs(lam[0])
+        assert r["errors"][i] < 10 * kw["tol"]
+        xr, _ = e.get_eigenvector(i)
+        gr = r["vectors"][i][0]
+        assert np.abs(np.sign(xr @ gr) * gr - xr).max() < 1e-5
+
+
 def _foreign_shell(ctx, csr):
     """A shell operator whose MatMult touches the device arrays of x and y behind the library's
     back, the way user code with kernels of its own does: x->array is copied out and y->array is

@@ -16,7 +16,14 @@ def main():
     scale = int(sys.argv[1]) if len(sys.argv) > 1 else 24
     settings = sys.argv[2:] or ["plain", "W=16384,H=2048,T=4"]
     t0 = time.perf_counter()
-    rp, ci, va = matgen.rmat_laplacian(scale)
+    cache = "/tmp/rmat_laplacian_%d.npz" % scale          # several profiler passes share one generation
+    if os.path.exists(cache):
+        z = np.load(cache)
+        rp, ci, va = z["rp"], z["ci"], z["va"]
+    else:
+        rp, ci, va = matgen.rmat_laplacian(scale)
+        if os.environ.get("KSG_RMAT_CACHE"):
+            np.savez(cache, rp=rp, ci=ci, va=va)
     n = len(rp) - 1
     print("scale %d: n=%d nnz=%d, generated in %.0f s" % (scale, n, rp[-1], time.perf_counter() - t0), flush=True)
     ctx = ksgpu.Context(0)
