@@ -87,15 +87,16 @@ void *ksg_ctx_stream(ksg_ctx ctx);
  * they touch), so that at any time the gathers fall into one slice of x whose most referenced
  * part the L2s can hold.  A row's sum is then formed group by group: the same products added
  * in another order.
- * KSG_OPT_BINS (default 0 = by size; 1 = never; 2 = always): a power-law operator created
- * afterwards on one rank (x of 64 MiB or more when chosen by size) keeps the entries of its well
- * filled (row block, column block) cells in a binned form: one pass looks x up in LDS slices and
- * writes the products in the order of the row blocks, a second pass sums them per row block in
+ * KSG_OPT_BINS (default 0 = by size; 1 = never; 2 = always): a block of a power-law operator
+ * created afterwards -- the local block of a rank, and the ghost block of a distributed operator,
+ * whose x is the ghost buffer -- (x of 64 MiB or more when chosen by size) keeps the entries of its
+ * well filled (row block, column block) cells in a binned form: one pass looks x up in LDS slices
+ * and writes the products in the order of the row blocks, a second pass sums them per row block in
  * LDS and adds the diagonal term; the remaining entries stay a CSR over the rows they touch and
  * are added afterwards.  The gathers from a large x, one memory request each, become two streams.
  * Takes precedence over the column groups.  A row's sum is formed from its binned entries by
  * column block, its diagonal entry, and its remaining entries: the same products added in another
- * order. */
+ * order, the same order in every product. */
 enum { KSG_OPT_FUSE_DOTS = 1, KSG_OPT_DOT_GRID = 2, KSG_OPT_MV_GRID = 3, KSG_OPT_LAZY_UPDATE = 4, KSG_OPT_HOT_COLS = 5,
        KSG_OPT_COL_GROUPS = 6, KSG_OPT_BINS = 7 };
 int ksg_ctx_set_option(ksg_ctx ctx, int option, int value);

@@ -130,12 +130,15 @@ __global__ __launch_bounds__(BINS_P1_THREADS) void k_bins_expand(const int64_t *
 
 /* One wave per row block: y[r] = sum of the block's products of row r + dv[r] * x[r + dshift].
  * A block whose first row lies at or beyond nrows is a piece of a long row: it has one row, and
- * its sum goes to part[r0 - nrows] (k_bins_long_rows adds the pieces to y afterwards). */
+ * its sum goes to part[r0 - nrows] (k_bins_long_rows adds the pieces to y afterwards).
+ * rowmap (may be NULL): row i of the block is row rowmap[i] of y and the sums are added to what y
+ * holds -- the ghost block of a distributed operator, whose rows are a list of the local rows. */
 __global__ __launch_bounds__(64) void k_bins_reduce(const int64_t *__restrict__ binp0, const int64_t *__restrict__ binp1,
                                                     const int32_t *__restrict__ bin_r0, const int32_t *__restrict__ bin_nr,
                                                     const uint16_t *__restrict__ rowloc, const double *__restrict__ xe,
                                                     const double *__restrict__ dv, const double *__restrict__ x, int64_t dshift,
-                                                    double *__restrict__ y, int64_t nrows, double *__restrict__ part) {
+                                                    double *__restrict__ y, int64_t nrows, double *__restrict__ part,
+                                                    const int32_t *__restrict__ rowmap) {
   extern __shared__ double acc[];
   const int64_t b = blockIdx.x;
   const int64_t p0 = binp0[b], p1 = binp1[b];
@@ -180,6 +183,29 @@ __global__ __launch_bounds__(64) void k_bins_reduce(const int64_t *__restrict__ 
   }
   for (; p < p1; p += 64) atomicAdd(&acc[rowloc[p]], xe[p]);
   /* the wave's own LDS operations complete in order: no barrier between its adds and its reads */
+  if (rowmap) {
+    /* the block's rows stand for rows rowmap[.] of y, which already holds the other blocks' sums */
+    for (int i0 = 0; i0 < nr; i0 += 64 * 8) {
+      int32_t rr[8];
+      double yy[8];
+#pragma unroll
+      for (int j = 0; j < 8; j++) {
+        const int i = i0 + 64 * j + lane;
+        rr[j] = i < nr ? rowmap[r0 + i] : 0;
+      }
+#pragma unroll
+      for (int j = 0; j < 8; j++) {
+        const int i = i0 + 64 * j + lane;
+        yy[j] = i < nr ? y[rr[j]] : 0.0;
+      }
+#pragma unroll
+      for (int j = 0; j < 8; j++) {
+        const int i = i0 + 64 * j + lane;
+        if (i < nr) y[rr[j]] = yy[j] + acc[i];
+      }
+    }
+    return;
+  }
   for (int i0 = 0; i0 < nr; i0 += 64 * 8) {
     double dd[8], xx[8];
 #pragma unroll
@@ -601,10 +627,11 @@ extern "C" int ksg_bins_host_check(int64_t nrows, int64_t ncols, const int64_t *
   return KSG_OK;
 }
 
-/* The same split, with the binned part uploaded as *B. */
+/* The same split, with the binned part uploaded as *B.  rowmap (may be NULL): the rows of y the
+ * block's rows stand for (ksg_bins_mult is then given the same list on the device). */
 int ksg_bins_build(ksg_ctx c, ksg_bins *B, int64_t nrows, int64_t ncols, const int64_t *rowptr, const int32_t *colidx,
                    const double *val, bool has_diag, int64_t dshift, std::vector<int32_t> &lrows, std::vector<int64_t> &lrp,
-                   std::vector<int32_t> &lci, std::vector<double> &lva) {
+                   std::vector<int32_t> &lci, std::vector<double> &lva, const int32_t *rowmap) {
   memset(B, 0, sizeof(*B));
   bins_host Hb;
   bins_build_host(&Hb, nrows, ncols, rowptr, colidx, val, has_diag, dshift, lrows, lrp, lci, lva);
@@ -629,7 +656,10 @@ int ksg_bins_build(ksg_ctx c, ksg_bins *B, int64_t nrows, int64_t ncols, const i
   if (Hb.fold_diag) KSG_CHK(bins_upload(&B->dv, Hb.dv.data(), Hb.dv.size()));
   B->nlong = (int64_t)Hb.long_rows.size(); B->npieces = (int64_t)Hb.piece_row.size();
   if (B->nlong) {
-    KSG_CHK(bins_upload(&B->long_rows, Hb.long_rows.data(), Hb.long_rows.size()));
+    /* k_bins_long_rows adds into y: with a row list, the rows of y the long rows stand for */
+    std::vector<int32_t> ly(Hb.long_rows);
+    if (rowmap) for (size_t j = 0; j < ly.size(); j++) ly[j] = rowmap[ly[j]];
+    KSG_CHK(bins_upload(&B->long_rows, ly.data(), ly.size()));
     KSG_CHK(bins_upload(&B->long_first, Hb.long_first.data(), Hb.long_first.size()));
     KSG_CHK(bins_upload(&B->piece_row, Hb.piece_row.data(), Hb.piece_row.size()));
     hipError_t e2 = hipMalloc((void **)&B->part, (size_t)B->npieces * sizeof(double));
@@ -645,8 +675,8 @@ int ksg_bins_build(ksg_ctx c, ksg_bins *B, int64_t nrows, int64_t ncols, const i
   return KSG_OK;
 }
 
-/* y = B x + d .* x on `st` (every row of the block is stored). */
-int ksg_bins_mult(const ksg_bins *B, const double *x, int64_t ncols, double *y, hipStream_t st) {
+/* y = B x + d .* x on `st` (every row of the block is stored); with a row list, y[list] += B x. */
+int ksg_bins_mult(const ksg_bins *B, const double *x, int64_t ncols, double *y, hipStream_t st, const int32_t *d_rowmap) {
   if (!B->nent) return KSG_OK;
   const size_t lds1 = ((size_t)B->W + 1) * sizeof(double), lds2 = (size_t)B->H * sizeof(double);
   const dim3 g1((unsigned)B->ntasks), b1((unsigned)B->threads);
@@ -657,7 +687,7 @@ int ksg_bins_mult(const ksg_bins *B, const double *x, int64_t ncols, double *y, 
   else
     hipLaunchKernelGGL(k_bins_expand<2>, g1, b1, lds1, st, B->tasks, B->col16, B->vidx, B->vtab, B->val, 1.0, B->gfirst, B->D, x, ncols, B->xe, B->W);
   hipLaunchKernelGGL(k_bins_reduce, dim3((unsigned)B->nbins), dim3(64), lds2, st, B->binp0, B->binp1, B->bin_r0, B->bin_nr, B->rowloc, B->xe,
-                     B->dv, x, B->dshift, y, B->nrows, B->part);
+                     B->dv, x, B->dshift, y, B->nrows, B->part, d_rowmap);
   if (B->nlong)
     hipLaunchKernelGGL(k_bins_long_rows, dim3((unsigned)((B->nlong + KSG_BLOCK - 1) / KSG_BLOCK)), dim3(KSG_BLOCK), 0, st, B->long_rows,
                        B->long_first, (int)B->nlong, B->part, y);

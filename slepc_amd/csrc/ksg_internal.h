@@ -185,7 +185,9 @@ struct ksg_mat_s {
   ksg_csr_dev diag;          /* columns local (col - col0); entries of a packed column: diag_ncols + its slot */
   int64_t diag_ncols;        /* nc, or the width of the first column group when there are several */
   std::vector<ksg_colgroup> cgs;   /* the column groups after the first (one rank, power-law operators) */
-  ksg_bins bins;             /* the binned part of the local block (one rank, power-law operators); diag then holds the rest */
+  ksg_bins bins;             /* the binned part of the local block (power-law operators); what is left of the block is then cgs[0], diag is empty */
+  ksg_bins gbins;            /* the same for the ghost block: its x is the ghost buffer, its rows the list o_rows */
+  std::vector<ksg_colgroup> gcgs;  /* what is left of a binned ghost block (d_rows: local rows of y) */
   /* packed copy of the x entries of the most referenced columns (power-law operators) */
   int64_t nhot;
   std::vector<int32_t> hot_cols; /* local column of every slot                  */
@@ -228,8 +230,8 @@ int ksg_comm_exchange_host(ksg_ctx ctx, const double *send, const int64_t *sendo
 /* binned part of a power-law block (ksg_bins.hip) */
 int ksg_bins_build(ksg_ctx c, ksg_bins *B, int64_t nrows, int64_t ncols, const int64_t *rowptr, const int32_t *colidx,
                    const double *val, bool has_diag, int64_t dshift, std::vector<int32_t> &lrows, std::vector<int64_t> &lrp,
-                   std::vector<int32_t> &lci, std::vector<double> &lva);
-int ksg_bins_mult(const ksg_bins *B, const double *x, int64_t ncols, double *y, hipStream_t st);
+                   std::vector<int32_t> &lci, std::vector<double> &lva, const int32_t *rowmap);
+int ksg_bins_mult(const ksg_bins *B, const double *x, int64_t ncols, double *y, hipStream_t st, const int32_t *d_rowmap);
 double ksg_bins_bytes(const ksg_bins *B);
 int ksg_bins_to_host(const ksg_bins *B, std::vector<int32_t> &rows, std::vector<int32_t> &cols, std::vector<double> &vals);
 void ksg_bins_free(ksg_bins *B);

@@ -824,13 +824,14 @@ static int column_groups_for(ksg_ctx c, int64_t ncols, int64_t nnz, const int32_
   return G;
 }
 
-/* Whether the local block of a new operator gets a binned part (KSG_OPT_BINS): one rank, a
+/* Whether a block of a new operator (the local block, or the ghost block with the ghost buffer
+ * as its x) gets a binned part (KSG_OPT_BINS): a
  * power-law operator (the test of the packing), and by default an x of 64 MiB or more (R-MAT scale 22: 0.50 ms
  * per product either way; scale 23: 0.98 ms as a CSR, 0.82 ms binned;
  * scale 24: 2.09 ms per product as a CSR, 1.61 ms binned; scale 26: 8.92 ms in column groups,
  * 7.05 ms binned). */
 static bool bins_wanted(ksg_ctx c, int64_t ncols, int64_t nnz, const int32_t *colidx) {
-  if (c->nranks > 1 || c->bins == 1 || ncols < 4096 || ncols > (int64_t)INT32_MAX) return false;
+  if (c->bins == 1 || ncols < 64 || ncols > (int64_t)INT32_MAX) return false;
   if (c->bins == 0 && ncols < ((int64_t)64 << 20) / 8) return false;
   return is_power_law(ncols, nnz, colidx);
 }
@@ -848,7 +849,7 @@ static int diag_to_device(ksg_mat A, int64_t nrows, const int64_t *rowptr, const
     std::vector<int32_t> lrows, lci;
     std::vector<int64_t> lrp;
     std::vector<double> lva;
-    KSG_CHK(ksg_bins_build(c, &A->bins, nrows, A->nc, rowptr, colidx, val, square, A->row0 - A->col0, lrows, lrp, lci, lva));
+    KSG_CHK(ksg_bins_build(c, &A->bins, nrows, A->nc, rowptr, colidx, val, square, A->row0 - A->col0, lrows, lrp, lci, lva, NULL));
     if (A->bins.nent) {
       A->cgs.clear();
       if (!lrows.empty()) {
@@ -977,6 +978,7 @@ static int mat_create(ksg_ctx c, int64_t n, int64_t N, int64_t row0, int64_t nc,
   A->no_rows = 0; A->o_rows = NULL; A->o_nnz = 0;
   memset(&A->ghost, 0, sizeof(A->ghost));
   memset(&A->bins, 0, sizeof(A->bins));
+  memset(&A->gbins, 0, sizeof(A->gbins));
   A->g_nhot = 0; A->d_g_hot_idx = NULL; A->d_g_xhot = NULL;
   A->nghost = A->nsend = 0;
   A->d_ghost = A->d_send = A->h_ghost = A->h_send = NULL; A->d_send_idx = NULL;
@@ -1070,7 +1072,26 @@ static int mat_create(ksg_ctx c, int64_t n, int64_t N, int64_t row0, int64_t nc,
   A->no_rows = (int64_t)o_rows.size();
   A->o_nnz = (int64_t)o_ci.size();
   if (!rc) rc = upload(&A->o_rows, o_rows.data(), o_rows.size());
-  if (!rc && A->no_rows)
+  if (!rc && A->no_rows && bins_wanted(c, A->nghost, A->o_nnz, o_ci.data())) {
+    /* the ghost block in the binned form: its x is the ghost buffer, its rows the compressed list
+     * o_rows (the reduce pass adds into y through that list), what is left a group over some of them */
+    std::vector<int32_t> lrows, lci;
+    std::vector<int64_t> lrp;
+    std::vector<double> lva;
+    rc = ksg_bins_build(c, &A->gbins, A->no_rows, A->nghost, o_rp.data(), o_ci.data(), o_v.data(), false, 0, lrows, lrp, lci, lva, o_rows.data());
+    if (!rc && A->gbins.nent && !lrows.empty()) {
+      for (size_t i = 0; i < lrows.size(); i++) lrows[i] = o_rows[(size_t)lrows[i]];      /* local rows of y */
+      A->gcgs.emplace_back();
+      ksg_colgroup &cg = A->gcgs.back();
+      memset(&cg.blk, 0, sizeof(cg.blk));
+      cg.col_first = 0; cg.ncols = A->nghost; cg.nrows = (int64_t)lrows.size();
+      cg.d_rows = NULL; cg.nhot = 0; cg.d_hot_idx = NULL; cg.d_xhot = NULL;
+      rc = upload(&cg.d_rows, lrows.data(), lrows.size());
+      if (!rc) rc = block_to_device(c, &cg.blk, cg.ncols, cg.nrows, lrp.data(), lci.data(), lva.data(), cg.hot_cols, &cg.nhot, &cg.d_hot_idx,
+                                    &cg.d_xhot);
+    }
+  }
+  if (!rc && A->no_rows && !A->gbins.nent)
     rc = block_to_device(c, &A->ghost, A->nghost, A->no_rows, o_rp.data(), o_ci.data(), o_v.data(), A->g_hot_cols, &A->g_nhot,
                          &A->d_g_hot_idx, &A->d_g_xhot);
   if (!rc) rc = upload(&A->d_send_idx, send_idx.data(), (size_t)A->nsend);
@@ -1113,33 +1134,76 @@ static int download(std::vector<T> &dst, const T *src, size_t count) {
   return KSG_OK;
 }
 
-/* Adds the entries of the binned part (and its folded diagonal) to the rows in rp/ci/va, every
- * row that gains entries in ascending column order. */
-static int bins_merge_host(ksg_mat A, std::vector<int64_t> &rp, std::vector<int32_t> &ci, std::vector<double> &va) {
-  if (!A->bins.nent) return KSG_OK;
-  std::vector<int32_t> br, bc;
-  std::vector<double> bv;
-  KSG_CHK(ksg_bins_to_host(&A->bins, br, bc, bv));
-  std::vector<int64_t> nrp((size_t)A->n + 1, 0);
-  for (int64_t i = 0; i < A->n; i++) nrp[i + 1] = rp[i + 1] - rp[i];
-  for (size_t e = 0; e < br.size(); e++) nrp[(size_t)br[e] + 1]++;
-  for (int64_t i = 0; i < A->n; i++) nrp[i + 1] += nrp[i];
-  std::vector<int32_t> nci((size_t)nrp[A->n]);
-  std::vector<double> nva((size_t)nrp[A->n]);
-  std::vector<int64_t> pos(nrp.begin(), nrp.end() - 1);
-  for (int64_t i = 0; i < A->n; i++)
-    for (int64_t p = rp[i]; p < rp[i + 1]; p++) { nci[(size_t)pos[i]] = ci[(size_t)p]; nva[(size_t)pos[i]] = va[(size_t)p]; pos[i]++; }
-  for (size_t e = 0; e < br.size(); e++) { const int64_t q = pos[br[e]]++; nci[(size_t)q] = bc[e]; nva[(size_t)q] = bv[e]; }
-  std::vector<std::pair<int32_t, double>> row;
-  for (int64_t i = 0; i < A->n; i++) {
-    const int64_t a = nrp[i], b = nrp[i + 1];
-    if (b - a == rp[i + 1] - rp[i]) continue;              /* nothing binned in this row */
-    row.clear();
-    for (int64_t p = a; p < b; p++) row.push_back({nci[(size_t)p], nva[(size_t)p]});
-    std::stable_sort(row.begin(), row.end(), [](const std::pair<int32_t, double> &u, const std::pair<int32_t, double> &v) { return u.first < v.first; });
-    for (int64_t p = a; p < b; p++) { nci[(size_t)p] = row[(size_t)(p - a)].first; nva[(size_t)p] = row[(size_t)(p - a)].second; }
+/* One block of an operator back on the host as a CSR over its `nrows` rows, columns as the block
+ * numbers them: the base CSR `D` (over all rows; the columns of its packed entries named again),
+ * the groups `cgs` (each a CSR over some of the rows: `rows_index` gives, for a group row's entry in
+ * d_rows, the row of this block it stands for -- NULL: d_rows holds those rows themselves) and the
+ * binned part.  Every row in ascending column order when it was given so. */
+static int block_to_host(const ksg_csr_dev &D, const std::vector<int32_t> &hot, int64_t base_ncols, const std::vector<ksg_colgroup> &cgs,
+                         const ksg_bins &bins, int64_t nrows, const std::vector<int32_t> *rows_index, std::vector<int64_t> &rp,
+                         std::vector<int32_t> &ci, std::vector<double> &va) {
+  std::vector<int64_t> drp;
+  std::vector<int32_t> dci;
+  std::vector<double> dva;
+  if (D.rowptr) {
+    KSG_CHK(download(drp, D.rowptr, (size_t)nrows + 1));
+    KSG_CHK(download(dci, D.colidx, (size_t)D.nnz));
+    KSG_CHK(download(dva, D.val, (size_t)D.nnz));
+    if (!hot.empty()) for (size_t p = 0; p < dci.size(); p++) if ((int64_t)dci[p] >= base_ncols) dci[p] = hot[(size_t)((int64_t)dci[p] - base_ncols)];
+  } else {
+    drp.assign((size_t)nrows + 1, 0);
   }
-  rp.swap(nrp); ci.swap(nci); va.swap(nva);
+  if (cgs.empty() && !bins.nent) { rp.swap(drp); ci.swap(dci); va.swap(dva); return KSG_OK; }
+  /* triplets of everything that is not in the base CSR */
+  std::vector<int32_t> tr, tc;
+  std::vector<double> tv;
+  bool ordered = true;                                     /* groups by ascending columns after the base: rows stay sorted without a sort */
+  for (const ksg_colgroup &cg : cgs) {
+    std::vector<int32_t> grows, gci;
+    std::vector<int64_t> grp;
+    std::vector<double> gva;
+    KSG_CHK(download(grows, cg.d_rows, (size_t)cg.nrows));
+    KSG_CHK(download(grp, cg.blk.rowptr, (size_t)cg.nrows + 1));
+    KSG_CHK(download(gci, cg.blk.colidx, (size_t)cg.blk.nnz));
+    KSG_CHK(download(gva, cg.blk.val, (size_t)cg.blk.nnz));
+    if (cg.col_first == 0) ordered = false;                /* the remaining entries of a binned block: any column */
+    for (int64_t i = 0; i < cg.nrows; i++) {
+      int32_t r = grows[(size_t)i];
+      if (rows_index) r = (int32_t)(std::lower_bound(rows_index->begin(), rows_index->end(), r) - rows_index->begin());
+      for (int64_t p = grp[(size_t)i]; p < grp[(size_t)i + 1]; p++) {
+        int64_t col = gci[(size_t)p];
+        if (col >= cg.ncols) col = cg.hot_cols[(size_t)(col - cg.ncols)];
+        tr.push_back(r); tc.push_back((int32_t)(col + cg.col_first)); tv.push_back(gva[(size_t)p]);
+      }
+    }
+  }
+  if (bins.nent) {
+    std::vector<int32_t> br, bc;
+    std::vector<double> bv;
+    KSG_CHK(ksg_bins_to_host(&bins, br, bc, bv));
+    tr.insert(tr.end(), br.begin(), br.end()); tc.insert(tc.end(), bc.begin(), bc.end()); tv.insert(tv.end(), bv.begin(), bv.end());
+    ordered = false;
+  }
+  rp.assign((size_t)nrows + 1, 0);
+  for (int64_t i = 0; i < nrows; i++) rp[i + 1] = drp[i + 1] - drp[i];
+  for (size_t e = 0; e < tr.size(); e++) rp[(size_t)tr[e] + 1]++;
+  for (int64_t i = 0; i < nrows; i++) rp[i + 1] += rp[i];
+  ci.resize((size_t)rp[nrows]); va.resize((size_t)rp[nrows]);
+  std::vector<int64_t> pos(rp.begin(), rp.end() - 1);
+  for (int64_t i = 0; i < nrows; i++)
+    for (int64_t p = drp[i]; p < drp[i + 1]; p++) { ci[(size_t)pos[i]] = dci[p]; va[(size_t)pos[i]] = dva[p]; pos[i]++; }
+  for (size_t e = 0; e < tr.size(); e++) { const int64_t q = pos[tr[e]]++; ci[(size_t)q] = tc[e]; va[(size_t)q] = tv[e]; }
+  if (!ordered) {
+    std::vector<std::pair<int32_t, double>> row;
+    for (int64_t i = 0; i < nrows; i++) {
+      const int64_t a = rp[i], b = rp[i + 1];
+      if (b - a == drp[i + 1] - drp[i]) continue;          /* nothing added to this row */
+      row.clear();
+      for (int64_t p = a; p < b; p++) row.push_back({ci[(size_t)p], va[(size_t)p]});
+      std::stable_sort(row.begin(), row.end(), [](const std::pair<int32_t, double> &u, const std::pair<int32_t, double> &v) { return u.first < v.first; });
+      for (int64_t p = a; p < b; p++) { ci[(size_t)p] = row[(size_t)(p - a)].first; va[(size_t)p] = row[(size_t)(p - a)].second; }
+    }
+  }
   return KSG_OK;
 }
 
@@ -1148,65 +1212,22 @@ static int bins_merge_host(ksg_mat A, std::vector<int64_t> &rp, std::vector<int3
 static int mat_to_host(ksg_mat A, std::vector<int64_t> &rp, std::vector<int32_t> &ci, std::vector<double> &va) {
   ksg_ctx c = A->ctx;
   KSG_HIP(hipSetDevice(c->device));
+  KSG_HIP(hipStreamSynchronize(c->comm_stream));
   KSG_HIP(hipStreamSynchronize(c->stream));
   std::vector<int64_t> drp;
   std::vector<int32_t> dci;
   std::vector<double> dva;
-  if (A->diag.rowptr) {
-    KSG_CHK(download(drp, A->diag.rowptr, (size_t)A->n + 1));
-    KSG_CHK(download(dci, A->diag.colidx, (size_t)A->diag.nnz));
-    KSG_CHK(download(dva, A->diag.val, (size_t)A->diag.nnz));
-    if (A->nhot) for (size_t p = 0; p < dci.size(); p++) if ((int64_t)dci[p] >= A->diag_ncols) dci[p] = A->hot_cols[(size_t)((int64_t)dci[p] - A->diag_ncols)];
-  } else {
-    drp.assign((size_t)A->n + 1, 0);
-  }
-  if (c->nranks == 1 && A->cgs.empty()) {
-    rp.swap(drp); ci.swap(dci); va.swap(dva);
-    return bins_merge_host(A, rp, ci, va);
-  }
+  KSG_CHK(block_to_host(A->diag, A->hot_cols, A->diag_ncols, A->cgs, A->bins, A->n, NULL, drp, dci, dva));
   if (c->nranks == 1) {
-    /* column groups: a row's entries are those of group 0, 1, ... in turn (ascending columns) */
-    const size_t G = A->cgs.size();
-    std::vector<std::vector<int64_t>> grp(G);
-    std::vector<std::vector<int32_t>> gci(G), grows(G);
-    std::vector<std::vector<double>> gva(G);
-    rp.assign((size_t)A->n + 1, 0);
-    for (int64_t i = 0; i < A->n; i++) rp[i + 1] = drp[i + 1] - drp[i];
-    for (size_t g = 0; g < G; g++) {
-      const ksg_colgroup &cg = A->cgs[g];
-      KSG_CHK(download(grows[g], cg.d_rows, (size_t)cg.nrows));
-      KSG_CHK(download(grp[g], cg.blk.rowptr, (size_t)cg.nrows + 1));
-      KSG_CHK(download(gci[g], cg.blk.colidx, (size_t)cg.blk.nnz));
-      KSG_CHK(download(gva[g], cg.blk.val, (size_t)cg.blk.nnz));
-      for (size_t p = 0; p < gci[g].size(); p++) {
-        int64_t col = gci[g][p];
-        if (col >= cg.ncols) col = cg.hot_cols[(size_t)(col - cg.ncols)];
-        gci[g][p] = (int32_t)(col + cg.col_first);
-      }
-      for (int64_t i = 0; i < cg.nrows; i++) rp[grows[g][i] + 1] += grp[g][i + 1] - grp[g][i];
-    }
-    for (int64_t i = 0; i < A->n; i++) rp[i + 1] += rp[i];
-    ci.resize((size_t)rp[A->n]); va.resize((size_t)rp[A->n]);
-    std::vector<int64_t> pos(rp.begin(), rp.end() - 1);
-    for (int64_t i = 0; i < A->n; i++)
-      for (int64_t p = drp[i]; p < drp[i + 1]; p++) { ci[(size_t)pos[i]] = dci[p]; va[(size_t)pos[i]] = dva[p]; pos[i]++; }
-    for (size_t g = 0; g < G; g++)
-      for (int64_t i = 0; i < A->cgs[g].nrows; i++) {
-        const int64_t r = grows[g][i];
-        for (int64_t p = grp[g][i]; p < grp[g][i + 1]; p++) { ci[(size_t)pos[r]] = gci[g][p]; va[(size_t)pos[r]] = gva[g][p]; pos[r]++; }
-      }
-    return bins_merge_host(A, rp, ci, va);
+    rp.swap(drp); ci.swap(dci); va.swap(dva);
+    return KSG_OK;
   }
   std::vector<int32_t> orows, oci;
   std::vector<int64_t> orp;
   std::vector<double> ova;
   KSG_CHK(download(orows, A->o_rows, (size_t)A->no_rows));
-  if (A->no_rows) {
-    KSG_CHK(download(orp, A->ghost.rowptr, (size_t)A->no_rows + 1));
-    KSG_CHK(download(oci, A->ghost.colidx, (size_t)A->o_nnz));
-    KSG_CHK(download(ova, A->ghost.val, (size_t)A->o_nnz));
-    if (A->g_nhot) for (size_t p = 0; p < oci.size(); p++) if ((int64_t)oci[p] >= A->nghost) oci[p] = A->g_hot_cols[(size_t)((int64_t)oci[p] - A->nghost)];
-  } else orp.assign(1, 0);
+  if (A->no_rows) KSG_CHK(block_to_host(A->ghost, A->g_hot_cols, A->nghost, A->gcgs, A->gbins, A->no_rows, &orows, orp, oci, ova));
+  else orp.assign(1, 0);
   rp.assign((size_t)A->n + 1, 0);
   ci.clear(); va.clear();
   ci.reserve((size_t)A->nnz); va.reserve((size_t)A->nnz);
@@ -1315,6 +1336,14 @@ extern "C" int ksg_mat_destroy(ksg_mat A) {
   }
   A->cgs.clear();
   ksg_bins_free(&A->bins);
+  ksg_bins_free(&A->gbins);
+  for (ksg_colgroup &cg : A->gcgs) {
+    csr_free(&cg.blk);
+    if (cg.d_rows) hipFree(cg.d_rows);
+    if (cg.d_hot_idx) hipFree(cg.d_hot_idx);
+    if (cg.d_xhot) hipFree(cg.d_xhot);
+  }
+  A->gcgs.clear();
   if (A->o_rows) hipFree(A->o_rows);
   if (A->d_g_hot_idx) hipFree(A->d_g_hot_idx);
   if (A->d_g_xhot) hipFree(A->d_g_xhot);
@@ -1365,7 +1394,7 @@ static int mat_mult_raw(ksg_mat A, const double *x, double *y) {
   }
   if (A->bins.nent) {
     /* the binned part and the diagonal store y; the remaining entries are added below */
-    KSG_CHK(ksg_bins_mult(&A->bins, x, A->nc, y, c->stream));
+    KSG_CHK(ksg_bins_mult(&A->bins, x, A->nc, y, c->stream, NULL));
   } else if (A->diag.pc_w) {
     launch_rowcode<0>(c->stream, A->diag, x, y, 0.0, 0.0, NULL, NULL);
   } else if (A->diag.ntiles) {
@@ -1386,7 +1415,14 @@ static int mat_mult_raw(ksg_mat A, const double *x, double *y) {
     KSG_CHK(ksg_comm_exchange(c, A));
     KSG_HIP(hipEventRecord(c->ev_halo_done, c->comm_stream));
     KSG_HIP(hipStreamWaitEvent(c->stream, c->ev_halo_done, 0));
-    if (A->no_rows) {
+    if (A->gbins.nent) {
+      /* the ghost block in the binned form: LDS slices of the ghost buffer, sums added into the rows the block touches */
+      KSG_CHK(ksg_bins_mult(&A->gbins, A->d_ghost, A->nghost, y, c->stream, A->o_rows));
+      for (const ksg_colgroup &cg : A->gcgs) {
+        if (cg.nhot) hipLaunchKernelGGL(k_gather, dim3(ksg_grid_for(cg.nhot)), dim3(KSG_BLOCK), 0, c->stream, (const double *)A->d_ghost, cg.d_hot_idx, cg.d_xhot, cg.nhot);
+        launch_tiles<2>(c->stream, cg.blk, A->d_ghost, y, 0.0, 0.0, NULL, NULL, cg.nhot ? cg.d_xhot : NULL, (int32_t)cg.ncols, cg.d_rows);
+      }
+    } else if (A->no_rows) {
       /* the ghost block through the same tile kernel (one lane per row, several lanes per row,
        * whole workgroup for a long row), adding into the rows it touches */
       if (A->g_nhot) hipLaunchKernelGGL(k_gather, dim3(ksg_grid_for(A->g_nhot)), dim3(KSG_BLOCK), 0, c->stream, (const double *)A->d_ghost, A->d_g_hot_idx, A->d_g_xhot, A->g_nhot);
@@ -1414,9 +1450,12 @@ static inline double spmv_bytes(ksg_mat A) {
   for (const ksg_colgroup &cg : A->cgs)       /* entry stream, row list, read-modify-write of the rows touched, packing */
     b += block_stream_bytes(cg.blk) + 20.0 * (double)cg.nrows + 20.0 * (double)cg.nhot;
   b += ksg_bins_bytes(&A->bins);
-  if (A->ctx->nranks > 1)
-    b += (A->no_rows ? block_stream_bytes(A->ghost) : 0.0) + 20.0 * (double)A->no_rows + 20.0 * (double)A->g_nhot +
+  if (A->ctx->nranks > 1) {
+    b += (A->no_rows && !A->gbins.nent ? block_stream_bytes(A->ghost) + 20.0 * (double)A->no_rows : 0.0) + 20.0 * (double)A->g_nhot +
          8.0 * (double)A->nghost + 20.0 * (double)A->nsend;
+    b += ksg_bins_bytes(&A->gbins);
+    for (const ksg_colgroup &cg : A->gcgs) b += block_stream_bytes(cg.blk) + 20.0 * (double)cg.nrows + 20.0 * (double)cg.nhot;
+  }
   return b;
 }
 /* The same product by the plain CSR model (12 bytes per entry, 8 per row pointer, x and y once):
@@ -1461,7 +1500,13 @@ extern "C" int ksg_mat_describe(ksg_mat A, char *buf, size_t len) {
     k += snprintf(buf + k, len - (size_t)k, "; %d column groups of <= %lld columns multiplied one after the other (groups after the first: %lld entries in "
                   "%lld row pieces, %lld packed)", (int)A->cgs.size() + 1, (long long)A->diag_ncols, ent, rows, hot);
   }
-  if (A->ctx->nranks > 1 && k > 0 && (size_t)k < len)
+  if (A->ctx->nranks > 1 && A->gbins.nent && k > 0 && (size_t)k < len) {
+    long long rows = 0, ent = 0;
+    for (const ksg_colgroup &cg : A->gcgs) { rows += cg.nrows; ent += cg.blk.nnz; }
+    snprintf(buf + k, len - (size_t)k, "; ghost block: %lld entries in %lld rows, %lld of them binned (LDS slices of the ghost buffer, %lld runs, %lld row blocks), "
+             "%lld remaining entries in %lld rows through the tile kernel", (long long)A->o_nnz, (long long)A->no_rows, (long long)A->gbins.nreal,
+             (long long)A->gbins.nseg, (long long)A->gbins.nbins, ent, rows);
+  } else if (A->ctx->nranks > 1 && k > 0 && (size_t)k < len)
     snprintf(buf + k, len - (size_t)k, "; ghost block: %lld entries in %lld rows through the same tile kernel (%lld/%lld/%lld tiles, %lld packed)",
              (long long)A->o_nnz, (long long)A->no_rows, (long long)A->ghost.n_stream, (long long)A->ghost.n_group, (long long)A->ghost.n_long,
              (long long)A->g_nhot);

@@ -159,6 +159,16 @@ def run():
         dev = ksgpu.DeviceCSR.__new__(ksgpu.DeviceCSR)
         dev.ctx, dev.lib, dev.h = ctx, ctx.lib, Am.p.contents.data
         res["variant"] = dev.describe()
+        if os.environ.get("KS_CHECK_CSR"):
+            # the rows read back from the device (both blocks, binned parts included) are the input's
+            dev._adopt(dev.h)
+            r2, c2, v2 = dev.get_csr()
+            ok = bool(np.array_equal(r2, rp) and np.array_equal(c2, ci) and np.array_equal(v2, va))
+            if size > 1:
+                oks = [None] * size
+                dist.all_gather_object(oks, ok)
+                ok = all(oks)
+            res["csr_ok"] = ok
         res["rows"] = [row0, row1]
         xv, yv = Am.create_vecs(), Am.create_vecs()
         xv.set_values(np.cos(0.37 * np.arange(row0, row1)) + (np.arange(row0, row1) % 7 == 0))

@@ -56,6 +56,33 @@ def test_rmat_balanced_blocks_match_single(case, ranks):
     assert sum(int(re.search(r"(\d+) packed\)", d).group(1)) for d in many["variant"]) > 0
 
 
+@pytest.mark.parametrize("ranks", [2, 3])
+def test_rmat_binned_blocks_match_single(ranks):
+    """The same split with both blocks of every rank in the binned form (KSG_OPT_BINS forced through
+    the environment, small cells): the ghost block's x is the ghost buffer and its sums are added into
+    the rows it touches; eigenvalues, the product and the rows read back against the plain single rank."""
+    import re
+    from scipy.sparse import csr_matrix
+    from slepc_amd import matgen as mg
+    env = {"KSG_SPMV_BINS": "2", "KSG_BINS_W": "512", "KSG_BINS_H": "128", "KSG_BINS_E": "1024", "KSG_BINS_T": "2", "KS_CHECK_CSR": "1"}
+    one = run_ranks("gpu", "rmat_nnz", 1)
+    many = run_ranks("gpu", "rmat_nnz", ranks, extra_env=env)
+    assert one["reason"] == many["reason"] == 1 and many["csr_ok"]
+    for a, b in zip(one["values"][:4], many["values"][:4]):
+        assert abs(a[0] - b[0]) <= 1e-10 * abs(a[0])
+    assert max(many["errors"]) < 1e-8
+    rp, ci, va = mg.rmat_laplacian(13)
+    N = 1 << 13
+    g = np.arange(N)
+    M = csr_matrix((va, ci, rp), shape=(N, N))
+    xg = np.cos(0.37 * g) + (g % 7 == 0)
+    assert np.all(np.abs(np.array(many["y"]) - M @ xg) <= 1e-14 * (np.abs(M) @ np.abs(xg)))
+    # a rank whose block has fewer than 4096 columns (the hub rows' rank) keeps the plain forms
+    assert any(d.startswith("binned part") for d in many["variant"]), many["variant"]
+    binned_ghost = [re.search(r"ghost block: (\d+) entries in (\d+) rows, (\d+) of them binned", d) for d in many["variant"]]
+    assert any(m and int(m.group(3)) > 0.5 * int(m.group(1)) for m in binned_ghost), many["variant"]
+
+
 @pytest.mark.parametrize("case,ranks", [("svd_tall", 2), ("svd_wide", 3)])
 def test_svd_ranks_match_single(case, ranks):
     """Rectangular operator with rows and columns split over the ranks, its transpose built
