@@ -128,6 +128,50 @@ __global__ __launch_bounds__(BINS_P1_THREADS) void k_bins_expand(const int64_t *
   }
 }
 
+/* data-parallel-primitive moves inside a row of 16 lanes: the value of the lane N places below;
+ * lanes whose source lies outside their row keep `old` */
+template <int N>
+__device__ __forceinline__ int bins_row_shr(int old, int src) { return __builtin_amdgcn_update_dpp(old, src, 0x110 + N, 0xf, 0xf, false); }
+template <int N>
+__device__ __forceinline__ double bins_row_shr(double old, double src) {
+  const long long o = __double_as_longlong(old), v = __double_as_longlong(src);
+  const int lo = __builtin_amdgcn_update_dpp((int)o, (int)v, 0x110 + N, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp((int)(o >> 32), (int)(v >> 32), 0x110 + N, 0xf, 0xf, false);
+  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+/* one step of a segmented scan: f = a stretch starts at or below this lane within the window so far */
+template <int N>
+__device__ __forceinline__ void bins_scan_step(double &v, int &f) {
+  const double vv = bins_row_shr<N>(0.0, v);
+  const int ff = bins_row_shr<N>(1, f);
+  if (!f) { v += vv; f = ff; }
+}
+
+/* The 64 products of one load of a reduce wave into the block's sums.  The products of a cell come
+ * sorted by row, and a row with many entries in a column block of hub columns fills whole stretches
+ * of lanes: additions to one LDS address are done one after the other (all 64 lanes on one row:
+ * 2.7 times the time of distinct rows in tools/bins_stream_probe.hip; a quarter of the pass at
+ * R-MAT scale 24).  When at least half of the lanes repeat the row of the lane before them, every
+ * row of 16 lanes first adds up its stretches of equal rows with a segmented scan in registers
+ * (four DPP steps, no LDS traffic, a fixed order) and only the last lane of a stretch adds to LDS:
+ * the pass 0.71 -> 0.56 ms (scan from 8 / 16 / 32 repeats on, or always: 1.478 / 1.468 / 1.445 /
+ * 1.488 ms per product; without it 1.601 ms).  Every lane of the wave must be active. */
+__device__ __forceinline__ void bins_add_group(double *acc, uint16_t r, double v) {
+  const int ri = (int)r;
+  const int rprev = bins_row_shr<1>(-1, ri);                /* lane 0 of a row of 16: -1, a stretch starts */
+  int f = rprev != ri;
+  if (__popcll(__ballot(f)) > 32) {                         /* uniform over the wave */
+    atomicAdd(&acc[r], v);
+    return;
+  }
+  const int next_starts = __builtin_amdgcn_update_dpp(1, f, 0x101, 0xf, 0xf, false);   /* row_shl:1: the flag of the lane above */
+  bins_scan_step<1>(v, f);
+  bins_scan_step<2>(v, f);
+  bins_scan_step<4>(v, f);
+  bins_scan_step<8>(v, f);
+  if (next_starts) atomicAdd(&acc[r], v);
+}
+
 /* One wave per row block: y[r] = sum of the block's products of row r + dv[r] * x[r + dshift].
  * A block whose first row lies at or beyond nrows is a piece of a long row: it has one row, and
  * its sum goes to part[r0 - nrows] (k_bins_long_rows adds the pieces to y afterwards).
@@ -170,7 +214,8 @@ __global__ __launch_bounds__(64) void k_bins_reduce(const int64_t *__restrict__ 
   }
   for (int i = lane; i < nr; i += 64) acc[i] = 0.0;
   int64_t p = p0 + lane;
-  for (; p + 64 * (BINS_P2_UNROLL - 1) < p1; p += 64 * BINS_P2_UNROLL) {
+  /* whole batches of loads (every lane active: bins_add_group), then one guarded batch for what is left */
+  for (; p - lane + 64 * BINS_P2_UNROLL <= p1; p += 64 * BINS_P2_UNROLL) {
     uint16_t r[BINS_P2_UNROLL];
     double v[BINS_P2_UNROLL];
 #pragma unroll
@@ -179,9 +224,20 @@ __global__ __launch_bounds__(64) void k_bins_reduce(const int64_t *__restrict__ 
       v[j] = __builtin_nontemporal_load(xe + p + 64 * j);
     }
 #pragma unroll
-    for (int j = 0; j < BINS_P2_UNROLL; j++) atomicAdd(&acc[r[j]], v[j]);
+    for (int j = 0; j < BINS_P2_UNROLL; j++) bins_add_group(acc, r[j], v[j]);
   }
-  for (; p < p1; p += 64) atomicAdd(&acc[rowloc[p]], xe[p]);
+  {
+    uint16_t r[BINS_P2_UNROLL];
+    double v[BINS_P2_UNROLL];
+#pragma unroll
+    for (int j = 0; j < BINS_P2_UNROLL; j++) {
+      r[j] = 0; v[j] = 0.0;
+      if (p + 64 * j < p1) { r[j] = rowloc[p + 64 * j]; v[j] = xe[p + 64 * j]; }
+    }
+#pragma unroll
+    for (int j = 0; j < BINS_P2_UNROLL; j++)
+      if (p + 64 * j < p1) atomicAdd(&acc[r[j]], v[j]);
+  }
   /* the wave's own LDS operations complete in order: no barrier between its adds and its reads */
   if (rowmap) {
     /* the block's rows stand for rows rowmap[.] of y, which already holds the other blocks' sums */
@@ -308,8 +364,9 @@ static void bins_build_host(bins_host *B, int64_t nrows, int64_t ncols, const in
                             std::vector<int32_t> &lci, std::vector<double> &lva) {
   *B = bins_host();
   lrows.clear(); lrp.clear(); lci.clear(); lva.clear();
-  /* R-MAT scale 26 (1.13e9 entries): 7.05 ms per product with H = 2048, 7.11 with 4096, 7.21 with 8192 (E = 131072); T = 6: 7.26;
-   * scale 24: W = 16384 1.61 ms, 8192 1.63, 4096 1.69 (profiles/r02_spmv_rmat_binned.txt) */
+  /* R-MAT scale 26 (1.13e9 entries): 6.65 ms per product with H = 2048, 7.27 with 4096; before the reduce pass combined
+   * equal rows: 7.05 / 7.11 / 7.21 ms with H = 2048 / 4096 / 8192 (E = 131072), T = 6: 7.26;
+   * scale 24 then: W = 16384 1.61 ms, 8192 1.63, 4096 1.69 (profiles/r02_spmv_rmat_binned.txt) */
   int W = env_int("KSG_BINS_W", 16384), H = env_int("KSG_BINS_H", 2048);
   const int64_t E = env_int("KSG_BINS_E", 65536);
   const int T = env_int("KSG_BINS_T", 4);

@@ -826,10 +826,9 @@ static int column_groups_for(ksg_ctx c, int64_t ncols, int64_t nnz, const int32_
 
 /* Whether a block of a new operator (the local block, or the ghost block with the ghost buffer
  * as its x) gets a binned part (KSG_OPT_BINS): a
- * power-law operator (the test of the packing), and by default an x of 64 MiB or more (R-MAT scale 22: 0.50 ms
- * per product either way; scale 23: 0.98 ms as a CSR, 0.82 ms binned;
- * scale 24: 2.09 ms per product as a CSR, 1.61 ms binned; scale 26: 8.92 ms in column groups,
- * 7.05 ms binned). */
+ * power-law operator (the test of the packing), and by default an x of 64 MiB or more (R-MAT scale 23:
+ * 0.98 ms per product as a CSR, 0.70 ms binned; scale 24: 2.09 and 1.44 ms; scale 26: 8.92 ms in
+ * column groups, 6.65 ms binned; profiles/r02_spmv_rmat_binned.txt). */
 static bool bins_wanted(ksg_ctx c, int64_t ncols, int64_t nnz, const int32_t *colidx) {
   if (c->bins == 1 || ncols < 64 || ncols > (int64_t)INT32_MAX) return false;
   if (c->bins == 0 && ncols < ((int64_t)64 << 20) / 8) return false;

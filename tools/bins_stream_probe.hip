@@ -190,7 +190,7 @@ int main(int argc, char **argv) {
   {
     uint16_t *rl2; CK(hipMalloc(&rl2, N * 2));
     std::vector<uint16_t> h2((size_t)N);
-    for (int pat = 0; pat < 4; pat++) {
+    for (int pat = 0; pat < 7; pat++) {
       for (int64_t i = 0; i < N; i += 64) {
         uint16_t t[64];
         for (int l = 0; l < 64; l++) t[l] = h[(size_t)(i + l)] & 2047;
@@ -198,11 +198,16 @@ int main(int argc, char **argv) {
         if (pat == 1) { for (int l = 0; l < 64; l++) t[l] = h[(size_t)(i + l / 4)] & 2047; std::sort(t, t + 64); }
         if (pat == 2) { for (int l = 52; l < 64; l++) t[l] = 0; }
         if (pat == 3) { for (int l = 52; l < 64; l++) t[l] = (uint16_t)(l - 52); }
+        if (pat == 4) { for (int l = 0; l < 64; l++) t[l] = h[(size_t)(i + l / 16)] & 2047; std::sort(t, t + 64); }
+        if (pat == 5) { for (int l = 0; l < 64; l++) t[l] = h[(size_t)i] & 2047; }
+        if (pat == 6) { if ((i / 64) % 5 == 0) for (int l = 0; l < 64; l++) t[l] = h[(size_t)i] & 2047; else std::sort(t, t + 64); }
         for (int l = 0; l < 64; l++) h2[(size_t)(i + l)] = t[l];
       }
       CK(hipMemcpy(rl2, h2.data(), N * 2, hipMemcpyHostToDevice));
-      const char *names[4] = {"R1 U=16 add, rows sorted within groups of 64", "R1 U=16 add, every row four times in a row, sorted",
-                              "R1 U=16 add, 12 of 64 lanes add to row 0", "R1 U=16 add, 12 of 64 lanes add to rows 0..11"};
+      const char *names[7] = {"R1 U=16 add, rows sorted within groups of 64", "R1 U=16 add, every row four times in a row, sorted",
+                              "R1 U=16 add, 12 of 64 lanes add to row 0", "R1 U=16 add, 12 of 64 lanes add to rows 0..11",
+                              "R1 U=16 add, every row 16 times in a row", "R1 U=16 add, all 64 lanes of a group the same row",
+                              "R1 U=16 add, one group in five all the same row"};
       timeit(names[pat], N, 10, [&] { hipLaunchKernelGGL((r1<16, true, true>), dim3(nb), dim3(64), H * 8, 0, rl2, xe, y, bin, H); });
     }
     CK(hipFree(rl2));

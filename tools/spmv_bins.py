@@ -31,8 +31,8 @@ def main():
     ctx.vec_fill_hash(x, n, 0, 5)
     y0 = None
     for setting in settings:
-        for k in [k for k in os.environ if k.startswith("KSG_BINS_")]:
-            del os.environ[k]
+        for k in ("W", "H", "E", "T", "TASK_GROUPS", "THREADS"):
+            os.environ.pop("KSG_BINS_" + k, None)
         if setting == "plain":
             ctx.set_option(ksgpu.OPT_BINS, 1)
         else:
