@@ -38,7 +38,7 @@
 
 #define BINS_P1_THREADS 1024    /* most threads of an expand workgroup (launch bound); KSG_BINS_THREADS sets the actual number */
 #ifndef BINS_P1_UNROLL
-#define BINS_P1_UNROLL  8
+#define BINS_P1_UNROLL  16
 #endif
 #ifndef BINS_P2_UNROLL
 #define BINS_P2_UNROLL  16
