@@ -79,3 +79,43 @@ def test_binned_layout_rectangular_and_sparse():
     xl = rng.standard_normal(3600)
     yl, info = _with_env({"KSG_BINS_W": 64, "KSG_BINS_H": 64, "KSG_BINS_T": 500}, lambda: ksgpu.bins_host_check(lp, lc, lv, xl))
     assert info["binned"] == 0 and np.array_equal(yl, csr_matrix((lv, lc, lp)) @ xl)
+
+
+def test_binned_layout_random_blocks():
+    """Random small blocks -- empty rows, rows of one entry, rows longer than a row block may be, columns
+    beyond the last full column block, square with and without a complete diagonal, rectangular -- under
+    random settings of the tuning variables: the walk of the binned arrays gives A x."""
+    rng = np.random.default_rng(12345)
+    built = 0
+    for trial in range(120):
+        n = int(rng.integers(1, 400))
+        nc = n if trial % 3 else int(rng.integers(1, 600))
+        # columns drawn with a skew so that some cells fill up
+        dens = rng.choice([0.5, 2.0, 6.0, 20.0])
+        nnz_t = int(min(n * nc, max(1, dens * n)))
+        rows = rng.integers(0, n, nnz_t)
+        cols = np.minimum((nc * rng.random(nnz_t) ** rng.choice([1.0, 2.0, 4.0])).astype(np.int64), nc - 1)
+        if trial % 4 == 0:                                   # one hub row
+            hub = int(rng.integers(0, n))
+            extra = rng.integers(0, nc, int(rng.integers(50, 900)))
+            rows = np.concatenate([rows, np.full(len(extra), hub)])
+            cols = np.concatenate([cols, extra])
+        if nc == n and trial % 2:                            # a complete diagonal
+            rows = np.concatenate([rows, np.arange(n)])
+            cols = np.concatenate([cols, np.arange(n)])
+        key = np.unique(rows * nc + cols)
+        rows, cols = key // nc, key % nc
+        kind = int(rng.integers(0, 3))
+        vals = rng.standard_normal(len(key)) if kind == 0 else (np.full(len(key), -1.0) if kind == 1 else rng.choice(np.array([0.5, -2.0, 0.0]), len(key)))
+        rp = np.concatenate([[0], np.cumsum(np.bincount(rows, minlength=n))]).astype(np.int64)
+        x = rng.standard_normal(nc)
+        env = {"KSG_BINS_W": int(rng.choice([64, 128, 256, 1024])), "KSG_BINS_H": int(rng.choice([64, 100, 256])),
+               "KSG_BINS_E": int(rng.choice([40, 200, 5000])), "KSG_BINS_T": int(rng.choice([1, 2, 3])),
+               "KSG_BINS_TASK_GROUPS": int(rng.choice([1, 2, 9]))}
+        y, info = _with_env(env, lambda: ksgpu.bins_host_check(rp, cols.astype(np.int32), vals, x, ncols=nc, has_diag=(nc == n)))
+        M = csr_matrix((vals, cols, rp), shape=(n, nc))
+        assert np.all(np.abs(y - M @ x) <= 1e-13 * (np.abs(M) @ np.abs(x) + 1e-300)), (trial, env, info)
+        if info["binned"]:
+            built += 1
+            assert info["binned"] + info["csr_entries"] + (n if info["diagonal_folded"] else 0) == rp[-1]
+    assert built > 40

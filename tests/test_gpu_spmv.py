@@ -508,6 +508,67 @@ def test_binned_product(gpu_ctx, W, H, E, T, values):
         ctx.vec_free(p_)
 
 
+def test_binned_random_blocks(gpu_ctx):
+    """Random small operators with skewed columns, hub rows, empty rows, with and without a complete
+    diagonal, square and rectangular, under random settings of the tuning variables: whatever form
+    the library chooses under KSG_OPT_BINS = always, the product is A x and the rows read back are
+    the input's."""
+    import os
+    from scipy.sparse import csr_matrix
+    from slepc_amd import ksgpu
+    ctx = gpu_ctx
+    rng = np.random.default_rng(4242)
+    keys = ("KSG_BINS_W", "KSG_BINS_H", "KSG_BINS_E", "KSG_BINS_T", "KSG_BINS_TASK_GROUPS")
+    old = {k: os.environ.get(k) for k in keys}
+    binned = 0
+    try:
+        ctx.set_option(ksgpu.OPT_BINS, 2)
+        for trial in range(40):
+            n = int(rng.integers(64, 3000))
+            nc = n if trial % 3 else int(rng.integers(64, 4000))
+            nnz_t = int(rng.choice([2.0, 6.0, 20.0]) * n)
+            rows = rng.integers(0, n, nnz_t)
+            cols = np.minimum((nc * rng.random(nnz_t) ** rng.choice([2.0, 4.0, 6.0])).astype(np.int64), nc - 1)
+            if trial % 4 == 0:
+                extra = rng.integers(0, nc, int(rng.integers(200, 3000)))
+                rows = np.concatenate([rows, np.full(len(extra), int(rng.integers(0, n)))])
+                cols = np.concatenate([cols, extra])
+            if nc == n and trial % 2:
+                rows = np.concatenate([rows, np.arange(n)])
+                cols = np.concatenate([cols, np.arange(n)])
+            key = np.unique(rows * nc + cols)
+            rows, cols = key // nc, (key % nc).astype(np.int32)
+            kind = int(rng.integers(0, 3))
+            vals = rng.standard_normal(len(key)) if kind == 0 else (np.full(len(key), -1.0) if kind == 1 else rng.choice(np.array([0.5, -2.0, 0.0]), len(key)))
+            rp = np.concatenate([[0], np.cumsum(np.bincount(rows, minlength=n))]).astype(np.int64)
+            os.environ.update({"KSG_BINS_W": str(rng.choice([64, 256, 1024])), "KSG_BINS_H": str(rng.choice([64, 100, 256])),
+                               "KSG_BINS_E": str(rng.choice([40, 200, 5000])), "KSG_BINS_T": str(rng.choice([1, 2, 3])),
+                               "KSG_BINS_TASK_GROUPS": str(rng.choice([1, 2, 9]))})
+            A = ksgpu.DeviceCSR(ctx, rp, cols, vals, cols=None if nc == n else (nc, nc, 0))
+            binned += "binned part" in A.describe()
+            x = rng.standard_normal(nc)
+            xd, yd = ctx.vec_alloc(nc), ctx.vec_alloc(n)
+            ctx.upload(xd, x)
+            ctx.upload(yd, np.full(n, np.nan))
+            A.mult(xd, yd)
+            y = ctx.download(yd, n)
+            M = csr_matrix((vals, cols, rp), shape=(n, nc))
+            assert np.all(np.abs(y - M @ x) <= 1e-13 * (np.abs(M) @ np.abs(x) + 1e-300)), (trial, A.describe())
+            r1, c1, v1 = A.get_csr()
+            assert np.array_equal(r1, rp) and np.array_equal(c1, cols) and np.array_equal(v1, vals), (trial, A.describe())
+            A.destroy()
+            ctx.vec_free(xd)
+            ctx.vec_free(yd)
+    finally:
+        ctx.set_option(ksgpu.OPT_BINS, 0)
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    assert binned >= 10, binned
+
+
 @pytest.mark.parametrize("gen", ["lap1d", "lap2d", "lap3d", "band"])
 def test_row_code_kernel_equals_tile_kernel(gpu_ctx, gen):
     """Stencils and other banded operators with few distinct (column - row, value) pairs are
