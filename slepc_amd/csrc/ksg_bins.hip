@@ -15,7 +15,8 @@
  *   reduce : the rows are cut into blocks of at most H rows and E entries; one wave holds a
  *            block's partial sums in LDS, streams the block's products (8 bytes) and row
  *            numbers within the block (2 bytes), adds them up with LDS atomics (one wave per
- *            block: the order of the additions is fixed), adds the diagonal term and stores y.
+ *            block: the order of the additions is fixed; stretches of lanes that share a row are
+ *            added up in registers first), adds the diagonal term and stores y.
  *            A row longer than E is cut into pieces, each summed by a wave of its own in
  *            registers; the sums of the pieces are added to the row afterwards, in their order.
  *
@@ -658,6 +659,13 @@ extern "C" int ksg_bins_host_check(int64_t nrows, int64_t ncols, const int64_t *
                                    int has_diag, int64_t dshift, const double *x, double *y, int64_t info[6]) {
   if (!rowptr || !x || !y || nrows < 0 || ncols < 0 || (rowptr[nrows] && (!colidx || !val)))
     KSG_FAIL(KSG_ERR_ARG, "ksg_bins_host_check: bad arguments");
+  if (rowptr[0] != 0) KSG_FAIL(KSG_ERR_ARG, "ksg_bins_host_check: rowptr[0] must be 0");
+  for (int64_t r = 0; r < nrows; r++) {
+    if (rowptr[r + 1] < rowptr[r]) KSG_FAIL(KSG_ERR_ARG, "ksg_bins_host_check: rowptr decreases at row %lld", (long long)r);
+    for (int64_t p = rowptr[r]; p < rowptr[r + 1]; p++)
+      if (colidx[p] < 0 || (int64_t)colidx[p] >= ncols)
+        KSG_FAIL(KSG_ERR_ARG, "ksg_bins_host_check: column %d of row %lld outside [0,%lld)", colidx[p], (long long)r, (long long)ncols);
+  }
   bins_host B;
   std::vector<int32_t> lrows, lci;
   std::vector<int64_t> lrp;
