@@ -137,6 +137,27 @@ __global__ __launch_bounds__(T) void es(const uint16_t *__restrict__ c16, double
   }
 }
 
+// RS: reduce-like with the products read run by run from scattered places: run k (rl entries) starts at src[k]; the rows
+// stream in order.  What the second pass would do if the first wrote its products in its own order.
+template <int U>
+__global__ __launch_bounds__(64) void rs(const uint16_t *__restrict__ rl, const double *__restrict__ xe, double *__restrict__ y, int64_t bin, int H,
+                                         const int64_t *__restrict__ src, int rlen) {
+  extern __shared__ double acc[];
+  const int lane = threadIdx.x;
+  for (int i = lane; i < H; i += 64) acc[i] = 0.0;
+  const int64_t p0 = (int64_t)blockIdx.x * bin, p1 = p0 + bin;
+  for (int64_t p = p0 + lane; p + 64 * (U - 1) < p1; p += 64 * U) {
+    uint16_t r[U]; int64_t s[U]; double v[U];
+#pragma unroll
+    for (int j = 0; j < U; j++) { r[j] = __builtin_nontemporal_load(rl + p + 64 * j); s[j] = src[(p + 64 * j) / rlen]; }
+#pragma unroll
+    for (int j = 0; j < U; j++) v[j] = __builtin_nontemporal_load(xe + s[j] + (p + 64 * j) % rlen);
+#pragma unroll
+    for (int j = 0; j < U; j++) atomicAdd(&acc[r[j] & (H - 1)], v[j]);
+  }
+  for (int i = lane; i < H; i += 64) y[(int64_t)blockIdx.x * H + i] = acc[i];
+}
+
 template <class F>
 static void timeit(const char *name, int64_t n, double bytes_per_entry, F f) {
   hipEvent_t a, b;
@@ -211,6 +232,20 @@ int main(int argc, char **argv) {
       timeit(names[pat], N, 10, [&] { hipLaunchKernelGGL((r1<16, true, true>), dim3(nb), dim3(64), H * 8, 0, rl2, xe, y, bin, H); });
     }
     CK(hipFree(rl2));
+  }
+  // the second pass reading scattered runs
+  for (int rlen : {8, 16, 32, 64, 256}) for (int shift : {0, 3}) {
+    const int64_t nrun = N / rlen;
+    std::vector<int64_t> perm((size_t)nrun);
+    for (int64_t k = 0; k < nrun; k++) perm[(size_t)k] = k;
+    uint64_t z = 7654321;
+    for (int64_t k = nrun - 1; k > 0; k--) { z ^= z << 13; z ^= z >> 7; z ^= z << 17; std::swap(perm[(size_t)k], perm[(size_t)(z % (uint64_t)(k + 1))]); }
+    for (int64_t k = 0; k < nrun; k++) perm[(size_t)k] = perm[(size_t)k] * rlen + (perm[(size_t)k] == nrun - 1 ? 0 : shift);
+    int64_t *srcd; CK(hipMalloc(&srcd, nrun * 8)); CK(hipMemcpy(srcd, perm.data(), nrun * 8, hipMemcpyHostToDevice));
+    char name[128];
+    snprintf(name, sizeof name, "RS U=16 wave/bin, add, products read in scattered runs of %3d%s", rlen, shift ? ", off by 24 bytes" : "");
+    timeit(name, N, 10, [&] { hipLaunchKernelGGL((rs<16>), dim3(nb), dim3(64), H * 8, 0, rl, xe, y, bin, H, srcd, rlen); });
+    CK(hipFree(srcd));
   }
   // scattered runs: the groups of 64 entries in runs of rl groups; run k goes to position perm[k] * rl * 64 (+ shift)
   for (int rlen : {1, 2}) for (int shift : {0, 3, 8, 16, 100, 101}) {
