@@ -56,7 +56,7 @@ def test_rmat_balanced_blocks_match_single(case, ranks):
     assert sum(int(re.search(r"(\d+) packed\)", d).group(1)) for d in many["variant"]) > 0
 
 
-@pytest.mark.parametrize("ranks", [2, 3])
+@pytest.mark.parametrize("ranks", [2, 3, 8])
 def test_rmat_binned_blocks_match_single(ranks):
     """The same split with both blocks of every rank in the binned form (KSG_OPT_BINS forced through
     the environment, small cells): the ghost block's x is the ghost buffer and its sums are added into
