@@ -425,7 +425,8 @@ def main():
         roofline = None
         if dom:
             kname = {"dotvec": "k_dotw", "multvec": "k_multvec_dot",
-                     "matmult": "k_spmv_rowcode" if spmv_variant.startswith("row codes") else "k_spmv_tiles"}[dom]
+                     "matmult": "k_spmv_rowcode" if spmv_variant.startswith("row codes") else
+                     "k_bins_expand + k_bins_reduce" if spmv_variant.startswith("binned part") else "k_spmv_tiles"}[dom]
             ach = st[dom]["bytes"] / st[dom]["ms"] / 1e6
             per_launch = st[dom]["bytes"] / st[dom]["calls"]
             roofline = {"bound": "hbm", "kernel": kname,
