@@ -800,6 +800,7 @@ int ksg_bins_to_host(const ksg_bins *B, std::vector<int32_t> &rows, std::vector<
   std::vector<int64_t> starts(order.size());
   for (size_t i = 0; i < order.size(); i++) starts[i] = binp0[(size_t)order[i]];
   rows.reserve((size_t)(B->nent + (B->dv ? B->nrows : 0))); cols.reserve(rows.capacity()); vals.reserve(rows.capacity());
+  int64_t cur_lo = 0, cur_hi = 0, cur_r0 = 0;
   for (int64_t t = 0; t < B->ntasks; t++) {
     const int64_t cb = tasks[3 * t];
     for (int64_t g = tasks[3 * t + 1]; g < tasks[3 * t + 2]; g++) {
@@ -809,9 +810,12 @@ int ksg_bins_to_host(const ksg_bins *B, std::vector<int32_t> &rows, std::vector<
         if (l && (col16[(size_t)p] & 0x8000u)) seg++;
         const int64_t q = p + D[(size_t)seg];
         if (q >= B->nent || (col16[(size_t)p] & 0x7fffu) == (unsigned)B->W) continue;   /* fill of a group or of a run */
-        /* the block that holds product q */
-        const int64_t i = (int64_t)(std::upper_bound(starts.begin(), starts.end(), q) - starts.begin()) - 1;
-        const int64_t r0 = r0s[(size_t)order[(size_t)i]];
+        /* the block that holds product q (consecutive products mostly share it) */
+        if (q < cur_lo || q >= cur_hi) {
+          const int64_t i = (int64_t)(std::upper_bound(starts.begin(), starts.end(), q) - starts.begin()) - 1;
+          cur_lo = starts[(size_t)i]; cur_hi = binp1[(size_t)order[(size_t)i]]; cur_r0 = r0s[(size_t)order[(size_t)i]];
+        }
+        const int64_t r0 = cur_r0;
         rows.push_back(r0 >= B->nrows ? piece_row[(size_t)(r0 - B->nrows)] : (int32_t)(r0 + rowloc[(size_t)q]));
         cols.push_back((int32_t)(cb * B->W + (col16[(size_t)p] & 0x7fffu)));
         vals.push_back(B->vmode == 0 ? B->vconst : B->vmode == 1 ? tab[vidx[(size_t)p]] : val1[(size_t)p]);
