@@ -205,3 +205,77 @@ def test_rmat_scale22_solve_matches_oracle(gpu_ctx):
     assert max(errs) < 10 * tol
     eps.destroy()
     A.destroy()
+
+
+def test_markov3000_first_restarts_match_oracle(gpu_ctx):
+    """BASELINE configuration 4 at its full size -- ex5's Markov chain, m = 3000 (4.5M rows, 1.8e7 entries),
+    nonsymmetric Krylov-Schur, largest real part, nev = 16 (ncv = 32), start vector e0 + e1 (ex5.c:86-94):
+    the Ritz values (real and imaginary parts) and error estimates the product reports after each of the
+    first three restarts against the CPU restatement on its compiled kernels."""
+    from oracle import ckern, eps as oeps
+    from slepc_amd import kseps as K, matgen
+    m, nev, its = 3000, 16, 3
+    rp, ci, va = matgen.markov(m)
+    n = len(rp) - 1
+    assert n == m * (m + 1) // 2
+    start = np.zeros(n)
+    start[:2] = 1.0
+    A = K.Mat.create_aij_hip(gpu_ctx, rp, ci, va)
+    eps = K.EPS(gpu_ctx.h)
+    eps.set_operators(A)
+    eps.set_problem_type(K.EPS_NHEP)
+    eps.set_which(K.EPS_LARGEST_REAL)
+    eps.set_dimensions(nev)
+    eps.set_tolerances(0.0, its)
+    v0 = A.create_vecs()
+    v0.set_values(start)
+    eps.set_initial_space([v0])
+    got = {}
+    eps.set_monitor(lambda i, nconv, er, ei, ee, nest: got.__setitem__(i, (er[:nev].copy(), ei[:nev].copy(), ee[:nev].copy(), nconv)))
+    eps.solve()
+    assert eps.dimensions()[1] == 32
+    kern = ckern.Kernels(16)
+    want = {}
+    o = oeps.EPS(kern.csr(rp, ci, va).mult, n, hermitian=False, nev=nev, max_it=its, which="largest_real", v0=start, bv_factory=kern.bv,
+                 monitor=lambda i, nconv, er, ei, ee, nv: want.__setitem__(i, (er[:nev].copy(), ei[:nev].copy(), ee[:nev].copy(), nconv)))
+    o.solve()
+    assert o.ncv == 32 and sorted(got) == sorted(want) == [1, 2, 3]
+    for i in (1, 2, 3):
+        assert got[i][3] == want[i][3]
+        assert np.abs(got[i][0] - want[i][0]).max() <= 1e-10 and np.abs(got[i][1] - want[i][1]).max() <= 1e-10
+        assert np.abs(got[i][2] - want[i][2]).max() <= 1e-6 * max(want[i][2].max(), 1e-30) + 1e-12
+    v0.destroy()
+    eps.destroy()
+    A.destroy()
+
+
+def test_lap3d_256_first_restarts_match_oracle(gpu_ctx):
+    """The 3-D 7-point Laplacian of BASELINE configuration 3 on a 256^3 grid (16.7M rows, the rows one of
+    eight GPUs owns at 512^3), nev = 32, ncv = 64, default start vector: the Ritz values and error
+    estimates after each of the first two restarts against the CPU restatement on its compiled kernels."""
+    from oracle import ckern, eps as oeps
+    from slepc_amd import kseps as K, matgen
+    g, nev, its = 256, 32, 2
+    rp, ci, va = matgen.laplacian3d(g, g, g)
+    n = g ** 3
+    A = K.Mat.create_aij_hip(gpu_ctx, rp, ci, va)
+    eps = K.EPS(gpu_ctx.h)
+    eps.set_operators(A)
+    eps.set_problem_type(K.EPS_HEP)
+    eps.set_dimensions(nev)
+    eps.set_tolerances(0.0, its)
+    got = {}
+    eps.set_monitor(lambda i, nconv, er, ei, ee, nest: got.__setitem__(i, (er[:nev].copy(), ee[:nev].copy(), nest)))
+    eps.solve()
+    kern = ckern.Kernels(16)
+    want = {}
+    o = oeps.EPS(kern.csr(rp, ci, va).mult, n, hermitian=True, nev=nev, max_it=its, bv_factory=kern.bv,
+                 monitor=lambda i, nconv, er, ei, ee, nv: want.__setitem__(i, (er[:nev].copy(), ee[:nev].copy(), nv)))
+    o.solve()
+    assert sorted(got) == sorted(want) == [1, 2]
+    for i in (1, 2):
+        assert got[i][2] == want[i][2] == 64
+        assert np.abs(got[i][0] - want[i][0]).max() <= 1e-10 * 12.0
+        assert np.abs(got[i][1] - want[i][1]).max() <= 1e-7 * max(want[i][1].max(), 1e-30) + 1e-12
+    eps.destroy()
+    A.destroy()
