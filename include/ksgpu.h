@@ -238,7 +238,11 @@ int ksg_bv_matmult(ksg_bv V, ksg_mat A, ksg_bv W);
  * matrix is split into the diagonal block and the ghost block and the gather
  * lists of the halo exchange are built (collective), as MatMPIAIJ does inside
  * PETSc.  Stands in for MatCreateAIJ + MatSetValues + MatAssembly as used by
- * the examples (ex2.c:50-66). */
+ * the examples (ex2.c:50-66).  From a million entries on, the passes over the entries
+ * (validation, column counts, value tables, row codes, the binned build) run on host
+ * threads: KSG_HOST_THREADS of them, else OMP_NUM_THREADS, else the machine's, at most
+ * 16; the operator built is the same for any number.  KSG_SETUP_TIMING=1 prints the
+ * stages on stderr. */
 int ksg_mat_create_csr(ksg_ctx ctx, int64_t n_local, int64_t N, int64_t row0,
                        const int64_t *rowptr, const int32_t *colidx, const double *val,
                        ksg_mat *A);

@@ -342,11 +342,13 @@ struct bins_host {
   int W = 0, H = 0, vmode = 2;
   bool fold_diag = false;
   double vconst = 0.0;
-  std::vector<uint16_t> col16, rowloc;
-  std::vector<uint8_t> vidx;
-  std::vector<double> vtab, val, dv;
-  std::vector<uint32_t> gfirst;
-  std::vector<int64_t> D, tasks, binp0, binp1;
+  ksg_hvec<uint16_t> col16, rowloc;                       /* the large arrays: filled by the build's threads, never cleared first */
+  ksg_hvec<uint8_t> vidx;
+  ksg_hvec<double> val, dv;
+  ksg_hvec<uint32_t> gfirst;
+  ksg_hvec<int64_t> D;
+  std::vector<double> vtab;
+  std::vector<int64_t> tasks, binp0, binp1;
   std::vector<int32_t> r0s, nrs;
   std::vector<int32_t> long_rows, long_first, piece_row;   /* rows cut into pieces; their pieces long_first[j] .. long_first[j+1]; row of every piece */
 };
@@ -382,13 +384,26 @@ static void bins_build_host(bins_host *B, int64_t nrows, int64_t ncols, const in
   const int64_t NC = (ncols + W - 1) >> wshift;
   if (nnz == 0 || nrows == 0 || NC > (int64_t)INT32_MAX || nrows > (int64_t)INT32_MAX / 2) return;
 
+  ksg_phase_timer tm("binned build");
+  /* the passes over the entries run on several host threads; every array comes out the same
+   * whatever their number (parts are consecutive rows or units, joined in order) */
+  const int NT = nnz >= ((int64_t)1 << 20) ? ksg_host_threads() : 1;
+
   /* the diagonal is folded into the reduce pass only when every row has it exactly once */
   bool fold = has_diag;
-  for (int64_t r = 0; r < nrows && fold; r++) {
-    int seen = 0;
-    for (int64_t p = rowptr[r]; p < rowptr[r + 1]; p++) if ((int64_t)colidx[p] == r + dshift) seen++;
-    if (seen != 1) fold = false;
+  if (fold) {
+    std::vector<char> bad((size_t)NT, 0);
+    ksg_parallel(NT, [&](int t, int nt) {
+      const int64_t ra = ksg_split_rows(rowptr, nrows, t, nt), rb = ksg_split_rows(rowptr, nrows, t + 1, nt);
+      for (int64_t r = ra; r < rb; r++) {
+        int seen = 0;
+        for (int64_t p = rowptr[r]; p < rowptr[r + 1]; p++) if ((int64_t)colidx[p] == r + dshift) seen++;
+        if (seen != 1) { bad[(size_t)t] = 1; break; }
+      }
+    });
+    for (int t = 0; t < NT; t++) if (bad[(size_t)t]) fold = false;
   }
+  tm.lap("diagonal check");
 
   /* row blocks: consecutive rows, at most H rows and E entries.  A row longer than E belongs to a
    * block (which stores its diagonal term) but its entries are cut into pieces of at most E, each
@@ -418,133 +433,213 @@ static void bins_build_host(bins_host *B, int64_t nrows, int64_t ncols, const in
     B->long_first.push_back((int32_t)B->piece_row.size());
   }
   const int64_t NB = (int64_t)blocks.size();
+  /* the units in NT consecutive parts of about as many entries each: part t is ub[t] .. ub[t+1] */
+  std::vector<int64_t> ub((size_t)NT + 1, NB);
+  {
+    std::vector<int64_t> w((size_t)NB + 1, 0);
+    for (int64_t b = 0; b < NB; b++) {
+      const bins_block &k = blocks[(size_t)b];
+      w[(size_t)b + 1] = w[(size_t)b] + (k.e0 >= 0 ? k.e1 - k.e0 : rowptr[(int64_t)k.r0 + k.nr] - rowptr[k.r0]);
+    }
+    for (int t = 0; t < NT; t++)
+      ub[(size_t)t] = t == 0 ? 0 : (int64_t)(std::lower_bound(w.begin(), w.end(), w[(size_t)NB] / NT * t) - w.begin());
+    for (int t = 1; t <= NT; t++) ub[(size_t)t] = std::max(std::min(ub[(size_t)t], NB), ub[(size_t)t - 1]);
+  }
+  tm.lap("row blocks");
 
   /* cells: per unit the entries per column block; cells of at least T entries (any cell of a
    * piece) are binned, laid out unit by unit, within a unit by column block */
-  std::vector<bins_seg> S;
+  ksg_hvec<bins_seg> S;
   std::vector<int64_t> segb((size_t)NB + 1, 0);            /* runs of unit b: S[segb[b] .. segb[b+1]) */
   std::vector<int64_t> bp0((size_t)NB), bp1((size_t)NB);
+  std::vector<int64_t> sfirst((size_t)NT + 1, 0);          /* part t's runs: S[sfirst[t] .. sfirst[t+1]) */
   {
-    std::vector<int32_t> cnt((size_t)NC, 0), touched;
-    int64_t pos2 = 0, nreal = 0;
-    for (int64_t b = 0; b < NB; b++) {
-      const bins_block &k = blocks[(size_t)b];
-      touched.clear();
-      bp0[b] = pos2;
-      for (int64_t r = k.r0; r < (int64_t)k.r0 + k.nr; r++) {
-        int64_t pa = rowptr[r], pb = rowptr[r + 1];
-        if (k.e0 >= 0) { pa = k.e0; pb = k.e1; }
-        else if (pb - pa > E) continue;
-        for (int64_t p = pa; p < pb; p++) {
-          if (fold && (int64_t)colidx[p] == r + dshift) continue;
-          const int32_t cb = colidx[p] >> wshift;
-          if (cnt[cb]++ == 0) touched.push_back(cb);
+    std::vector<std::vector<bins_seg>> St((size_t)NT);
+    std::vector<int64_t> tpos((size_t)NT + 1, 0), treal((size_t)NT, 0);
+    ksg_parallel(NT, [&](int t, int) {
+      std::vector<bins_seg> &Sl = St[(size_t)t];
+      std::vector<int32_t> cnt((size_t)NC, 0), touched;
+      int64_t pos2 = 0, nreal = 0;                         /* counted from the part's first product */
+      for (int64_t b = ub[(size_t)t]; b < ub[(size_t)t + 1]; b++) {
+        const bins_block &k = blocks[(size_t)b];
+        touched.clear();
+        bp0[(size_t)b] = pos2;
+        const size_t before = Sl.size();
+        for (int64_t r = k.r0; r < (int64_t)k.r0 + k.nr; r++) {
+          int64_t pa = rowptr[r], pb = rowptr[r + 1];
+          if (k.e0 >= 0) { pa = k.e0; pb = k.e1; }
+          else if (pb - pa > E) continue;
+          for (int64_t p = pa; p < pb; p++) {
+            if (fold && (int64_t)colidx[p] == r + dshift) continue;
+            const int32_t cb = colidx[p] >> wshift;
+            if (cnt[(size_t)cb]++ == 0) touched.push_back(cb);
+          }
         }
-      }
-      std::sort(touched.begin(), touched.end());
-      for (int32_t cb : touched) {
-        if (cnt[cb] >= T || k.e0 >= 0) {
-          const int32_t padded = (cnt[cb] + BINS_RUN_ALIGN - 1) / BINS_RUN_ALIGN * BINS_RUN_ALIGN;
-          S.push_back({cb, padded, cnt[cb], pos2, 0}); pos2 += padded; nreal += cnt[cb];
+        std::sort(touched.begin(), touched.end());
+        for (int32_t cb : touched) {
+          if (cnt[(size_t)cb] >= T || k.e0 >= 0) {
+            const int32_t padded = (cnt[(size_t)cb] + BINS_RUN_ALIGN - 1) / BINS_RUN_ALIGN * BINS_RUN_ALIGN;
+            Sl.push_back({cb, padded, cnt[(size_t)cb], pos2, 0}); pos2 += padded; nreal += cnt[(size_t)cb];
+          }
+          cnt[(size_t)cb] = 0;
         }
-        cnt[cb] = 0;
+        segb[(size_t)b + 1] = (int64_t)(Sl.size() - before);
+        bp1[(size_t)b] = pos2;
       }
-      segb[b + 1] = (int64_t)S.size();
-      bp1[b] = pos2;
+      tpos[(size_t)t + 1] = pos2; treal[(size_t)t] = nreal;
+    });
+    int64_t nreal = 0;
+    for (int t = 0; t < NT; t++) {
+      tpos[(size_t)t + 1] += tpos[(size_t)t];
+      sfirst[(size_t)t + 1] = sfirst[(size_t)t] + (int64_t)St[(size_t)t].size();
+      nreal += treal[(size_t)t];
     }
-    B->nent = pos2; B->nreal = nreal;
+    for (int64_t b = 0; b < NB; b++) segb[(size_t)b + 1] += segb[(size_t)b];
+    B->nent = tpos[(size_t)NT]; B->nreal = nreal;
+    if (B->nreal * 2 < nnz || (uint64_t)sfirst[(size_t)NT] >= (uint64_t)UINT32_MAX - (uint64_t)NC) { *B = bins_host(); return; }
+    S.resize((size_t)sfirst[(size_t)NT]);
+    ksg_parallel(NT, [&](int t, int) {
+      const int64_t off = tpos[(size_t)t];
+      bins_seg *dst = S.data() + sfirst[(size_t)t];
+      const std::vector<bins_seg> &Sl = St[(size_t)t];
+      for (size_t i = 0; i < Sl.size(); i++) { dst[i] = Sl[i]; dst[i].pos2 += off; }
+      for (int64_t b = ub[(size_t)t]; b < ub[(size_t)t + 1]; b++) { bp0[(size_t)b] += off; bp1[(size_t)b] += off; }
+      std::vector<bins_seg>().swap(St[(size_t)t]);
+    });
   }
-  if (B->nreal * 2 < nnz || S.size() >= (size_t)UINT32_MAX - (size_t)NC) { *B = bins_host(); return; }
+  tm.lap("cells");
   B->W = W; B->H = H; B->nrows = nrows; B->fold_diag = fold; B->dshift = dshift;
 
   /* the expand order: by column block, within it by unit; every column block's stream is padded
    * to whole groups of 64 entries (the padding forms a run of its own whose products land in 64
    * spare slots behind the last product) */
-  const int64_t nseg = (int64_t)S.size();
   std::vector<int64_t> centries((size_t)NC, 0), csegs((size_t)NC, 0);
-  for (int64_t i = 0; i < nseg; i++) { centries[S[i].c] += S[i].cnt; csegs[S[i].c]++; }
   std::vector<int64_t> cpos((size_t)NC + 1, 0), cseg((size_t)NC + 1, 0);
+  std::vector<std::vector<int64_t>> he((size_t)NT), hs((size_t)NT);   /* per part: entries and runs per column block, then where they start */
+  ksg_parallel(NT, [&](int t, int) {
+    he[(size_t)t].assign((size_t)NC, 0); hs[(size_t)t].assign((size_t)NC, 0);
+    for (int64_t i = sfirst[(size_t)t]; i < sfirst[(size_t)t + 1]; i++) { he[(size_t)t][(size_t)S[(size_t)i].c] += S[(size_t)i].cnt; hs[(size_t)t][(size_t)S[(size_t)i].c]++; }
+  });
   for (int64_t cb = 0; cb < NC; cb++) {
-    const int64_t pad = (64 - centries[cb] % 64) % 64;
-    cpos[cb + 1] = cpos[cb] + centries[cb] + pad;
-    cseg[cb + 1] = cseg[cb] + csegs[cb] + (pad ? 1 : 0);
-  }
-  const int64_t nent1 = cpos[NC], nseg1 = cseg[NC], ngroups = nent1 / 64;
-  std::vector<int64_t> &D = B->D;
-  D.resize((size_t)nseg1);
-  std::vector<int64_t> P1((size_t)nseg1 + 1);
-  {
-    std::vector<int64_t> fseg(cseg.begin(), cseg.end() - 1), fpos(cpos.begin(), cpos.end() - 1);
-    for (int64_t i = 0; i < nseg; i++) {
-      const int32_t cb = S[i].c;
-      const int64_t j = fseg[cb]++, p1 = fpos[cb];
-      fpos[cb] += S[i].cnt;
-      S[i].pos1 = p1;
-      D[j] = S[i].pos2 - p1;
-      P1[j] = p1;
+    for (int t = 0; t < NT; t++) { centries[(size_t)cb] += he[(size_t)t][(size_t)cb]; csegs[(size_t)cb] += hs[(size_t)t][(size_t)cb]; }
+    const int64_t pad = (64 - centries[(size_t)cb] % 64) % 64;
+    cpos[(size_t)cb + 1] = cpos[(size_t)cb] + centries[(size_t)cb] + pad;
+    cseg[(size_t)cb + 1] = cseg[(size_t)cb] + csegs[(size_t)cb] + (pad ? 1 : 0);
+    int64_t fe = cpos[(size_t)cb], fs = cseg[(size_t)cb];
+    for (int t = 0; t < NT; t++) {
+      const int64_t e = he[(size_t)t][(size_t)cb], s = hs[(size_t)t][(size_t)cb];
+      he[(size_t)t][(size_t)cb] = fe; hs[(size_t)t][(size_t)cb] = fs;
+      fe += e; fs += s;
     }
-    for (int64_t cb = 0; cb < NC; cb++)
-      if (fpos[cb] < cpos[cb + 1]) { const int64_t j = fseg[cb]++; D[j] = B->nent - fpos[cb]; P1[j] = fpos[cb]; }
-    P1[nseg1] = nent1;
   }
-  std::vector<uint32_t> &gfirst = B->gfirst;
+  const int64_t nent1 = cpos[(size_t)NC], nseg1 = cseg[(size_t)NC], ngroups = nent1 / 64;
+  ksg_hvec<int64_t> &D = B->D;
+  D.resize((size_t)nseg1);
+  ksg_hvec<int64_t> P1((size_t)nseg1 + 1);
+  ksg_parallel(NT, [&](int t, int) {
+    std::vector<int64_t> &fpos = he[(size_t)t], &fseg = hs[(size_t)t];
+    for (int64_t i = sfirst[(size_t)t]; i < sfirst[(size_t)t + 1]; i++) {
+      bins_seg &s = S[(size_t)i];
+      const int64_t j = fseg[(size_t)s.c]++, p1 = fpos[(size_t)s.c];
+      fpos[(size_t)s.c] += s.cnt;
+      s.pos1 = p1;
+      D[(size_t)j] = s.pos2 - p1;
+      P1[(size_t)j] = p1;
+    }
+  });
+  for (int64_t cb = 0; cb < NC; cb++) {
+    const int64_t p = cpos[(size_t)cb] + centries[(size_t)cb];
+    if (p < cpos[(size_t)cb + 1]) { const int64_t j = cseg[(size_t)cb] + csegs[(size_t)cb]; D[(size_t)j] = B->nent - p; P1[(size_t)j] = p; }
+  }
+  P1[(size_t)nseg1] = nent1;
+  ksg_hvec<uint32_t> &gfirst = B->gfirst;
   gfirst.resize((size_t)ngroups);
-  for (int64_t j = 0; j < nseg1; j++)
-    for (int64_t g = (P1[j] + 63) / 64; g * 64 < P1[j + 1]; g++) gfirst[g] = (uint32_t)j;
-  { std::vector<int64_t>().swap(P1); }
+  ksg_parallel(NT, [&](int t, int nt) {
+    for (int64_t j = nseg1 * t / nt; j < nseg1 * (t + 1) / nt; j++)
+      for (int64_t g = (P1[(size_t)j] + 63) / 64; g * 64 < P1[(size_t)j + 1]; g++) gfirst[(size_t)g] = (uint32_t)j;
+  });
+  { ksg_hvec<int64_t>().swap(P1); std::vector<std::vector<int64_t>>().swap(he); std::vector<std::vector<int64_t>>().swap(hs); }
+  tm.lap("expand order");
 
   /* the entries themselves: columns and values in the expand order, rows in the reduce order, the
    * diagonal as a dense vector; what is not binned goes to the CSR of the remaining entries (the
    * row blocks come first and in row order, so that CSR is in row order too) */
-  std::vector<uint16_t> &col16 = B->col16, &rowloc = B->rowloc;
-  std::vector<double> &val1 = B->val;
-  col16.assign((size_t)nent1, 0); rowloc.resize((size_t)B->nent);
-  val1.assign((size_t)nent1, 0.0);
-  if (fold) B->dv.assign((size_t)nrows, 0.0);
-  for (int64_t cb = 0; cb < NC; cb++) {
-    const int64_t p = cpos[cb] + centries[cb];
-    if (p < cpos[cb + 1]) col16[(size_t)p] = 0x8000u;       /* first padding entry opens the padding run */
-  }
-  lci.reserve((size_t)(nnz - B->nreal)); lva.reserve((size_t)(nnz - B->nreal));
-  std::vector<uint8_t> pad((size_t)nent1, 0);             /* entries that stand for nothing: the fill of the runs and of the groups */
+  ksg_hvec<uint16_t> &col16 = B->col16, &rowloc = B->rowloc;
+  ksg_hvec<double> &val1 = B->val;
+  col16.resize((size_t)nent1); rowloc.resize((size_t)B->nent);
+  val1.resize((size_t)nent1);
+  if (fold) B->dv.resize((size_t)nrows);
+  ksg_hvec<uint8_t> pad((size_t)nent1);                   /* entries that stand for nothing: the fill of the runs and of the groups */
   for (int64_t cb = 0; cb < NC; cb++)
-    for (int64_t p = cpos[cb] + centries[cb]; p < cpos[cb + 1]; p++) pad[(size_t)p] = 1;
-  lrp.push_back(0);
-  {
-    std::vector<int64_t> segid((size_t)NC, -1);
-    std::vector<int32_t> fill((size_t)NC, 0);
-    for (int64_t b = 0; b < NB; b++) {
-      const bins_block &k = blocks[(size_t)b];
-      for (int64_t i = segb[b]; i < segb[b + 1]; i++) { segid[S[i].c] = i; fill[S[i].c] = 0; }
-      for (int64_t r = k.r0; r < (int64_t)k.r0 + k.nr; r++) {
-        int64_t pa = rowptr[r], pb = rowptr[r + 1];
-        const bool longrow = k.e0 < 0 && pb - pa > E;       /* its entries are binned with its pieces */
-        if (k.e0 >= 0) { pa = k.e0; pb = k.e1; }
-        const size_t before = lci.size();
-        for (int64_t p = pa; p < pb; p++) {
-          if (fold && (int64_t)colidx[p] == r + dshift) { if (k.e0 < 0) B->dv[(size_t)r] = val[p]; continue; }
-          if (longrow) continue;
-          const int32_t cb = colidx[p] >> wshift;
-          const int64_t i = segid[cb];
-          if (i < 0) { lci.push_back(colidx[p]); lva.push_back(val[p]); continue; }
-          const int32_t f = fill[cb]++;
-          col16[(size_t)(S[i].pos1 + f)] = (uint16_t)((colidx[p] & (W - 1)) | (f == 0 ? 0x8000 : 0));
-          val1[(size_t)(S[i].pos1 + f)] = val[p];
-          rowloc[(size_t)(S[i].pos2 + f)] = (uint16_t)(r - k.r0);
-        }
-        if (lci.size() > before) { lrows.push_back((int32_t)r); lrp.push_back((int64_t)lci.size()); }
-      }
-      for (int64_t i = segb[b]; i < segb[b + 1]; i++) {
-        segid[S[i].c] = -1;
-        for (int32_t f = S[i].real; f < S[i].cnt; f++) {     /* the fill: column W (x = 0 there), any row of the unit */
-          col16[(size_t)(S[i].pos1 + f)] = (uint16_t)W;
-          pad[(size_t)(S[i].pos1 + f)] = 1;
-          rowloc[(size_t)(S[i].pos2 + f)] = (uint16_t)((f - S[i].real) % k.nr);
-        }
-      }
+    for (int64_t p0 = cpos[(size_t)cb] + centries[(size_t)cb], p = p0; p < cpos[(size_t)cb + 1]; p++) {
+      col16[(size_t)p] = p == p0 ? 0x8000u : 0;           /* the first padding entry opens the padding run */
+      val1[(size_t)p] = 0.0; pad[(size_t)p] = 1;
     }
+  tm.lap("allocate entry arrays");
+  {
+    std::vector<std::vector<int32_t>> tci((size_t)NT), trows((size_t)NT);
+    std::vector<std::vector<double>> tva((size_t)NT);
+    std::vector<std::vector<int64_t>> trp((size_t)NT);      /* ends of the part's rows, counted from the part's first entry */
+    ksg_parallel(NT, [&](int t, int) {
+      std::vector<int64_t> segid((size_t)NC, -1);
+      std::vector<int32_t> fill((size_t)NC, 0);
+      std::vector<int32_t> &lc = tci[(size_t)t], &lr = trows[(size_t)t];
+      std::vector<double> &lv = tva[(size_t)t];
+      std::vector<int64_t> &lp = trp[(size_t)t];
+      for (int64_t b = ub[(size_t)t]; b < ub[(size_t)t + 1]; b++) {
+        const bins_block &k = blocks[(size_t)b];
+        for (int64_t i = segb[(size_t)b]; i < segb[(size_t)b + 1]; i++) { segid[(size_t)S[(size_t)i].c] = i; fill[(size_t)S[(size_t)i].c] = 0; }
+        for (int64_t r = k.r0; r < (int64_t)k.r0 + k.nr; r++) {
+          int64_t pa = rowptr[r], pb = rowptr[r + 1];
+          const bool longrow = k.e0 < 0 && pb - pa > E;     /* its entries are binned with its pieces */
+          if (k.e0 >= 0) { pa = k.e0; pb = k.e1; }
+          const size_t before = lc.size();
+          for (int64_t p = pa; p < pb; p++) {
+            if (fold && (int64_t)colidx[p] == r + dshift) { if (k.e0 < 0) B->dv[(size_t)r] = val[p]; continue; }
+            if (longrow) continue;
+            const int32_t cb = colidx[p] >> wshift;
+            const int64_t i = segid[(size_t)cb];
+            if (i < 0) { lc.push_back(colidx[p]); lv.push_back(val[p]); continue; }
+            const int32_t f = fill[(size_t)cb]++;
+            const bins_seg &s = S[(size_t)i];
+            col16[(size_t)(s.pos1 + f)] = (uint16_t)((colidx[p] & (W - 1)) | (f == 0 ? 0x8000 : 0));
+            val1[(size_t)(s.pos1 + f)] = val[p];
+            pad[(size_t)(s.pos1 + f)] = 0;
+            rowloc[(size_t)(s.pos2 + f)] = (uint16_t)(r - k.r0);
+          }
+          if (lc.size() > before) { lr.push_back((int32_t)r); lp.push_back((int64_t)lc.size()); }
+        }
+        for (int64_t i = segb[(size_t)b]; i < segb[(size_t)b + 1]; i++) {
+          const bins_seg &s = S[(size_t)i];
+          segid[(size_t)s.c] = -1;
+          for (int32_t f = s.real; f < s.cnt; f++) {           /* the fill: column W (x = 0 there), any row of the unit */
+            col16[(size_t)(s.pos1 + f)] = (uint16_t)W;
+            val1[(size_t)(s.pos1 + f)] = 0.0;
+            pad[(size_t)(s.pos1 + f)] = 1;
+            rowloc[(size_t)(s.pos2 + f)] = (uint16_t)((f - s.real) % k.nr);
+          }
+        }
+      }
+    });
+    /* the remaining entries of the parts, one behind the other */
+    std::vector<int64_t> eoff((size_t)NT + 1, 0), roff((size_t)NT + 1, 0);
+    for (int t = 0; t < NT; t++) { eoff[(size_t)t + 1] = eoff[(size_t)t] + (int64_t)tci[(size_t)t].size(); roff[(size_t)t + 1] = roff[(size_t)t] + (int64_t)trows[(size_t)t].size(); }
+    lci.resize((size_t)eoff[(size_t)NT]); lva.resize((size_t)eoff[(size_t)NT]);
+    lrows.resize((size_t)roff[(size_t)NT]); lrp.resize((size_t)roff[(size_t)NT] + 1);
+    lrp[0] = 0;
+    ksg_parallel(NT, [&](int t, int) {
+      if (!tci[(size_t)t].empty()) {
+        memcpy(lci.data() + eoff[(size_t)t], tci[(size_t)t].data(), tci[(size_t)t].size() * sizeof(int32_t));
+        memcpy(lva.data() + eoff[(size_t)t], tva[(size_t)t].data(), tva[(size_t)t].size() * sizeof(double));
+      }
+      for (size_t i = 0; i < trows[(size_t)t].size(); i++) {
+        lrows[(size_t)roff[(size_t)t] + i] = trows[(size_t)t][i];
+        lrp[(size_t)roff[(size_t)t] + i + 1] = eoff[(size_t)t] + trp[(size_t)t][i];
+      }
+    });
   }
-  { std::vector<bins_seg>().swap(S); }
+  { ksg_hvec<bins_seg>().swap(S); }
+  tm.lap("entries");
 
   /* every unit stores its rows of y (or its piece's sum); the units with the most products are
    * started first */
@@ -562,21 +657,19 @@ static void bins_build_host(bins_host *B, int64_t nrows, int64_t ncols, const in
     B->nbins = NB;
   }
 
-  /* values: one, at most 256, or as they are (the padding entries take no part) */
-  std::vector<double> &tab = B->vtab;
-  std::vector<uint8_t> &vidx = B->vidx;
+  tm.lap("unit order");
+  /* values: one, at most 256 (a table in the order in which the expand order meets them), or as
+   * they are; the padding entries take no part */
   B->vmode = 2;
   {
-    if (ksg_build_value_table(nent1, val1.data(), pad.data(), 256, tab, vidx)) {
-      int distinct = 0;
-      for (int64_t p = 0; p < nent1; p++) if (!pad[(size_t)p]) distinct = std::max(distinct, (int)vidx[(size_t)p] + 1);
-      if (distinct == 1) { B->vmode = 0; B->vconst = tab[0]; }
-      else B->vmode = 1;
-    }
-    if (B->vmode != 1) { std::vector<uint8_t>().swap(vidx); tab.clear(); }
-    if (B->vmode != 2) std::vector<double>().swap(val1);
+    const int distinct = ksg_build_value_table(nent1, val1.data(), pad.data(), 256, B->vtab, B->vidx);
+    if (distinct == 1) { B->vmode = 0; B->vconst = B->vtab[0]; }
+    else if (distinct > 1) B->vmode = 1;
+    if (B->vmode != 1) { ksg_hvec<uint8_t>().swap(B->vidx); B->vtab.clear(); }
+    if (B->vmode != 2) ksg_hvec<double>().swap(val1);
   }
 
+  tm.lap("value table");
   /* expand tasks: a column block's groups in pieces of at most TG groups, the longest first */
   const int64_t TG = env_int("KSG_BINS_TASK_GROUPS", 2048);
   {
@@ -594,6 +687,7 @@ static void bins_build_host(bins_host *B, int64_t nrows, int64_t ncols, const in
       for (int k = 0; k < 3; k++) B->tasks[(size_t)(3 * i + k)] = t3[(size_t)(3 * order[(size_t)i] + k)];
     B->ntasks = nt;
   }
+  tm.lap("tasks");
   B->nent1 = nent1; B->nseg = nseg1;
 }
 

@@ -15,6 +15,16 @@ void ksg_set_error(const char *fmt, ...) {
 
 extern "C" const char *ksg_last_error(void) { return g_err; }
 
+int ksg_host_threads(void) {
+  int n = 0;
+  const char *e = getenv("KSG_HOST_THREADS");
+  if (e && atoi(e) > 0) n = atoi(e);
+  if (!n) { e = getenv("OMP_NUM_THREADS"); if (e && atoi(e) > 0) n = atoi(e); }
+  if (!n) n = (int)std::thread::hardware_concurrency();
+  if (n < 1) n = 1;
+  return n > 16 ? 16 : n;
+}
+
 int ksg_comm_destroy(ksg_ctx c);
 extern "C" int ksg_ctx_destroy(ksg_ctx c);
 

@@ -5,7 +5,13 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
+#include <algorithm>
+#include <chrono>
+#include <new>
+#include <thread>
+#include <utility>
 #include <vector>
 
 #include "ksgpu.h"
@@ -26,6 +32,86 @@ void ksg_set_error(const char *fmt, ...);
 #define KSG_CHK(call) do { int r_ = (call); if (r_) return r_; } while (0)
 
 enum { KSG_COMM_NONE = 0, KSG_COMM_RCCL = 1, KSG_COMM_CALLBACKS = 2 };
+
+/* ---- host threads for the set-up of an operator (the passes over its entries) ---- */
+
+/* KSG_HOST_THREADS, else OMP_NUM_THREADS, else the machine's hardware threads; at most 16. */
+int ksg_host_threads(void);
+
+/* fn(t, T) for t = 0 .. T-1, each on a host thread of its own (t = 0 on the caller's).  Parts for
+ * which no thread could be started run on the caller's thread afterwards. */
+template <class F>
+static inline void ksg_parallel(int T, F fn) {
+  if (T <= 1) { fn(0, 1); return; }
+  std::vector<std::thread> th;
+  th.reserve((size_t)T - 1);
+  int started = 1;
+  try {
+    for (; started < T; started++) { const int t = started; th.emplace_back([&fn, t, T] { fn(t, T); }); }
+  } catch (...) { }
+  fn(0, T);
+  for (auto &x : th) x.join();
+  for (int t = started; t < T; t++) fn(t, T);
+}
+
+/* First row of part t when rows 0 .. nrows-1 are cut into T parts of about as many entries each. */
+static inline int64_t ksg_split_rows(const int64_t *rowptr, int64_t nrows, int t, int T) {
+  if (t <= 0) return 0;
+  if (t >= T) return nrows;
+  const int64_t want = rowptr[0] + (rowptr[nrows] - rowptr[0]) / T * t;
+  return (int64_t)(std::lower_bound(rowptr, rowptr + nrows + 1, want) - rowptr);
+}
+
+/* Allocator whose elements start out uninitialised: resize() of a vector of several GiB touches
+ * no page, the threads that fill it do. */
+template <class T>
+struct ksg_noinit_alloc {
+  typedef T value_type;
+  ksg_noinit_alloc() noexcept {}
+  template <class U> ksg_noinit_alloc(const ksg_noinit_alloc<U> &) noexcept {}
+  T *allocate(size_t n) { return static_cast<T *>(::operator new(n * sizeof(T))); }
+  void deallocate(T *p, size_t) noexcept { ::operator delete(p); }
+  template <class U> void construct(U *p) noexcept { ::new ((void *)p) U; }
+  template <class U, class... A> void construct(U *p, A &&...a) { ::new ((void *)p) U(std::forward<A>(a)...); }
+  template <class U> bool operator==(const ksg_noinit_alloc<U> &) const noexcept { return true; }
+  template <class U> bool operator!=(const ksg_noinit_alloc<U> &) const noexcept { return false; }
+};
+template <class T> using ksg_hvec = std::vector<T, ksg_noinit_alloc<T>>;
+
+/* KSG_SETUP_TIMING=1: the stages of an operator's set-up, in seconds, on stderr. */
+struct ksg_phase_timer {
+  const char *who;
+  bool on;
+  std::chrono::steady_clock::time_point t;
+  explicit ksg_phase_timer(const char *w) : who(w), on(getenv("KSG_SETUP_TIMING") && atoi(getenv("KSG_SETUP_TIMING")) > 0),
+                                           t(std::chrono::steady_clock::now()) {}
+  void lap(const char *what) {
+    if (!on) return;
+    const auto now = std::chrono::steady_clock::now();
+    fprintf(stderr, "%s: %-28s %.3f s\n", who, what, std::chrono::duration<double>(now - t).count());
+    t = now;
+  }
+};
+
+/* Up to 257 distinct 64-bit patterns and the number each was given: open addressing over 1024 slots. */
+struct ksg_value_set {
+  uint64_t key[1024];
+  int num[1024];
+  ksg_value_set() { for (int i = 0; i < 1024; i++) num[i] = -1; }
+  static unsigned slot(uint64_t bits) { return (unsigned)((bits * 0x9E3779B97F4A7C15ull) >> 54); }
+  int find(uint64_t bits) const {
+    unsigned h = slot(bits);
+    while (num[h] >= 0 && key[h] != bits) h = (h + 1) & 1023;
+    return num[h];
+  }
+  /* the number of `bits`; a pattern not seen before gets `next` */
+  int find_or_add(uint64_t bits, int next) {
+    unsigned h = slot(bits);
+    while (num[h] >= 0 && key[h] != bits) h = (h + 1) & 1023;
+    if (num[h] < 0) { key[h] = bits; num[h] = next; }
+    return num[h];
+  }
+};
 
 struct ksg_timer { hipEvent_t e0, e1; int ev; };
 
@@ -235,9 +321,10 @@ int ksg_bins_mult(const ksg_bins *B, const double *x, int64_t ncols, double *y, 
 double ksg_bins_bytes(const ksg_bins *B);
 int ksg_bins_to_host(const ksg_bins *B, std::vector<int32_t> &rows, std::vector<int32_t> &cols, std::vector<double> &vals);
 void ksg_bins_free(ksg_bins *B);
-/* indices of the entries' values in a table of their distinct bit patterns (ksg_spmv.hip) */
-bool ksg_build_value_table(int64_t nnz, const double *val, const uint8_t *skip, size_t limit, std::vector<double> &tab,
-                           std::vector<uint8_t> &idx);
+/* indices of the entries' values in a table of their distinct bit patterns; the number of distinct
+ * values or -1 for more than `limit` (ksg_spmv.hip) */
+int ksg_build_value_table(int64_t nnz, const double *val, const uint8_t *skip, size_t limit, std::vector<double> &tab,
+                          ksg_hvec<uint8_t> &idx);
 
 /* workspace helpers */
 int ksg_scratch_bind(ksg_ctx ctx);                /* ksg_bv.hip; the context's device must be current */

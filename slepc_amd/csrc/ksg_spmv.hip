@@ -564,20 +564,46 @@ static int upload(T **dst, const T *src, size_t count) {
   return KSG_OK;
 }
 
+/* Host threads for a pass over nnz entries (one below a million). */
+static int setup_threads(int64_t nnz) { return nnz >= ((int64_t)1 << 20) ? ksg_host_threads() : 1; }
+
+/* Entries per column of one block, counted once for the decisions that need them (binned form,
+ * column groups, packed columns). */
+struct col_counts {
+  const int32_t *of = NULL;        /* the index array counted */
+  std::vector<int32_t> cnt;
+};
+
+/* cnt[j] = entries in column j. */
+static void count_columns(int64_t ncols, int64_t nnz, const int32_t *colidx, std::vector<int32_t> &cnt) {
+  cnt.assign((size_t)ncols, 0);
+  int32_t *c = cnt.data();
+  ksg_parallel(setup_threads(nnz), [&](int t, int nt) {
+    if (nt == 1) { for (int64_t p = 0; p < nnz; p++) c[colidx[p]]++; return; }
+    for (int64_t p = nnz * t / nt; p < nnz * (t + 1) / nt; p++) __atomic_fetch_add(&c[colidx[p]], 1, __ATOMIC_RELAXED);
+  });
+}
+
+static const std::vector<int32_t> &counts_of(col_counts *cc, col_counts &own, int64_t ncols, int64_t nnz, const int32_t *colidx) {
+  col_counts &k = cc ? *cc : own;
+  if (k.of != colidx || (int64_t)k.cnt.size() != ncols) { count_columns(ncols, nnz, colidx, k.cnt); k.of = colidx; }
+  return k.cnt;
+}
+
 /* Chooses the columns whose x entries are kept packed (see KSG_OPT_HOT_COLS): those referenced
  * at least four times as often as the average, the most referenced first, at most `maxhot`,
  * and only when they hold 15 % of the entries and x is much larger than the packed array.
  * On success `hot` lists them and `relabeled` is a copy of colidx in which their entries carry
  * ncols + slot; both stay empty when nothing is packed. */
 static void choose_hot_columns(int64_t ncols, int64_t nnz, const int32_t *colidx, int64_t maxhot,
-                               std::vector<int32_t> &hot, std::vector<int32_t> &relabeled) {
+                               std::vector<int32_t> &hot, std::vector<int32_t> &relabeled, col_counts *cc = NULL) {
   hot.clear(); relabeled.clear();
   /* the packed array has to stay much smaller than x: operators too small for the full limit
    * get the 2 MiB (one half of an XCD's L2) that suits them */
   if (ncols <= 4 * maxhot && maxhot > 262144) maxhot = 262144;
   if (maxhot <= 0 || ncols <= 4 * maxhot || nnz == 0 || ncols + maxhot > (int64_t)INT32_MAX) return;
-  std::vector<int32_t> cnt((size_t)ncols, 0);
-  for (int64_t p = 0; p < nnz; p++) cnt[colidx[p]]++;
+  col_counts own;
+  const std::vector<int32_t> &cnt = counts_of(cc, own, ncols, nnz, colidx);
   const int64_t thresh = std::max<int64_t>(8, 4 * ((nnz + ncols - 1) / ncols));
   for (int64_t j = 0; j < ncols; j++) if (cnt[j] >= thresh) hot.push_back((int32_t)j);
   /* most referenced first; ties by column, so that every run packs alike */
@@ -589,42 +615,64 @@ static void choose_hot_columns(int64_t ncols, int64_t nnz, const int32_t *colidx
   std::vector<int32_t> slot((size_t)ncols, -1);
   for (size_t h = 0; h < hot.size(); h++) slot[hot[h]] = (int32_t)h;
   relabeled.resize((size_t)nnz);
-  for (int64_t p = 0; p < nnz; p++) {
-    const int32_t s = slot[colidx[p]];
-    relabeled[p] = s >= 0 ? (int32_t)(ncols + s) : colidx[p];
-  }
+  ksg_parallel(setup_threads(nnz), [&](int t, int nt) {
+    for (int64_t p = nnz * t / nt; p < nnz * (t + 1) / nt; p++) {
+      const int32_t sl = slot[colidx[p]];
+      relabeled[p] = sl >= 0 ? (int32_t)(ncols + sl) : colidx[p];
+    }
+  });
 }
 
-/* Indices of the entries' values in a table of their distinct bit patterns (at most `limit`);
- * entries with skip[p] set are left out (their index becomes 255).  false: too many values. */
-bool ksg_build_value_table(int64_t nnz, const double *val, const uint8_t *skip, size_t limit, std::vector<double> &tab,
-                           std::vector<uint8_t> &idx) {
+/* Indices of the entries' values in a table of their distinct bit patterns, numbered in the order
+ * in which the entries meet them; entries with skip[p] set are left out (their index becomes 255).
+ * Returns the number of distinct values, or -1 when there are more than `limit` (at most 256).
+ * Two passes on several host threads: every part lists the patterns it meets, the lists are
+ * joined in order, then the indices are looked up. */
+int ksg_build_value_table(int64_t nnz, const double *val, const uint8_t *skip, size_t limit, std::vector<double> &tab,
+                          ksg_hvec<uint8_t> &idx) {
   tab.clear();
-  idx.assign((size_t)nnz, 255);
-  /* values are told apart by their bits; open addressing over 1024 slots, at most 256 in use */
-  uint64_t hkey[1024];
-  int hval[1024];
-  for (int t = 0; t < 1024; t++) hval[t] = -1;
-  uint64_t lastbits = 0;
-  int last = -1;
-  for (int64_t p = 0; p < nnz; p++) {
-    if (skip && skip[p]) continue;
-    uint64_t bits;
-    memcpy(&bits, &val[p], 8);
-    if (last < 0 || bits != lastbits) {
-      unsigned h = (unsigned)((bits * 0x9E3779B97F4A7C15ull) >> 54);
-      while (hval[h] >= 0 && hkey[h] != bits) h = (h + 1) & 1023;
-      if (hval[h] < 0) {
-        if (tab.size() == limit) return false;
-        hkey[h] = bits; hval[h] = (int)tab.size();
-        tab.push_back(val[p]);
-      }
-      last = hval[h]; lastbits = bits;
+  idx.clear();
+  const int NT = setup_threads(nnz);
+  std::vector<std::vector<uint64_t>> seen((size_t)NT);
+  ksg_parallel(NT, [&](int t, int nt) {
+    std::vector<uint64_t> &mine = seen[(size_t)t];
+    ksg_value_set set;
+    uint64_t lastbits = 0;
+    bool have = false;
+    for (int64_t p = nnz * t / nt; p < nnz * (t + 1) / nt; p++) {
+      if (skip && skip[p]) continue;
+      uint64_t bits;
+      memcpy(&bits, &val[p], 8);
+      if (have && bits == lastbits) continue;
+      lastbits = bits; have = true;
+      if (set.find_or_add(bits, (int)mine.size()) == (int)mine.size()) mine.push_back(bits);
+      if (mine.size() > limit) return;
     }
-    idx[(size_t)p] = (uint8_t)last;
+  });
+  ksg_value_set all;
+  std::vector<uint64_t> order;
+  for (int t = 0; t < NT; t++) {
+    if (seen[(size_t)t].size() > limit) return -1;
+    for (size_t i = 0; i < seen[(size_t)t].size(); i++) {
+      if (all.find_or_add(seen[(size_t)t][i], (int)order.size()) == (int)order.size()) order.push_back(seen[(size_t)t][i]);
+      if (order.size() > limit) return -1;
+    }
   }
-  tab.resize(256, 0.0);
-  return true;
+  tab.assign(256, 0.0);
+  for (size_t i = 0; i < order.size(); i++) memcpy(&tab[i], &order[i], 8);
+  idx.resize((size_t)nnz);
+  ksg_parallel(NT, [&](int t, int nt) {
+    uint64_t lastbits = 0;
+    int last = -1;
+    for (int64_t p = nnz * t / nt; p < nnz * (t + 1) / nt; p++) {
+      if (skip && skip[p]) { idx[(size_t)p] = 255; continue; }
+      uint64_t bits;
+      memcpy(&bits, &val[p], 8);
+      if (last < 0 || bits != lastbits) { last = all.find(bits); lastbits = bits; }
+      idx[(size_t)p] = (uint8_t)last;
+    }
+  });
+  return (int)order.size();
 }
 
 /* diag_cols: for a block that holds the operator's diagonal, the column index every entry had
@@ -638,9 +686,11 @@ static int csr_to_device(ksg_csr_dev *D, int64_t nrows, const int64_t *rowptr, c
                          const int32_t *row_ids = NULL, int64_t dv_len = 0) {
   D->nrows = nrows;
   D->nnz = rowptr[nrows];
+  ksg_phase_timer tm("csr block");
   std::vector<int32_t> tiles;
   build_tiles(nrows, rowptr, tiles, &D->n_stream, &D->n_group, &D->n_long);
   D->ntiles = (int64_t)tiles.size() - 1;
+  tm.lap("tiles");
   KSG_CHK(upload(&D->rowptr, rowptr, (size_t)nrows + 1));
   KSG_CHK(upload(&D->colidx, colidx, (size_t)D->nnz));
   KSG_CHK(upload(&D->val, val, (size_t)D->nnz));
@@ -648,13 +698,14 @@ static int csr_to_device(ksg_csr_dev *D, int64_t nrows, const int64_t *rowptr, c
   std::vector<int64_t> tile_p(tiles.size());
   for (size_t i = 0; i < tiles.size(); i++) tile_p[i] = rowptr[tiles[i]];
   KSG_CHK(upload(&D->tile_p, tile_p.data(), tile_p.size()));
+  tm.lap("upload");
   /* at most 256 distinct values: one-byte indices into a table for the product kernel; failing
    * that, at most 255 distinct values off the diagonal and the diagonal as a dense vector */
   D->nvt = 0;
   if (D->nnz >= 4096) {
     std::vector<double> tab;
-    std::vector<uint8_t> idx;
-    if (ksg_build_value_table(D->nnz, val, NULL, 256, tab, idx)) D->nvt = 1;
+    ksg_hvec<uint8_t> idx;
+    if (ksg_build_value_table(D->nnz, val, NULL, 256, tab, idx) >= 0) D->nvt = 1;
     else if (diag_cols && dshift > -(int64_t)INT32_MAX && dshift < (int64_t)INT32_MAX) {
       std::vector<uint8_t> isdiag((size_t)D->nnz, 0);
       std::vector<double> dv((size_t)(row_ids ? dv_len : nrows), 0.0);
@@ -666,7 +717,7 @@ static int csr_to_device(ksg_csr_dev *D, int64_t nrows, const int64_t *rowptr, c
           if ((int64_t)diag_cols[p] == want) { isdiag[(size_t)p] = 1; dv[(size_t)(row_ids ? want : r)] = val[p]; seen++; }
         if (seen > 1) one_per_row = false;              /* duplicate entries: leave the matrix as it is */
       }
-      if (one_per_row && ksg_build_value_table(D->nnz, val, isdiag.data(), 255, tab, idx)) {
+      if (one_per_row && ksg_build_value_table(D->nnz, val, isdiag.data(), 255, tab, idx) >= 0) {
         KSG_CHK(upload(&D->dvals, dv.data(), dv.size()));
         D->dshift = row_ids ? 0 : (int32_t)dshift;      /* the kernel reads dvals[column - dshift] */
         D->nvt = 2;
@@ -677,6 +728,7 @@ static int csr_to_device(ksg_csr_dev *D, int64_t nrows, const int64_t *rowptr, c
       KSG_CHK(upload(&D->vtab, tab.data(), tab.size()));
     }
   }
+  tm.lap("value table");
   /* row offsets inside the tiles (a tile that is one long row has no use for them) */
   std::vector<uint16_t> rowoff((size_t)nrows + (size_t)D->ntiles + 1, 0);
   for (int64_t i = 0; i < D->ntiles; i++) {
@@ -684,6 +736,7 @@ static int csr_to_device(ksg_csr_dev *D, int64_t nrows, const int64_t *rowptr, c
     if (rowptr[tiles[i + 1]] - base > KSG_TILE_NNZ) continue;
     for (int64_t r = tiles[i]; r <= tiles[i + 1]; r++) rowoff[(size_t)(r + i)] = (uint16_t)(rowptr[r] - base);
   }
+  tm.lap("row offsets");
   KSG_CHK(upload(&D->rowoff, rowoff.data(), rowoff.size()));
   return KSG_OK;
 }
@@ -716,39 +769,92 @@ static double cross_xcd_cost(const std::vector<int32_t> &offs, int C) {
  * entries with little padding, at most 256 distinct (column - row - shift, value) pairs. */
 static int rowcode_to_device(ksg_csr_dev *D, int64_t nrows, const int64_t *rowptr, const int32_t *colidx, const double *val,
                              int64_t ncols) {
+  ksg_phase_timer tm("row codes");
   D->pc_w = 0;
   const char *env = getenv("KSG_SPMV_ROWCODE");
   if (env && env[0] == '0') return KSG_OK;
   const int64_t nnz = rowptr[nrows];
   if (nrows < 4096 || nnz < 4096) return KSG_OK;
+  const int NT = setup_threads(nnz);
   int64_t w = 0;
-  for (int64_t r = 0; r < nrows; r++) w = std::max(w, rowptr[r + 1] - rowptr[r]);
+  {
+    std::vector<int64_t> wt((size_t)NT, 0);
+    ksg_parallel(NT, [&](int t, int nt) {
+      int64_t m = 0;
+      for (int64_t r = nrows * t / nt; r < nrows * (t + 1) / nt; r++) m = std::max(m, rowptr[r + 1] - rowptr[r]);
+      wt[(size_t)t] = m;
+    });
+    for (int t = 0; t < NT; t++) w = std::max(w, wt[(size_t)t]);
+  }
   if (w > 15 || (double)w * (double)nrows > 1.25 * (double)nnz) return KSG_OK;
   const int nw = w <= 7 ? 1 : 2;
-  std::vector<uint64_t> words((size_t)nw * (size_t)nrows, 0);
+  /* the distinct (column - row, value) pairs, numbered in the order in which the rows meet them:
+   * every part of the rows lists its own, the lists are joined in order, then the codes are looked up */
+  struct pair_set {
+    struct slot { int64_t off; uint64_t bits; int code; };
+    std::vector<slot> ht;
+    pair_set() : ht(2048) { for (auto &e : ht) e.code = -1; }
+    static unsigned hash(int64_t off, uint64_t bits) {
+      return (unsigned)((((uint64_t)off * 0x9E3779B97F4A7C15ull) ^ (bits * 0xC2B2AE3D27D4EB4Full)) >> 53);
+    }
+    int find_or_add(int64_t off, uint64_t bits, int next) {
+      unsigned h = hash(off, bits);
+      while (ht[h].code >= 0 && (ht[h].off != off || ht[h].bits != bits)) h = (h + 1) & 2047;
+      if (ht[h].code < 0) { ht[h].off = off; ht[h].bits = bits; ht[h].code = next; }
+      return ht[h].code;
+    }
+    int find(int64_t off, uint64_t bits) const {
+      unsigned h = hash(off, bits);
+      while (ht[h].code >= 0 && (ht[h].off != off || ht[h].bits != bits)) h = (h + 1) & 2047;
+      return ht[h].code;
+    }
+  };
+  std::vector<std::vector<std::pair<int64_t, uint64_t>>> seen((size_t)NT);
+  ksg_parallel(NT, [&](int t, int nt) {
+    std::vector<std::pair<int64_t, uint64_t>> &mine = seen[(size_t)t];
+    pair_set set;
+    for (int64_t r = nrows * t / nt; r < nrows * (t + 1) / nt; r++)
+      for (int64_t p = rowptr[r]; p < rowptr[r + 1]; p++) {
+        const int64_t off = (int64_t)colidx[p] - r;
+        uint64_t bits;
+        memcpy(&bits, &val[p], 8);
+        if (set.find_or_add(off, bits, (int)mine.size()) == (int)mine.size()) mine.push_back({off, bits});
+        if (mine.size() > 256) return;
+      }
+  });
+  pair_set all;
   std::vector<int32_t> otab;
   std::vector<double> vtab;
-  struct slot { int64_t off; uint64_t bits; int code; };
-  std::vector<slot> ht(2048);
-  for (auto &e : ht) e.code = -1;
-  for (int64_t r = 0; r < nrows; r++) {
-    words[(size_t)r] |= (uint64_t)(rowptr[r + 1] - rowptr[r]) << 56;
-    for (int64_t p = rowptr[r], k = 0; p < rowptr[r + 1]; p++, k++) {
-      const int64_t off = (int64_t)colidx[p] - r;
-      uint64_t bits;
-      memcpy(&bits, &val[p], 8);
-      unsigned h = (unsigned)((((uint64_t)off * 0x9E3779B97F4A7C15ull) ^ (bits * 0xC2B2AE3D27D4EB4Full)) >> 53);
-      while (ht[h].code >= 0 && (ht[h].off != off || ht[h].bits != bits)) h = (h + 1) & 2047;
-      if (ht[h].code < 0) {
-        if (otab.size() == 256) return KSG_OK;               /* too many pairs: the tile kernel keeps the block */
-        ht[h].off = off; ht[h].bits = bits; ht[h].code = (int)otab.size();
+  for (int t = 0; t < NT; t++) {
+    if (seen[(size_t)t].size() > 256) return KSG_OK;         /* too many pairs: the tile kernel keeps the block */
+    for (size_t i = 0; i < seen[(size_t)t].size(); i++) {
+      const int64_t off = seen[(size_t)t][i].first;
+      const uint64_t bits = seen[(size_t)t][i].second;
+      if (all.find_or_add(off, bits, (int)otab.size()) == (int)otab.size()) {
+        if (otab.size() == 256) return KSG_OK;
+        double v;
+        memcpy(&v, &bits, 8);
         otab.push_back((int32_t)off);
-        vtab.push_back(val[p]);
+        vtab.push_back(v);
       }
-      if (k < 7) words[(size_t)r] |= (uint64_t)ht[h].code << (8 * k);
-      else words[(size_t)nrows + (size_t)r] |= (uint64_t)ht[h].code << (8 * (k - 7));
     }
   }
+  ksg_hvec<uint64_t> words((size_t)nw * (size_t)nrows);
+  ksg_parallel(NT, [&](int t, int nt) {
+    for (int64_t r = nrows * t / nt; r < nrows * (t + 1) / nt; r++) {
+      uint64_t w0 = (uint64_t)(rowptr[r + 1] - rowptr[r]) << 56, w1 = 0;
+      for (int64_t p = rowptr[r], k = 0; p < rowptr[r + 1]; p++, k++) {
+        uint64_t bits;
+        memcpy(&bits, &val[p], 8);
+        const uint64_t code = (uint64_t)all.find((int64_t)colidx[p] - r, bits);
+        if (k < 7) w0 |= code << (8 * k);
+        else w1 |= code << (8 * (k - 7));
+      }
+      words[(size_t)r] = w0;
+      if (nw == 2) words[(size_t)nrows + (size_t)r] = w1;
+    }
+  });
+  tm.lap("codes");
   (void)ncols;
   /* consecutive blocks per XCD: the smallest chunk with the least x shared across XCDs */
   int best = 1;
@@ -773,9 +879,9 @@ static int rowcode_to_device(ksg_csr_dev *D, int64_t nrows, const int64_t *rowpt
  * on the packing of its most referenced columns. */
 static int block_to_device(ksg_ctx c, ksg_csr_dev *D, int64_t ncols, int64_t nrows, const int64_t *rowptr, const int32_t *colidx,
                            const double *val, std::vector<int32_t> &hot_cols, int64_t *nhot, int32_t **d_hot_idx, double **d_xhot,
-                           bool has_diag = false, int64_t dshift = 0, const int32_t *row_ids = NULL) {
+                           bool has_diag = false, int64_t dshift = 0, const int32_t *row_ids = NULL, col_counts *cc = NULL) {
   std::vector<int32_t> relabeled;
-  choose_hot_columns(ncols, rowptr[nrows], colidx, c->hot_cols, hot_cols, relabeled);
+  choose_hot_columns(ncols, rowptr[nrows], colidx, c->hot_cols, hot_cols, relabeled, cc);
   *nhot = (int64_t)hot_cols.size();
   if (*nhot) {
     /* a diagonal entry keeps its own column: the kernel finds its value by that column, and the
@@ -797,10 +903,10 @@ static int block_to_device(ksg_ctx c, ksg_csr_dev *D, int64_t ncols, int64_t nro
 
 /* Power-law test of the packing (choose_hot_columns): columns referenced at least four times as
  * often as the average hold 15 % or more of the entries. */
-static bool is_power_law(int64_t ncols, int64_t nnz, const int32_t *colidx) {
+static bool is_power_law(int64_t ncols, int64_t nnz, const int32_t *colidx, col_counts *cc = NULL) {
   if (ncols <= 0 || nnz <= 0) return false;
-  std::vector<int32_t> cnt((size_t)ncols, 0);
-  for (int64_t p = 0; p < nnz; p++) cnt[colidx[p]]++;
+  col_counts own;
+  const std::vector<int32_t> &cnt = counts_of(cc, own, ncols, nnz, colidx);
   const int64_t thresh = std::max<int64_t>(8, 4 * ((nnz + ncols - 1) / ncols));
   int64_t covered = 0;
   for (int64_t j = 0; j < ncols; j++) if (cnt[j] >= thresh) covered += cnt[j];
@@ -808,7 +914,7 @@ static bool is_power_law(int64_t ncols, int64_t nnz, const int32_t *colidx) {
 }
 
 /* Number of column groups the local block of a new operator gets (1: none). */
-static int column_groups_for(ksg_ctx c, int64_t ncols, int64_t nnz, const int32_t *colidx) {
+static int column_groups_for(ksg_ctx c, int64_t ncols, int64_t nnz, const int32_t *colidx, col_counts *cc = NULL) {
   if (c->nranks > 1 || c->col_groups == 1 || ncols < 64) return 1;
   int G = c->col_groups;
   if (G == 0) {
@@ -820,7 +926,7 @@ static int column_groups_for(ksg_ctx c, int64_t ncols, int64_t nnz, const int32_
     G = (int)((ncols + slice - 1) / slice);
   }
   if ((int64_t)G > ncols / 32) G = (int)(ncols / 32);
-  if (G < 2 || !is_power_law(ncols, nnz, colidx)) return 1;
+  if (G < 2 || !is_power_law(ncols, nnz, colidx, cc)) return 1;
   return G;
 }
 
@@ -830,10 +936,10 @@ static int column_groups_for(ksg_ctx c, int64_t ncols, int64_t nnz, const int32_
  * 16 MiB: 0.26 ms per product as a CSR, 0.32 ms binned -- too few column blocks to fill the device;
  * scale 22: 0.51 and 0.44 ms; scale 23: 0.98 and 0.70 ms; scale 24: 2.09 and 1.42 ms; scale 26: 8.92 ms
  * in column groups, 6.65 ms binned; profiles/r02_spmv_rmat_binned.txt). */
-static bool bins_wanted(ksg_ctx c, int64_t ncols, int64_t nnz, const int32_t *colidx) {
+static bool bins_wanted(ksg_ctx c, int64_t ncols, int64_t nnz, const int32_t *colidx, col_counts *cc = NULL) {
   if (c->bins == 1 || ncols < 64 || ncols > (int64_t)INT32_MAX) return false;
   if (c->bins == 0 && ncols < ((int64_t)32 << 20) / 8) return false;
-  return is_power_law(ncols, nnz, colidx);
+  return is_power_law(ncols, nnz, colidx, cc);
 }
 
 static int diag_to_device(ksg_mat A, int64_t nrows, const int64_t *rowptr, const int32_t *colidx, const double *val) {
@@ -842,14 +948,19 @@ static int diag_to_device(ksg_mat A, int64_t nrows, const int64_t *rowptr, const
   const bool square = A->N == A->NC;
   ksg_ctx c = A->ctx;
   A->diag_ncols = A->nc;
-  if (bins_wanted(c, A->nc, rowptr[nrows], colidx)) {
+  ksg_phase_timer tm("local block");
+  col_counts cc;                                         /* the block's entries per column, counted at most once */
+  if (bins_wanted(c, A->nc, rowptr[nrows], colidx, &cc)) {
+    { std::vector<int32_t>().swap(cc.cnt); cc.of = NULL; }
     /* well filled (row block, column block) cells and the diagonal go to the binned form, which
      * stores y; what is left is a CSR over the rows it touches, held like a column group over all
      * columns and added afterwards.  A->diag stays empty. */
     std::vector<int32_t> lrows, lci;
     std::vector<int64_t> lrp;
     std::vector<double> lva;
+    tm.lap("power-law test");
     KSG_CHK(ksg_bins_build(c, &A->bins, nrows, A->nc, rowptr, colidx, val, square, A->row0 - A->col0, lrows, lrp, lci, lva, NULL));
+    tm.lap("binned part");
     if (A->bins.nent) {
       A->cgs.clear();
       if (!lrows.empty()) {
@@ -866,10 +977,12 @@ static int diag_to_device(ksg_mat A, int64_t nrows, const int64_t *rowptr, const
       return KSG_OK;
     }
   }
-  const int G = column_groups_for(c, A->nc, rowptr[nrows], colidx);
+  tm.lap("binned form not taken");
+  const int G = column_groups_for(c, A->nc, rowptr[nrows], colidx, &cc);
   if (G <= 1)
     return block_to_device(c, &A->diag, A->nc, nrows, rowptr, colidx, val, A->hot_cols, &A->nhot, &A->d_hot_idx, &A->d_xhot,
-                           square, A->row0 - A->col0);
+                           square, A->row0 - A->col0, NULL, &cc);
+  { std::vector<int32_t>().swap(cc.cnt); cc.of = NULL; }
   /* column groups: boundaries on multiples of 32 columns; group 0 over all rows (it stores y),
    * the others over the rows they touch */
   const int64_t width = ((A->nc + G - 1) / G + 31) / 32 * 32;
@@ -931,9 +1044,15 @@ static int validate_csr(int64_t n, int64_t N, const int64_t *rowptr, const int32
   for (int64_t i = 0; i < n; i++)
     if (rowptr[i + 1] < rowptr[i]) KSG_FAIL(KSG_ERR_ARG, "ksg_mat_create_csr: rowptr decreases at row %lld", (long long)i);
   const int64_t nnz = rowptr[n];
-  for (int64_t p = 0; p < nnz; p++)
-    if (colidx[p] < 0 || (int64_t)colidx[p] >= N)
-      KSG_FAIL(KSG_ERR_ARG, "ksg_mat_create_csr: column index %d out of range at entry %lld", colidx[p], (long long)p);
+  const int NT = setup_threads(nnz);
+  std::vector<int64_t> bad((size_t)NT, -1);                /* per part: its first entry out of range */
+  ksg_parallel(NT, [&](int t, int nt) {
+    for (int64_t p = nnz * t / nt; p < nnz * (t + 1) / nt; p++)
+      if (colidx[p] < 0 || (int64_t)colidx[p] >= N) { bad[(size_t)t] = p; return; }
+  });
+  for (int t = 0; t < NT; t++)
+    if (bad[(size_t)t] >= 0)
+      KSG_FAIL(KSG_ERR_ARG, "ksg_mat_create_csr: column index %d out of range at entry %lld", colidx[bad[(size_t)t]], (long long)bad[(size_t)t]);
   return KSG_OK;
 }
 
@@ -967,8 +1086,10 @@ static int mat_create(ksg_ctx c, int64_t n, int64_t N, int64_t row0, int64_t nc,
   if (NC > (int64_t)INT32_MAX) KSG_FAIL(KSG_ERR_UNSUPPORTED, "ksg_mat_create_csr: N exceeds 32-bit column indices");
   if (n > (int64_t)INT32_MAX) KSG_FAIL(KSG_ERR_UNSUPPORTED, "ksg_mat_create_csr: more than 2^31-1 local rows");
   if (rowptr[n] > 0 && (!colidx || !val)) KSG_FAIL(KSG_ERR_ARG, "ksg_mat_create_csr: NULL arrays");
+  ksg_phase_timer tmc("operator");
   KSG_CHK(validate_csr(n, NC, rowptr, colidx));
   KSG_HIP(hipSetDevice(c->device));
+  tmc.lap("validation");
   ksg_mat A = new (std::nothrow) ksg_mat_s();
   if (!A) KSG_FAIL(KSG_ERR_MEM, "ksg_mat_create_csr: out of host memory");
   A->ctx = c; A->n = n; A->N = N; A->row0 = row0; A->nnz = rowptr[n];
@@ -989,6 +1110,7 @@ static int mat_create(ksg_ctx c, int64_t n, int64_t N, int64_t row0, int64_t nc,
   if (P == 1) {
     if (row0 != 0 || n != N || col0 != 0 || nc != NC) { delete A; KSG_FAIL(KSG_ERR_ARG, "ksg_mat_create_csr: one rank must own all rows and columns"); }
     rc = diag_to_device(A, n, rowptr, colidx, val);
+    tmc.lap("local block");
     if (rc) { ksg_mat_destroy(A); return rc; }
     *out = A;
     return KSG_OK;
@@ -1015,25 +1137,42 @@ static int mat_create(ksg_ctx c, int64_t n, int64_t N, int64_t row0, int64_t nc,
   std::vector<int32_t> d_ci, o_ci, o_rows;
   std::vector<double> d_v, o_v;
   d_ci.reserve((size_t)nnz); d_v.reserve((size_t)nnz);
-  std::vector<int32_t> ghosts;                    /* global indices, later sorted unique */
+  std::vector<int32_t> ghosts;                    /* global indices of the columns the ghost block uses, in order */
   o_rp.push_back(0);
   for (int64_t i = 0; i < n; i++) {
     bool has = false;
     for (int64_t p = rowptr[i]; p < rowptr[i + 1]; p++) {
       const int64_t cg = colidx[p];
       if (cg >= lo && cg < hi) { d_ci.push_back((int32_t)(cg - lo)); d_v.push_back(val[p]); }
-      else { o_ci.push_back((int32_t)cg); o_v.push_back(val[p]); ghosts.push_back((int32_t)cg); has = true; }
+      else { o_ci.push_back((int32_t)cg); o_v.push_back(val[p]); has = true; }
     }
     d_rp[i + 1] = (int64_t)d_ci.size();
     if (has) { o_rows.push_back((int32_t)i); o_rp.push_back((int64_t)o_ci.size()); }
   }
-  std::sort(ghosts.begin(), ghosts.end());
-  ghosts.erase(std::unique(ghosts.begin(), ghosts.end()), ghosts.end());
-  for (size_t p = 0; p < o_ci.size(); p++)
-    o_ci[p] = (int32_t)(std::lower_bound(ghosts.begin(), ghosts.end(), o_ci[p]) - ghosts.begin());
+  {
+    const int64_t onz = (int64_t)o_ci.size();
+    if (NC <= std::max<int64_t>((int64_t)1 << 27, 4 * onz)) {
+      /* a mark per column of the operator, then the marked columns numbered in order */
+      std::vector<int32_t> num((size_t)NC, -1);
+      for (int64_t p = 0; p < onz; p++) num[(size_t)o_ci[(size_t)p]] = 0;
+      for (int64_t j = 0; j < NC; j++) if (num[(size_t)j] == 0) { num[(size_t)j] = (int32_t)ghosts.size(); ghosts.push_back((int32_t)j); }
+      ksg_parallel(setup_threads(onz), [&](int t, int nt) {
+        for (int64_t p = onz * t / nt; p < onz * (t + 1) / nt; p++) o_ci[(size_t)p] = num[(size_t)o_ci[(size_t)p]];
+      });
+    } else {
+      ghosts.assign(o_ci.begin(), o_ci.end());
+      std::sort(ghosts.begin(), ghosts.end());
+      ghosts.erase(std::unique(ghosts.begin(), ghosts.end()), ghosts.end());
+      ksg_parallel(setup_threads(onz), [&](int t, int nt) {
+        for (int64_t p = onz * t / nt; p < onz * (t + 1) / nt; p++)
+          o_ci[(size_t)p] = (int32_t)(std::lower_bound(ghosts.begin(), ghosts.end(), o_ci[(size_t)p]) - ghosts.begin());
+      });
+    }
+  }
   A->nghost = (int64_t)ghosts.size();
   A->ghosts = ghosts;
 
+  tmc.lap("split, ghost columns");
   /* ---- who owns my ghosts: receive offsets (ghosts are sorted, so grouped by owner) ---- */
   A->recvoff.assign((size_t)P + 1, 0);
   {
@@ -1067,6 +1206,7 @@ static int mat_create(ksg_ctx c, int64_t n, int64_t N, int64_t row0, int64_t nc,
   rc = agree(c, rc, "building the halo plan");
   if (rc) { delete A; return rc; }
 
+  tmc.lap("halo plan");
   /* ---- upload ---- */
   rc = diag_to_device(A, n, d_rp.data(), d_ci.data(), d_v.data());
   A->no_rows = (int64_t)o_rows.size();
@@ -1101,6 +1241,7 @@ static int mat_create(ksg_ctx c, int64_t n, int64_t N, int64_t row0, int64_t nc,
     if (hipHostMalloc(&A->h_ghost, (size_t)std::max<int64_t>(A->nghost, 1) * sizeof(double), hipHostMallocDefault) != hipSuccess) rc = KSG_ERR_MEM;
     if (!rc && hipHostMalloc(&A->h_send, (size_t)std::max<int64_t>(A->nsend, 1) * sizeof(double), hipHostMallocDefault) != hipSuccess) rc = KSG_ERR_MEM;
   }
+  tmc.lap("blocks to the device");
   if (rc == KSG_ERR_MEM) ksg_set_error("ksg_mat_create_csr: out of device memory");
   rc = agree(c, rc, "uploading the matrix");
   if (rc) { ksg_mat_destroy(A); return rc; }

@@ -119,3 +119,31 @@ def test_binned_layout_random_blocks():
             built += 1
             assert info["binned"] + info["csr_entries"] + (n if info["diagonal_folded"] else 0) == rp[-1]
     assert built > 40
+
+
+@pytest.mark.parametrize("values", ["laplacian", "few", "any"])
+def test_binned_layout_same_for_any_thread_count(values):
+    """The build runs its passes over the entries on several host threads (KSG_HOST_THREADS) from a
+    million entries on: the arrays -- and with them every bit of the product -- are the same for
+    1, 3 and 8 threads, with long rows cut into pieces and a few values or arbitrary ones."""
+    rp, ci, va = mg.rmat_laplacian(16, 10, seed=9)
+    n = len(rp) - 1
+    assert rp[-1] > 1 << 20
+    rng = np.random.default_rng(5)
+    offd = ci != np.repeat(np.arange(n), np.diff(rp))
+    va = va.copy()
+    if values == "few":
+        va[offd] = rng.choice(np.array([-1.0, -0.5, 2.25, 1e-3]), size=int(offd.sum()))
+    elif values == "any":
+        va[offd] = rng.standard_normal(int(offd.sum()))
+    x = rng.standard_normal(n)
+    out = []
+    for nt in (1, 3, 8):
+        out.append(_with_env({"KSG_HOST_THREADS": nt, "KSG_BINS_W": 2048, "KSG_BINS_H": 512, "KSG_BINS_E": 3000, "KSG_BINS_T": 3},
+                             lambda: ksgpu.bins_host_check(rp, ci, va, x)))
+    M = csr_matrix((va, ci, rp), shape=(n, n))
+    assert out[0][1]["binned"] > rp[-1] // 2
+    assert np.all(np.abs(out[0][0] - M @ x) <= 1e-14 * (np.abs(M) @ np.abs(x) + 1e-300))
+    for y, info in out[1:]:
+        assert info == out[0][1]
+        assert np.array_equal(y, out[0][0])

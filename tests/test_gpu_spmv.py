@@ -629,3 +629,57 @@ def test_row_code_kernel_equals_tile_kernel(gpu_ctx, gen):
     M.destroy()
     ctx.vec_free(xd)
     ctx.vec_free(yd)
+
+
+@pytest.mark.parametrize("case", ["stencil", "rmat_plain", "rmat_binned", "random_values"])
+def test_setup_same_for_any_host_thread_count(gpu_ctx, case):
+    """The set-up of an operator (validation, column counts, packed columns, value tables, row codes,
+    the binned build) runs its passes on several host threads from a million entries on
+    (KSG_HOST_THREADS): the operator described, the entries read back and every bit of the product
+    are the same for 1 and 7 threads; a column index out of range is reported as with one thread."""
+    import os
+    from slepc_amd import ksgpu, matgen as mg
+    ctx = gpu_ctx
+    rng = np.random.default_rng(3)
+    if case == "stencil":
+        rp, ci, va = mg.laplacian2d(600, 600)
+    else:
+        rp, ci, va = mg.rmat_laplacian(16, 10, seed=4)
+        if case == "random_values":
+            va = rng.standard_normal(len(va))
+    n = len(rp) - 1
+    assert rp[-1] > 1 << 20
+    x = rng.standard_normal(n)
+    xd, yd = ctx.vec_alloc(n), ctx.vec_alloc(n)
+    ctx.upload(xd, x)
+    old = os.environ.get("KSG_HOST_THREADS")
+    got = []
+    try:
+        ctx.set_option(ksgpu.OPT_BINS, 2 if case in ("rmat_binned", "random_values") else 1)
+        for nt in (1, 7):
+            os.environ["KSG_HOST_THREADS"] = str(nt)
+            A = ksgpu.DeviceCSR(ctx, rp, ci, va)
+            ctx.upload(yd, np.full(n, np.nan))
+            A.mult(xd, yd)
+            got.append((A.describe(), ctx.download(yd, n), A.get_csr()))
+            A.destroy()
+        bad = ci.copy()
+        bad[len(bad) // 2 + 11] = n
+        bad[len(bad) - 5] = -1
+        with pytest.raises(ksgpu.KsgError, match="out of range at entry %d" % (len(bad) // 2 + 11)):
+            ksgpu.DeviceCSR(ctx, rp, bad, va)
+    finally:
+        ctx.set_option(ksgpu.OPT_BINS, 0)
+        if old is None:
+            os.environ.pop("KSG_HOST_THREADS", None)
+        else:
+            os.environ["KSG_HOST_THREADS"] = old
+    assert got[0][0] == got[1][0], (got[0][0], got[1][0])
+    assert {"stencil": "row codes", "rmat_plain": "packed hot columns", "rmat_binned": "binned part",
+            "random_values": "binned part"}[case] in got[0][0], got[0][0]
+    assert np.array_equal(got[0][1], got[1][1])
+    for a, b in zip(got[0][2], got[1][2]):
+        assert np.array_equal(a, b)
+    assert np.array_equal(got[0][2][1], ci) and np.array_equal(got[0][2][2], va)
+    ctx.vec_free(xd)
+    ctx.vec_free(yd)
