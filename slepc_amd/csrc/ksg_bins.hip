@@ -405,6 +405,44 @@ static void bins_build_host(bins_host *B, int64_t nrows, int64_t ncols, const in
   }
   tm.lap("diagonal check");
 
+  /* the distinct values among the entries that may be binned (all but a folded diagonal), numbered
+   * in storage order, if there are at most 256: the build then writes one-byte indices at once
+   * instead of collecting 8-byte values and indexing them afterwards */
+  ksg_value_set vset;
+  std::vector<double> pretab;
+  bool few = true;
+  {
+    std::vector<std::vector<uint64_t>> seen((size_t)NT);
+    ksg_parallel(NT, [&](int t, int nt) {
+      std::vector<uint64_t> &mine = seen[(size_t)t];
+      ksg_value_set set;
+      uint64_t lastbits = 0;
+      bool have = false;
+      const int64_t ra = ksg_split_rows(rowptr, nrows, t, nt), rb = ksg_split_rows(rowptr, nrows, t + 1, nt);
+      for (int64_t r = ra; r < rb; r++)
+        for (int64_t p = rowptr[r]; p < rowptr[r + 1]; p++) {
+          if (fold && (int64_t)colidx[p] == r + dshift) continue;
+          uint64_t bits;
+          memcpy(&bits, &val[p], 8);
+          if (have && bits == lastbits) continue;
+          lastbits = bits; have = true;
+          if (set.find_or_add(bits, (int)mine.size()) == (int)mine.size()) mine.push_back(bits);
+          if (mine.size() > 256) return;
+        }
+    });
+    for (int t = 0; t < NT && few; t++) {
+      if (seen[(size_t)t].size() > 256) few = false;
+      for (size_t i = 0; i < seen[(size_t)t].size() && few; i++)
+        if (vset.find_or_add(seen[(size_t)t][i], (int)pretab.size()) == (int)pretab.size()) {
+          if (pretab.size() == 256) { few = false; break; }
+          double v;
+          memcpy(&v, &seen[(size_t)t][i], 8);
+          pretab.push_back(v);
+        }
+    }
+  }
+  tm.lap("distinct values");
+
   /* row blocks: consecutive rows, at most H rows and E entries.  A row longer than E belongs to a
    * block (which stores its diagonal term) but its entries are cut into pieces of at most E, each
    * a unit of its own whose sum is added to the row afterwards. */
@@ -566,23 +604,34 @@ static void bins_build_host(bins_host *B, int64_t nrows, int64_t ncols, const in
    * row blocks come first and in row order, so that CSR is in row order too) */
   ksg_hvec<uint16_t> &col16 = B->col16, &rowloc = B->rowloc;
   ksg_hvec<double> &val1 = B->val;
+  ksg_hvec<uint8_t> &vidx1 = B->vidx;
+  uint8_t nused[256] = {0};                               /* values of the table that binned entries have */
   col16.resize((size_t)nent1); rowloc.resize((size_t)B->nent);
-  val1.resize((size_t)nent1);
+  ksg_hvec<uint8_t> pad;                                  /* entries that stand for nothing: the fill of the runs and of the groups */
+  const bool one = few && pretab.size() == 1;             /* a single value: nothing to store per entry */
+  if (one) nused[0] = 1;
+  else if (few) vidx1.resize((size_t)nent1);
+  else { val1.resize((size_t)nent1); pad.resize((size_t)nent1); }
   if (fold) B->dv.resize((size_t)nrows);
-  ksg_hvec<uint8_t> pad((size_t)nent1);                   /* entries that stand for nothing: the fill of the runs and of the groups */
   for (int64_t cb = 0; cb < NC; cb++)
     for (int64_t p0 = cpos[(size_t)cb] + centries[(size_t)cb], p = p0; p < cpos[(size_t)cb + 1]; p++) {
       col16[(size_t)p] = p == p0 ? 0x8000u : 0;           /* the first padding entry opens the padding run */
-      val1[(size_t)p] = 0.0; pad[(size_t)p] = 1;
+      if (one) continue;
+      if (few) vidx1[(size_t)p] = 255;
+      else { val1[(size_t)p] = 0.0; pad[(size_t)p] = 1; }
     }
   tm.lap("allocate entry arrays");
   {
     std::vector<std::vector<int32_t>> tci((size_t)NT), trows((size_t)NT);
     std::vector<std::vector<double>> tva((size_t)NT);
     std::vector<std::vector<int64_t>> trp((size_t)NT);      /* ends of the part's rows, counted from the part's first entry */
+    std::vector<std::vector<uint8_t>> tused((size_t)NT, std::vector<uint8_t>(256, 0));
     ksg_parallel(NT, [&](int t, int) {
       std::vector<int64_t> segid((size_t)NC, -1);
       std::vector<int32_t> fill((size_t)NC, 0);
+      uint8_t *used = tused[(size_t)t].data();             /* values of the table that binned entries of this part have */
+      uint64_t lastbits = 0;
+      int lastcode = -1;
       std::vector<int32_t> &lc = tci[(size_t)t], &lr = trows[(size_t)t];
       std::vector<double> &lv = tva[(size_t)t];
       std::vector<int64_t> &lp = trp[(size_t)t];
@@ -603,8 +652,16 @@ static void bins_build_host(bins_host *B, int64_t nrows, int64_t ncols, const in
             const int32_t f = fill[(size_t)cb]++;
             const bins_seg &s = S[(size_t)i];
             col16[(size_t)(s.pos1 + f)] = (uint16_t)((colidx[p] & (W - 1)) | (f == 0 ? 0x8000 : 0));
-            val1[(size_t)(s.pos1 + f)] = val[p];
-            pad[(size_t)(s.pos1 + f)] = 0;
+            if (one) {
+            } else if (few) {
+              uint64_t bits;
+              memcpy(&bits, &val[p], 8);
+              if (lastcode < 0 || bits != lastbits) { lastcode = vset.find(bits); lastbits = bits; used[lastcode] = 1; }
+              vidx1[(size_t)(s.pos1 + f)] = (uint8_t)lastcode;
+            } else {
+              val1[(size_t)(s.pos1 + f)] = val[p];
+              pad[(size_t)(s.pos1 + f)] = 0;
+            }
             rowloc[(size_t)(s.pos2 + f)] = (uint16_t)(r - k.r0);
           }
           if (lc.size() > before) { lr.push_back((int32_t)r); lp.push_back((int64_t)lc.size()); }
@@ -614,13 +671,15 @@ static void bins_build_host(bins_host *B, int64_t nrows, int64_t ncols, const in
           segid[(size_t)s.c] = -1;
           for (int32_t f = s.real; f < s.cnt; f++) {           /* the fill: column W (x = 0 there), any row of the unit */
             col16[(size_t)(s.pos1 + f)] = (uint16_t)W;
-            val1[(size_t)(s.pos1 + f)] = 0.0;
-            pad[(size_t)(s.pos1 + f)] = 1;
+            if (one) { }
+            else if (few) vidx1[(size_t)(s.pos1 + f)] = 255;
+            else { val1[(size_t)(s.pos1 + f)] = 0.0; pad[(size_t)(s.pos1 + f)] = 1; }
             rowloc[(size_t)(s.pos2 + f)] = (uint16_t)((f - s.real) % k.nr);
           }
         }
       }
     });
+    for (int t = 0; t < NT; t++) for (int i = 0; i < 256; i++) if (tused[(size_t)t][(size_t)i]) nused[i] = 1;
     /* the remaining entries of the parts, one behind the other */
     std::vector<int64_t> eoff((size_t)NT + 1, 0), roff((size_t)NT + 1, 0);
     for (int t = 0; t < NT; t++) { eoff[(size_t)t + 1] = eoff[(size_t)t] + (int64_t)tci[(size_t)t].size(); roff[(size_t)t + 1] = roff[(size_t)t] + (int64_t)trows[(size_t)t].size(); }
@@ -658,10 +717,16 @@ static void bins_build_host(bins_host *B, int64_t nrows, int64_t ncols, const in
   }
 
   tm.lap("unit order");
-  /* values: one, at most 256 (a table in the order in which the expand order meets them), or as
-   * they are; the padding entries take no part */
+  /* values: one, at most 256 (one-byte indices into a table), or as they are; the padding entries
+   * take no part */
   B->vmode = 2;
-  {
+  if (few) {
+    int count = 0, only = 0;
+    for (int i = 0; i < 256; i++) if (nused[i]) { count++; only = i; }
+    if (count == 1) { B->vmode = 0; B->vconst = pretab[(size_t)only]; ksg_hvec<uint8_t>().swap(B->vidx); }
+    else { B->vmode = 1; B->vtab = pretab; B->vtab.resize(256, 0.0); }
+  } else {
+    /* more than 256 values among all entries, perhaps not among the binned ones */
     const int distinct = ksg_build_value_table(nent1, val1.data(), pad.data(), 256, B->vtab, B->vidx);
     if (distinct == 1) { B->vmode = 0; B->vconst = B->vtab[0]; }
     else if (distinct > 1) B->vmode = 1;
