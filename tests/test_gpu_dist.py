@@ -56,6 +56,18 @@ def test_rmat_balanced_blocks_match_single(case, ranks):
     assert sum(int(re.search(r"(\d+) packed\)", d).group(1)) for d in many["variant"]) > 0
 
 
+def test_ghost_columns_numbered_either_way():
+    """The columns a rank's ghost block uses are numbered through a mark per column of the operator or,
+    for operators with far more columns than the block has entries, by sorting them: both give the same
+    halo plan and the same bits."""
+    a = run_ranks("gpu", "rmat_nnz", 3)
+    b = run_ranks("gpu", "rmat_nnz", 3, extra_env={"KSG_GHOST_SORT": "1"})
+    assert a["reason"] == b["reason"] == 1
+    assert a["variant"] == b["variant"]
+    assert np.array_equal(np.array(a["y"]), np.array(b["y"]))
+    assert a["values"] == b["values"]
+
+
 @pytest.mark.parametrize("ranks", [2, 3, 8])
 def test_rmat_binned_blocks_match_single(ranks):
     """The same split with both blocks of every rank in the binned form (KSG_OPT_BINS forced through
