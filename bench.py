@@ -278,7 +278,10 @@ def main():
     if rank == 0:
         print("operator: %s, %d local rows, %d local entries, generated in %.1f s" % (
             wname, row1 - row0, int(rp[-1]), time.perf_counter() - t_gen), file=sys.stderr, flush=True)
+    t_setup = time.perf_counter()
     A = K.Mat.create_aij_hip(ctx, rp, ci, va, N=N, row0=row0)
+    ctx.sync()
+    operator_setup_s = time.perf_counter() - t_setup     # host conversion + upload; before EPSSolve, never in the timed region
     nnz_local = int(rp[-1])
     keep_csr = (not args.no_cpu_baseline) and size == 1 and not args.cpu_grid
     if not keep_csr:
@@ -460,6 +463,7 @@ def main():
                        "ncv": ncv, "tol": tol_used, "partition": partition,
                        "transport": args.transport if size > 1 else "none",
                        "spmv_variant": spmv_variant,
+                       "operator_setup_s": round(operator_setup_s, 3),
                        "spmv_per_step": mv / Ksteps, "gs_passes_per_step": gs / Ksteps},
             "frac_of_hbm_peak": round(value / (HBM_PEAK_GBS * size), 4),
             "reference_op_sequence_GBps": round(unfused / dt / 1e9, 1),
