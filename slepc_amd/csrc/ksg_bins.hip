@@ -332,7 +332,10 @@ void ksg_bins_free(ksg_bins *B) {
   if (B->long_first) hipFree(B->long_first);
   if (B->piece_row) hipFree(B->piece_row);
   if (B->part) hipFree(B->part);
-  if (B->xe) hipFree(B->xe);
+  if (B->xe && !B->xe_shared) hipFree(B->xe);
+  if (B->next) { ksg_bins_free(B->next); delete B->next; }
+  if (B->next_rows_blk && B->next_rows_blk != B->next_rows_y) hipFree(B->next_rows_blk);
+  if (B->next_rows_y) hipFree(B->next_rows_y);
   memset(B, 0, sizeof(*B));
 }
 
@@ -364,14 +367,13 @@ struct bins_block { int32_t r0, nr, piece; int64_t e0, e1; };
  * (B->nent == 0, the vectors stay empty). */
 static void bins_build_host(bins_host *B, int64_t nrows, int64_t ncols, const int64_t *rowptr, const int32_t *colidx,
                             const double *val, bool has_diag, int64_t dshift, std::vector<int32_t> &lrows, std::vector<int64_t> &lrp,
-                            std::vector<int32_t> &lci, std::vector<double> &lva) {
+                            std::vector<int32_t> &lci, std::vector<double> &lva, int H, int64_t E) {
   *B = bins_host();
   lrows.clear(); lrp.clear(); lci.clear(); lva.clear();
   /* R-MAT scale 26 (1.13e9 entries): 6.65 ms per product with H = 2048, 7.27 with 4096; before the reduce pass combined
    * equal rows: 7.05 / 7.11 / 7.21 ms with H = 2048 / 4096 / 8192 (E = 131072), T = 6: 7.26;
    * scale 24 then: W = 16384 1.61 ms, 8192 1.63, 4096 1.69 (profiles/r02_spmv_rmat_binned.txt) */
-  int W = env_int("KSG_BINS_W", 16384), H = env_int("KSG_BINS_H", 2048);
-  const int64_t E = env_int("KSG_BINS_E", 65536);
+  int W = env_int("KSG_BINS_W", 16384);
   const int T = env_int("KSG_BINS_T", 4);
   int wshift = 0;
   while ((1 << wshift) < W) wshift++;
@@ -380,6 +382,7 @@ static void bins_build_host(bins_host *B, int64_t nrows, int64_t ncols, const in
   if (W < 64) W = 64, wshift = 6;
   if (H > 8192) H = 8192;                                  /* 64 KiB of sums in LDS */
   if (H < 64) H = 64;
+  if (E < 1) E = 1;
   const int64_t nnz = rowptr[nrows];
   const int64_t NC = (ncols + W - 1) >> wshift;
   if (nnz == 0 || nrows == 0 || NC > (int64_t)INT32_MAX || nrows > (int64_t)INT32_MAX / 2) return;
@@ -808,6 +811,54 @@ static void bins_emulate(const bins_host &B, const double *x, int64_t ncols, dou
   }
 }
 
+/* The binned part of a block in one or two levels.  Level 1 as bins_build_host makes it (KSG_BINS_H
+ * rows per row block, 2048 unless set).  The entries its cells were too thin for form a CSR over the
+ * rows that have such entries; with KSG_BINS_LEVELS=2 that CSR is binned again with four times the
+ * rows per row block (KSG_BINS_H2, at most 8192): counted in rows of the block its cells are some
+ * twenty times as large, so most of those entries find a well filled cell after all.  Off unless
+ * asked for: at R-MAT scale 26 the 57.8M entries left after level 1 (5 %) take 1.03 of the product's
+ * 6.55 ms through the tile kernel (56 G entries/s, every one a gather beyond L2); a second level
+ * bins 54.8M of them, but its reduce pass needs 64 KiB of sums per wave -- two waves per CU -- and
+ * runs at 104 G products/s against 495 for level 1: 0.32 ms expand + 0.62 ms reduce + 0.10 ms for
+ * the rest, 6.53 ms in all (6.51 with 4096 rows per block; profiles/r02_spmv_rmat_binned.txt). */
+struct bins_levels {
+  bins_host L1, L2;
+  std::vector<int32_t> rows2;      /* the block row of every row of level 2 */
+};
+
+static void bins_build_levels(bins_levels *BL, int64_t nrows, int64_t ncols, const int64_t *rowptr, const int32_t *colidx,
+                              const double *val, bool has_diag, int64_t dshift, std::vector<int32_t> &lrows, std::vector<int64_t> &lrp,
+                              std::vector<int32_t> &lci, std::vector<double> &lva) {
+  BL->L2 = bins_host();
+  BL->rows2.clear();
+  const int H = env_int("KSG_BINS_H", 2048);
+  const int64_t E = env_int("KSG_BINS_E", 65536);
+  bins_build_host(&BL->L1, nrows, ncols, rowptr, colidx, val, has_diag, dshift, lrows, lrp, lci, lva, H, E);
+  if (!BL->L1.nent || lrows.empty()) return;
+  const int levels = env_int("KSG_BINS_LEVELS", 0);
+  const int H2 = std::min(env_int("KSG_BINS_H2", 4 * BL->L1.H), 8192);
+  const int64_t left = lrp.back();
+  if (levels != 2 || H2 <= BL->L1.H || left == 0) return;
+  std::vector<int32_t> rows3, ci3;
+  std::vector<int64_t> rp3;
+  std::vector<double> va3;
+  bins_build_host(&BL->L2, (int64_t)lrows.size(), ncols, lrp.data(), lci.data(), lva.data(), false, 0, rows3, rp3, ci3, va3, H2,
+                  4 * E);
+  if (!BL->L2.nent) return;
+  BL->rows2 = lrows;
+  for (size_t i = 0; i < rows3.size(); i++) rows3[i] = lrows[(size_t)rows3[i]];
+  lrows.swap(rows3); lrp.swap(rp3); lci.swap(ci3); lva.swap(va3);
+}
+
+/* y = A x of both levels on the host, the way the device forms it: level 1 stores its rows, level 2 is added. */
+static void bins_emulate_levels(const bins_levels &BL, const double *x, int64_t ncols, double *y) {
+  bins_emulate(BL.L1, x, ncols, y);
+  if (!BL.L2.nent) return;
+  std::vector<double> y2((size_t)BL.L2.nrows, 0.0);
+  bins_emulate(BL.L2, x, ncols, y2.data());
+  for (int64_t i = 0; i < BL.L2.nrows; i++) y[BL.rows2[(size_t)i]] += y2[(size_t)i];
+}
+
 /* Host-side check of the binned layout, no device needed: y = A x for the CSR block given, formed
  * as the library forms it (the binned part and the diagonal through the same walk of the same arrays
  * as the kernels, then the remaining entries row by row in storage order); info = {binned entries,
@@ -825,11 +876,12 @@ extern "C" int ksg_bins_host_check(int64_t nrows, int64_t ncols, const int64_t *
       if (colidx[p] < 0 || (int64_t)colidx[p] >= ncols)
         KSG_FAIL(KSG_ERR_ARG, "ksg_bins_host_check: column %d of row %lld outside [0,%lld)", colidx[p], (long long)r, (long long)ncols);
   }
-  bins_host B;
+  bins_levels BL;
   std::vector<int32_t> lrows, lci;
   std::vector<int64_t> lrp;
   std::vector<double> lva;
-  bins_build_host(&B, nrows, ncols, rowptr, colidx, val, has_diag != 0, dshift, lrows, lrp, lci, lva);
+  bins_build_levels(&BL, nrows, ncols, rowptr, colidx, val, has_diag != 0, dshift, lrows, lrp, lci, lva);
+  const bins_host &B = BL.L1;
   if (!B.nent) {
     for (int64_t r = 0; r < nrows; r++) {
       double s = 0.0;
@@ -837,7 +889,7 @@ extern "C" int ksg_bins_host_check(int64_t nrows, int64_t ncols, const int64_t *
       y[r] = s;
     }
   } else {
-    bins_emulate(B, x, ncols, y);
+    bins_emulate_levels(BL, x, ncols, y);
     for (size_t i = 0; i < lrows.size(); i++) {
       double s = 0.0;
       for (int64_t p = lrp[i]; p < lrp[i + 1]; p++) s += lva[(size_t)p] * x[lci[(size_t)p]];
@@ -845,21 +897,15 @@ extern "C" int ksg_bins_host_check(int64_t nrows, int64_t ncols, const int64_t *
     }
   }
   if (info) {
-    info[0] = B.nreal; info[1] = B.nseg; info[2] = B.nbins; info[3] = B.vmode;
+    info[0] = B.nreal + BL.L2.nreal; info[1] = B.nseg + BL.L2.nseg; info[2] = B.nbins + BL.L2.nbins; info[3] = B.vmode;
     info[4] = B.nent ? (int64_t)lci.size() : rowptr[nrows]; info[5] = B.fold_diag ? 1 : 0;
   }
   return KSG_OK;
 }
 
-/* The same split, with the binned part uploaded as *B.  rowmap (may be NULL): the rows of y the
- * block's rows stand for (ksg_bins_mult is then given the same list on the device). */
-int ksg_bins_build(ksg_ctx c, ksg_bins *B, int64_t nrows, int64_t ncols, const int64_t *rowptr, const int32_t *colidx,
-                   const double *val, bool has_diag, int64_t dshift, std::vector<int32_t> &lrows, std::vector<int64_t> &lrp,
-                   std::vector<int32_t> &lci, std::vector<double> &lva, const int32_t *rowmap) {
-  memset(B, 0, sizeof(*B));
-  bins_host Hb;
-  bins_build_host(&Hb, nrows, ncols, rowptr, colidx, val, has_diag, dshift, lrows, lrp, lci, lva);
-  if (!Hb.nent) return KSG_OK;
+/* One level on the device.  rowmap (may be NULL): the rows of y the level's rows stand for;
+ * shared_xe: the product array of the level above, used instead of one of its own. */
+static int bins_to_device(ksg_ctx c, ksg_bins *B, const bins_host &Hb, const int32_t *rowmap, double *shared_xe) {
   B->threads = env_int("KSG_BINS_THREADS", 1024) / 64 * 64;
   if (B->threads < 64) B->threads = 64;
   if (B->threads > BINS_P1_THREADS) B->threads = BINS_P1_THREADS;
@@ -889,13 +935,41 @@ int ksg_bins_build(ksg_ctx c, ksg_bins *B, int64_t nrows, int64_t ncols, const i
     hipError_t e2 = hipMalloc((void **)&B->part, (size_t)B->npieces * sizeof(double));
     if (e2 != hipSuccess) KSG_FAIL(KSG_ERR_MEM, "binned operator: sums of the pieces of long rows: %s", hipGetErrorString(e2));
   }
-  hipError_t e = hipMalloc((void **)&B->xe, (size_t)(B->nent + 64) * sizeof(double));
-  if (e != hipSuccess) KSG_FAIL(KSG_ERR_MEM, "binned operator: %zu bytes of products: %s", (size_t)(B->nent + 64) * sizeof(double), hipGetErrorString(e));
+  if (shared_xe) { B->xe = shared_xe; B->xe_shared = 1; }
+  else {
+    hipError_t e = hipMalloc((void **)&B->xe, (size_t)(B->nent + 64) * sizeof(double));
+    if (e != hipSuccess) KSG_FAIL(KSG_ERR_MEM, "binned operator: %zu bytes of products: %s", (size_t)(B->nent + 64) * sizeof(double), hipGetErrorString(e));
+  }
   /* the expand kernel's slice of x may exceed the 64 KiB a kernel gets without asking */
   const int lds = (B->W + 1) * (int)sizeof(double);
   KSG_HIP(hipFuncSetAttribute((const void *)k_bins_expand<0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
   KSG_HIP(hipFuncSetAttribute((const void *)k_bins_expand<1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
   KSG_HIP(hipFuncSetAttribute((const void *)k_bins_expand<2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+  return KSG_OK;
+}
+
+/* The same split, with the binned part uploaded as *B.  rowmap (may be NULL): the rows of y the
+ * block's rows stand for (ksg_bins_mult is then given the same list on the device). */
+int ksg_bins_build(ksg_ctx c, ksg_bins *B, int64_t nrows, int64_t ncols, const int64_t *rowptr, const int32_t *colidx,
+                   const double *val, bool has_diag, int64_t dshift, std::vector<int32_t> &lrows, std::vector<int64_t> &lrp,
+                   std::vector<int32_t> &lci, std::vector<double> &lva, const int32_t *rowmap) {
+  memset(B, 0, sizeof(*B));
+  bins_levels BL;
+  bins_build_levels(&BL, nrows, ncols, rowptr, colidx, val, has_diag, dshift, lrows, lrp, lci, lva);
+  if (!BL.L1.nent) return KSG_OK;
+  KSG_CHK(bins_to_device(c, B, BL.L1, rowmap, NULL));
+  { bins_host().col16.swap(BL.L1.col16); bins_host().rowloc.swap(BL.L1.rowloc); }    /* the host copy of level 1 is no longer needed */
+  if (BL.L2.nent) {
+    B->next = new (std::nothrow) ksg_bins;
+    if (!B->next) KSG_FAIL(KSG_ERR_MEM, "binned operator: out of host memory");
+    memset(B->next, 0, sizeof(*B->next));
+    std::vector<int32_t> ry(BL.rows2);
+    if (rowmap) for (size_t i = 0; i < ry.size(); i++) ry[i] = rowmap[ry[i]];
+    KSG_CHK(bins_upload(&B->next_rows_y, ry.data(), ry.size()));
+    if (rowmap) KSG_CHK(bins_upload(&B->next_rows_blk, BL.rows2.data(), BL.rows2.size()));
+    else B->next_rows_blk = B->next_rows_y;
+    KSG_CHK(bins_to_device(c, B->next, BL.L2, ry.data(), BL.L2.nent <= B->nent ? B->xe : NULL));
+  }
   return KSG_OK;
 }
 
@@ -916,6 +990,7 @@ int ksg_bins_mult(const ksg_bins *B, const double *x, int64_t ncols, double *y, 
     hipLaunchKernelGGL(k_bins_long_rows, dim3((unsigned)((B->nlong + KSG_BLOCK - 1) / KSG_BLOCK)), dim3(KSG_BLOCK), 0, st, B->long_rows,
                        B->long_first, (int)B->nlong, B->part, y);
   KSG_HIP(hipGetLastError());
+  if (B->next) KSG_CHK(ksg_bins_mult(B->next, x, ncols, y, st, B->next_rows_y));
   return KSG_OK;
 }
 
@@ -927,7 +1002,8 @@ double ksg_bins_bytes(const ksg_bins *B) {
   const double vb = B->vmode == 2 ? 8.0 : B->vmode == 1 ? 1.0 : 0.0;
   return (2.0 + vb) * (double)B->nent1 + 8.0 * (double)B->nseg + 4.0 * (double)(B->nent1 / 64) +
          (8.0 * B->W + 24.0) * (double)B->ntasks + 8.0 * (double)B->nent +
-         10.0 * (double)B->nent + 24.0 * (double)B->nbins + (B->dv ? 24.0 : 8.0) * (double)B->nrows;
+         10.0 * (double)B->nent + 24.0 * (double)B->nbins + (B->dv ? 24.0 : 8.0) * (double)B->nrows +
+         (B->next ? ksg_bins_bytes(B->next) + 12.0 * (double)B->next->nrows : 0.0);   /* level 2 reads and writes y through its row list */
 }
 
 /* The binned entries and the folded diagonal back on the host as (row, column, value) triplets,
@@ -982,5 +1058,12 @@ int ksg_bins_to_host(const ksg_bins *B, std::vector<int32_t> &rows, std::vector<
     }
   }
   for (int64_t r = 0; r < (B->dv ? B->nrows : 0); r++) { rows.push_back((int32_t)r); cols.push_back((int32_t)(r + B->dshift)); vals.push_back(dv[(size_t)r]); }
+  if (B->next) {
+    std::vector<int32_t> r2, c2, map((size_t)B->next->nrows);
+    std::vector<double> v2;
+    KSG_CHK(ksg_bins_to_host(B->next, r2, c2, v2));
+    KSG_HIP(hipMemcpy(map.data(), B->next_rows_blk, map.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < r2.size(); i++) { rows.push_back(map[(size_t)r2[i]]); cols.push_back(c2[i]); vals.push_back(v2[i]); }
+  }
   return KSG_OK;
 }

@@ -260,6 +260,14 @@ struct ksg_bins {
   double *part;              /* npieces sums, added to their rows after the reduce pass             */
   double *dv;                /* nrows: the block's diagonal, folded into the reduce pass (NULL: the block has none, or not one per row) */
   double *xe;                /* nent + 64 products                                               */
+  /* second level: the entries the cells of this level were too thin for, binned again over the
+   * rows that have such entries with four times the rows per row block (cells five to twenty
+   * times as large); its sums are added to y after this level has stored its rows, and it shares
+   * this level's product array */
+  ksg_bins *next;
+  int32_t *next_rows_y;      /* next->nrows: the row of y each of its rows is added to             */
+  int32_t *next_rows_blk;    /* the same in rows of this block (== next_rows_y without a row list) */
+  int xe_shared;             /* xe belongs to the level above                                      */
 };
 
 struct ksg_mat_s {

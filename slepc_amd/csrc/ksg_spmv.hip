@@ -1631,12 +1631,17 @@ extern "C" int ksg_mat_describe(ksg_mat A, char *buf, size_t len) {
   if (A->bins.nent && k > 0 && (size_t)k < len) {
     long long rows = 0, ent = 0, hot = 0;
     for (const ksg_colgroup &cg : A->cgs) { rows += cg.nrows; ent += cg.blk.nnz; hot += cg.nhot; }
+    char lvl2[200] = "";
+    if (A->bins.next)
+      snprintf(lvl2, sizeof(lvl2), "; second level: %lld of the entries left, over the %lld rows that have them, in row blocks of <= %d of those rows "
+               "(%lld runs, %lld row blocks), added to y", (long long)A->bins.next->nreal, (long long)A->bins.next->nrows, A->bins.next->H,
+               (long long)A->bins.next->nseg, (long long)A->bins.next->nbins);
     k = snprintf(buf, len, "binned part: %lld of %lld entries in cells of %d-column blocks x row blocks of <= %d rows (%lld runs, %lld row blocks, "
-                 "values: %s), expanded through LDS slices of x and summed per row block in LDS%s; remaining entries: %lld in %lld rows through "
+                 "values: %s), expanded through LDS slices of x and summed per row block in LDS%s%s; remaining entries: %lld in %lld rows through "
                  "the tile kernel (row tiles of <= %d entries, %lld packed hot columns), added afterwards",
                  (long long)A->bins.nreal, (long long)A->nnz, A->bins.W, A->bins.H, (long long)A->bins.nseg, (long long)A->bins.nbins,
                  A->bins.vmode == 0 ? "one" : A->bins.vmode == 1 ? "1-byte indices" : "8-byte stream",
-                 A->bins.dv ? ", the diagonal as a dense vector in the same pass" : "", ent, rows, KSG_TILE_NNZ, hot);
+                 A->bins.dv ? ", the diagonal as a dense vector in the same pass" : "", lvl2, ent, rows, KSG_TILE_NNZ, hot);
   } else if (!A->cgs.empty() && k > 0 && (size_t)k < len) {
     long long rows = 0, ent = 0, hot = 0;
     for (const ksg_colgroup &cg : A->cgs) { rows += cg.nrows; ent += cg.blk.nnz; hot += cg.nhot; }

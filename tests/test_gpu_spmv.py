@@ -518,9 +518,9 @@ def test_binned_random_blocks(gpu_ctx):
     from slepc_amd import ksgpu
     ctx = gpu_ctx
     rng = np.random.default_rng(4242)
-    keys = ("KSG_BINS_W", "KSG_BINS_H", "KSG_BINS_E", "KSG_BINS_T", "KSG_BINS_TASK_GROUPS")
+    keys = ("KSG_BINS_W", "KSG_BINS_H", "KSG_BINS_E", "KSG_BINS_T", "KSG_BINS_TASK_GROUPS", "KSG_BINS_LEVELS", "KSG_BINS_H2")
     old = {k: os.environ.get(k) for k in keys}
-    binned = 0
+    binned = two_levels = 0
     try:
         ctx.set_option(ksgpu.OPT_BINS, 2)
         for trial in range(40):
@@ -543,9 +543,11 @@ def test_binned_random_blocks(gpu_ctx):
             rp = np.concatenate([[0], np.cumsum(np.bincount(rows, minlength=n))]).astype(np.int64)
             os.environ.update({"KSG_BINS_W": str(rng.choice([64, 256, 1024])), "KSG_BINS_H": str(rng.choice([64, 100, 256])),
                                "KSG_BINS_E": str(rng.choice([40, 200, 5000])), "KSG_BINS_T": str(rng.choice([1, 2, 3])),
-                               "KSG_BINS_TASK_GROUPS": str(rng.choice([1, 2, 9]))})
+                               "KSG_BINS_TASK_GROUPS": str(rng.choice([1, 2, 9])), "KSG_BINS_LEVELS": str(rng.choice([1, 2, 2])),
+                               "KSG_BINS_H2": str(rng.choice([128, 300, 8192]))})
             A = ksgpu.DeviceCSR(ctx, rp, cols, vals, cols=None if nc == n else (nc, nc, 0))
             binned += "binned part" in A.describe()
+            two_levels += "second level" in A.describe()
             x = rng.standard_normal(nc)
             xd, yd = ctx.vec_alloc(nc), ctx.vec_alloc(n)
             ctx.upload(xd, x)
@@ -566,7 +568,7 @@ def test_binned_random_blocks(gpu_ctx):
                 os.environ.pop(k, None)
             else:
                 os.environ[k] = v
-    assert binned >= 10, binned
+    assert binned >= 10 and two_levels >= 3, (binned, two_levels)
 
 
 @pytest.mark.parametrize("gen", ["lap1d", "lap2d", "lap3d", "band"])
@@ -683,3 +685,69 @@ def test_setup_same_for_any_host_thread_count(gpu_ctx, case):
     assert np.array_equal(got[0][2][1], ci) and np.array_equal(got[0][2][2], va)
     ctx.vec_free(xd)
     ctx.vec_free(yd)
+
+
+@pytest.mark.parametrize("values", ["laplacian", "any"])
+def test_binned_second_level(gpu_ctx, values):
+    """Two levels of the binned form (KSG_BINS_LEVELS=2; one level by default): the
+    entries the first level's cells were too thin for are binned over the rows that have them and
+    added to y after the first level stored it.  Product against the CSR loop, the same bits on a second
+    product, the entries read back, the transpose, the residual norm."""
+    import os
+    from scipy.sparse import csr_matrix
+    from slepc_amd import ksgpu, matgen as mg
+    ctx = gpu_ctx
+    rp, ci, va = mg.rmat_laplacian(14, 6, seed=21)
+    n = len(rp) - 1
+    rng = np.random.default_rng(8)
+    if values == "any":
+        va = rng.standard_normal(len(va))
+    env = {"KSG_BINS_W": 512, "KSG_BINS_H": 64, "KSG_BINS_E": 2000, "KSG_BINS_T": 4, "KSG_BINS_TASK_GROUPS": 16, "KSG_BINS_H2": 1024}
+    old = {k: os.environ.get(k) for k in list(env) + ["KSG_BINS_LEVELS"]}
+    try:
+        os.environ.update({k: str(v) for k, v in env.items()})
+        ctx.set_option(ksgpu.OPT_BINS, 2)
+        os.environ["KSG_BINS_LEVELS"] = "1"
+        A1 = ksgpu.DeviceCSR(ctx, rp, ci, va)
+        os.environ["KSG_BINS_LEVELS"] = "2"
+        A2 = ksgpu.DeviceCSR(ctx, rp, ci, va)
+    finally:
+        ctx.set_option(ksgpu.OPT_BINS, 0)
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    d1, d2 = A1.describe(), A2.describe()
+    assert "binned part" in d1 and "second level" not in d1
+    assert "second level" in d2, d2
+    import re
+    left1 = int(re.search(r"remaining entries: (\d+)", d1).group(1))
+    left2 = int(re.search(r"remaining entries: (\d+)", d2).group(1))
+    second = int(re.search(r"second level: (\d+)", d2).group(1))
+    assert left1 == left2 + second and second > left1 // 4, (d1, d2)
+    M = csr_matrix((va, ci, rp), shape=(n, n))
+    xd, yd, zd, wd = (ctx.vec_alloc(n) for _ in range(4))
+    x = rng.standard_normal(n)
+    ctx.upload(xd, x)
+    bound = 1e-14 * (np.abs(M) @ np.abs(x) + 1e-300)
+    for A in (A1, A2):
+        ctx.upload(yd, np.full(n, np.nan))
+        A.mult(xd, yd)
+        y = ctx.download(yd, n)
+        assert np.all(np.abs(y - M @ x) <= bound)
+        ctx.upload(zd, np.full(n, np.nan))
+        A.mult(xd, zd)
+        assert np.array_equal(ctx.download(zd, n), y)
+    r2, c2, v2 = A2.get_csr()
+    assert np.array_equal(r2, rp) and np.array_equal(c2, ci) and np.array_equal(v2, va)
+    T1, T2 = A1.transpose(), A2.transpose()
+    for a, b in zip(T1.get_csr(), T2.get_csr()):
+        assert np.array_equal(a, b)
+    want = np.linalg.norm(M @ x - 0.5 * x)
+    assert abs(A2.residual_norm(0.5, 0.0, xd, None, wd) - want) <= 1e-13 * want
+    assert A2.traffic_model()[0] > 0
+    for o in (A1, A2, T1, T2):
+        o.destroy()
+    for p_ in (xd, yd, zd, wd):
+        ctx.vec_free(p_)
