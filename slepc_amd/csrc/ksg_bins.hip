@@ -370,7 +370,7 @@ static void bins_build_host(bins_host *B, int64_t nrows, int64_t ncols, const in
                             std::vector<int32_t> &lci, std::vector<double> &lva, int H, int64_t E) {
   *B = bins_host();
   lrows.clear(); lrp.clear(); lci.clear(); lva.clear();
-  /* R-MAT scale 26 (1.13e9 entries): 6.65 ms per product with H = 2048, 7.27 with 4096; before the reduce pass combined
+  /* R-MAT scale 26 (1.13e9 entries, E = 65536): 6.65 ms per product with H = 2048, 7.27 with 4096; before the reduce pass combined
    * equal rows: 7.05 / 7.11 / 7.21 ms with H = 2048 / 4096 / 8192 (E = 131072), T = 6: 7.26;
    * scale 24 then: W = 16384 1.61 ms, 8192 1.63, 4096 1.69 (profiles/r02_spmv_rmat_binned.txt) */
   int W = env_int("KSG_BINS_W", 16384);
@@ -739,7 +739,18 @@ static void bins_build_host(bins_host *B, int64_t nrows, int64_t ncols, const in
 
   tm.lap("value table");
   /* expand tasks: a column block's groups in pieces of at most TG groups, the longest first */
-  const int64_t TG = env_int("KSG_BINS_TASK_GROUPS", 2048);
+  /* A task loads its column block's slice of x (128 KiB) before it streams its entries: the larger
+   * the tasks, the less of that, as long as there are enough of them to balance 256 CUs.  Unless set,
+   * the largest of 8192, 4096, 2048 groups that leaves 2048 tasks (R-MAT scale 26, ~4250 groups per
+   * column block: 6.54 ms with 2048 groups per task, 6.45 with 4096, 6.42 with 8192 or 16384; scale 24
+   * the same for all; scale 22 has 256 column blocks in all). */
+  int64_t TG = env_int("KSG_BINS_TASK_GROUPS", 0);
+  if (TG <= 0)
+    for (TG = 8192; TG > 2048; TG /= 2) {
+      int64_t nt = 0;
+      for (int64_t cb = 0; cb < NC; cb++) nt += (cpos[cb + 1] / 64 - cpos[cb] / 64 + TG - 1) / TG;
+      if (nt >= 2048) break;
+    }
   {
     std::vector<int64_t> t3;
     for (int64_t cb = 0; cb < NC; cb++)
@@ -832,7 +843,19 @@ static void bins_build_levels(bins_levels *BL, int64_t nrows, int64_t ncols, con
   BL->L2 = bins_host();
   BL->rows2.clear();
   const int H = env_int("KSG_BINS_H", 2048);
-  const int64_t E = env_int("KSG_BINS_E", 65536);
+  /* Most entries per row block.  Where rows are long (the hub rows of a power-law operator) it is E
+   * and not H that ends a row block, and the fewer rows a block has, the thinner its cells: a larger
+   * E bins more entries in longer runs.  But one wave sums a row block, at some 0.3e9 products per
+   * second, so the largest blocks must stay well below the time of the whole pass (all products at
+   * some 500e9 per second).  Unless set: 3e-4 of the block's entries, as a power of two between 65536
+   * and 524288.  R-MAT scale 26 (1.13e9 entries): 6.54 ms per product with E = 65536, 6.16 with 131072,
+   * 5.97 with 262144 (5.88 with the larger tasks above), 5.86 / 5.91 with 393216 / 524288, 7.24 with
+   * 1048576; scale 24 (2.8e8 entries): 1.41 ms with 65536 or 131072, 1.73 with 262144, 2.46 with 524288. */
+  int64_t E = env_int("KSG_BINS_E", 0);
+  if (E <= 0) {
+    E = 65536;
+    while (E < 524288 && (double)(2 * E) <= 3e-4 * (double)rowptr[nrows]) E *= 2;
+  }
   bins_build_host(&BL->L1, nrows, ncols, rowptr, colidx, val, has_diag, dshift, lrows, lrp, lci, lva, H, E);
   if (!BL->L1.nent || lrows.empty()) return;
   const int levels = env_int("KSG_BINS_LEVELS", 0);

@@ -935,7 +935,7 @@ static int column_groups_for(ksg_ctx c, int64_t ncols, int64_t nnz, const int32_
  * power-law operator (the test of the packing), and by default an x of 32 MiB or more (R-MAT scale 21,
  * 16 MiB: 0.26 ms per product as a CSR, 0.32 ms binned -- too few column blocks to fill the device;
  * scale 22: 0.51 and 0.44 ms; scale 23: 0.98 and 0.70 ms; scale 24: 2.09 and 1.42 ms; scale 26: 8.92 ms
- * in column groups, 6.65 ms binned; profiles/r02_spmv_rmat_binned.txt). */
+ * in column groups, 5.89 ms binned; profiles/r02_spmv_rmat_binned.txt). */
 static bool bins_wanted(ksg_ctx c, int64_t ncols, int64_t nnz, const int32_t *colidx, col_counts *cc = NULL) {
   if (c->bins == 1 || ncols < 64 || ncols > (int64_t)INT32_MAX) return false;
   if (c->bins == 0 && ncols < ((int64_t)32 << 20) / 8) return false;
