@@ -28,9 +28,11 @@
  *
  * Tuning variables, read when an operator is created: KSG_BINS_W (columns per column block, a
  * power of two up to 16384 = 128 KiB of LDS), KSG_BINS_H (rows per row block, up to 8192),
- * KSG_BINS_E (entries per row block), KSG_BINS_T (fewest entries of a binned cell),
- * KSG_BINS_TASK_GROUPS (groups of 64 entries per expand workgroup), KSG_BINS_THREADS (threads
- * of an expand workgroup). */
+ * KSG_BINS_E (entries per row block; unless set, 3e-4 of the block's entries as a power of two
+ * between 65536 and 524288), KSG_BINS_T (fewest entries of a binned cell), KSG_BINS_TASK_GROUPS
+ * (groups of 64 entries per expand workgroup; unless set, up to 8192), KSG_BINS_THREADS (threads
+ * of an expand workgroup), KSG_BINS_LEVELS=2 (a second level for the entries of thin cells, with
+ * KSG_BINS_H2 rows per row block). */
 #include <algorithm>
 #include <numeric>
 #include <stdlib.h>
