@@ -3,7 +3,8 @@
 in (KSG_OPT_COL_GROUPS; 1 = the whole operator in one block).
 Usage: spmv_colgroups.py [scale=24] [groups=1,2,4,8] [limit of packed columns per group=1048576,...]
 KSG_RANK_OF=r/P: only the rows that rank r of P owns under the entry-balanced split, as a rectangular
-operator over all columns -- the shape of one rank's work in a P-rank run (its ghost entries included)."""
+operator over all columns -- the shape of one rank's work in a P-rank run (its ghost entries included).
+KSG_SWEEP_E=a,b,...: every setting once per value of KSG_BINS_E."""
 import os
 import sys
 import time
@@ -35,7 +36,12 @@ def main():
     x, y = ctx.vec_alloc(NC), ctx.vec_alloc(n)
     ctx.vec_fill_hash(x, NC, 0, 5)
     y0 = None
-    for g, hot in [(g, h) for g in groups for h in hots]:
+    # KSG_SWEEP_E=65536,131072,...: the same operator once per value of KSG_BINS_E (with KSG_SPMV_BINS=2)
+    sweep = [v for v in os.environ.get("KSG_SWEEP_E", "").split(",") if v]
+    for g, hot, e in [(g, h, e) for g in groups for h in hots for e in (sweep or [None])]:
+        if e is not None:
+            os.environ["KSG_BINS_E"] = e
+            print("KSG_BINS_E=%s" % e, flush=True)
         ctx.set_option(ksgpu.OPT_COL_GROUPS, g)
         ctx.set_option(ksgpu.OPT_HOT_COLS, hot)
         t0 = time.perf_counter()
