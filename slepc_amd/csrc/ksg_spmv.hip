@@ -939,7 +939,40 @@ static int column_groups_for(ksg_ctx c, int64_t ncols, int64_t nnz, const int32_
 static bool bins_wanted(ksg_ctx c, int64_t ncols, int64_t nnz, const int32_t *colidx, col_counts *cc = NULL) {
   if (c->bins == 1 || ncols < 64 || ncols > (int64_t)INT32_MAX) return false;
   if (c->bins == 0 && ncols < ((int64_t)32 << 20) / 8) return false;
-  return is_power_law(ncols, nnz, colidx, cc);
+  /* from 2^27 entries on the test is first made on every eighth stretch of 4096 entries (the same
+   * entries whatever the number of host threads): a block that passes it needs no exact count at
+   * all -- at R-MAT scale 26 the count is 1.0 s of a 4.3 s set-up -- and for one that fails it the
+   * other stretches are counted into the same array, which is then the exact count the decisions
+   * that follow use */
+  col_counts own;
+  col_counts &kc = cc ? *cc : own;
+  const char *smin = getenv("KSG_SAMPLE_MIN_NNZ");          /* for tests: the size from which the sample is taken */
+  const int64_t sample_from = smin && atoll(smin) > 0 ? atoll(smin) : ((int64_t)1 << 27);
+  if (nnz >= sample_from && nnz >= 8 * 4096 && !(kc.of == colidx && (int64_t)kc.cnt.size() == ncols)) {
+    const int64_t nch = nnz / (8 * 4096), ns = nch * 4096;
+    kc.of = NULL;
+    kc.cnt.assign((size_t)ncols, 0);
+    int32_t *k = kc.cnt.data();
+    ksg_parallel(setup_threads(ns), [&](int t, int nt) {
+      for (int64_t ch = nch * t / nt; ch < nch * (t + 1) / nt; ch++) {
+        const int32_t *ci = colidx + ch * 8 * 4096;
+        for (int i = 0; i < 4096; i++) __atomic_fetch_add(&k[ci[i]], 1, __ATOMIC_RELAXED);
+      }
+    });
+    const int64_t thresh = std::max<int64_t>(8, 4 * ((ns + ncols - 1) / ncols));
+    int64_t covered = 0;
+    for (int64_t j = 0; j < ncols; j++) if (k[j] >= thresh) covered += k[j];
+    if (covered * 100 >= ns * 15) return true;
+    ksg_parallel(setup_threads(nnz), [&](int t, int nt) {
+      for (int64_t ch = nch * t / nt; ch < nch * (t + 1) / nt; ch++) {
+        const int32_t *ci = colidx + ch * 8 * 4096;
+        for (int i = 4096; i < 8 * 4096; i++) __atomic_fetch_add(&k[ci[i]], 1, __ATOMIC_RELAXED);
+      }
+    });
+    for (int64_t p = nch * 8 * 4096; p < nnz; p++) k[colidx[p]]++;
+    kc.of = colidx;
+  }
+  return is_power_law(ncols, nnz, colidx, &kc);
 }
 
 static int diag_to_device(ksg_mat A, int64_t nrows, const int64_t *rowptr, const int32_t *colidx, const double *val) {

@@ -638,7 +638,8 @@ def test_setup_same_for_any_host_thread_count(gpu_ctx, case):
     """The set-up of an operator (validation, column counts, packed columns, value tables, row codes,
     the binned build) runs its passes on several host threads from a million entries on
     (KSG_HOST_THREADS): the operator described, the entries read back and every bit of the product
-    are the same for 1 and 7 threads; a column index out of range is reported as with one thread."""
+    are the same for 1 and 7 threads, and when the power-law test starts from a sample of the entries
+    (as it does for very large blocks); a column index out of range is reported as with one thread."""
     import os
     from slepc_amd import ksgpu, matgen as mg
     ctx = gpu_ctx
@@ -658,8 +659,12 @@ def test_setup_same_for_any_host_thread_count(gpu_ctx, case):
     got = []
     try:
         ctx.set_option(ksgpu.OPT_BINS, 2 if case in ("rmat_binned", "random_values") else 1)
-        for nt in (1, 7):
+        for nt, sample_from in ((1, None), (7, None), (7, 40000)):
             os.environ["KSG_HOST_THREADS"] = str(nt)
+            # the power-law test of very large blocks starts from a sample of the entries: here on this size
+            os.environ.pop("KSG_SAMPLE_MIN_NNZ", None)
+            if sample_from:
+                os.environ["KSG_SAMPLE_MIN_NNZ"] = str(sample_from)
             A = ksgpu.DeviceCSR(ctx, rp, ci, va)
             ctx.upload(yd, np.full(n, np.nan))
             A.mult(xd, yd)
@@ -672,11 +677,13 @@ def test_setup_same_for_any_host_thread_count(gpu_ctx, case):
             ksgpu.DeviceCSR(ctx, rp, bad, va)
     finally:
         ctx.set_option(ksgpu.OPT_BINS, 0)
+        os.environ.pop("KSG_SAMPLE_MIN_NNZ", None)
         if old is None:
             os.environ.pop("KSG_HOST_THREADS", None)
         else:
             os.environ["KSG_HOST_THREADS"] = old
-    assert got[0][0] == got[1][0], (got[0][0], got[1][0])
+    assert got[0][0] == got[1][0] == got[2][0], (got[0][0], got[1][0], got[2][0])
+    assert np.array_equal(got[0][1], got[2][1])
     assert {"stencil": "row codes", "rmat_plain": "packed hot columns", "rmat_binned": "binned part",
             "random_values": "binned part"}[case] in got[0][0], got[0][0]
     assert np.array_equal(got[0][1], got[1][1])
