@@ -194,6 +194,17 @@ def analytic_laplacian_top(dims, count):
     return np.sort(acc)[::-1][:count]
 
 
+def pmc_record(wname):
+    """The record of `wname` in profiles/pmc_traffic.json (HBM bytes per kernel from the rocprofv3
+    counter passes of this same command, tools/profile_bench.sh), or None."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            pmc = json.load(f)
+        return next((r for r in pmc["records"] if r.get("workload") == wname), None)
+    except (OSError, ValueError, KeyError, TypeError):
+        return None
+
+
 # ---------------------------------------------------------------------------------------------
 # CPU baseline
 # ---------------------------------------------------------------------------------------------
@@ -439,16 +450,12 @@ def main():
                         "bytes_per_launch": round(per_launch)}
             # HBM bytes per launch from the PMC passes (cannot be collected from inside this
             # process: they come from the committed rocprofv3 summary of this same command)
-            try:
-                with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
-                    pmc = json.load(f)
-                k = pmc["kernels"].get(kname)
-                if k and k.get("traffic_over_algorithmic") and pmc.get("workload") == wname:
-                    roofline["traffic"] = round(k["traffic_over_algorithmic"] * per_launch)
-                    roofline["traffic_source"] = "profiles/pmc_traffic.json: measured traffic/algorithmic = %.4f over %d launches" % (
-                        k["traffic_over_algorithmic"], k["launches"])
-            except (OSError, ValueError, KeyError):
-                pass
+            pmc = pmc_record(wname)
+            k = pmc["kernels"].get(kname) if pmc else None
+            if k and k.get("traffic_over_algorithmic"):
+                roofline["traffic"] = round(k["traffic_over_algorithmic"] * per_launch)
+                roofline["traffic_source"] = "profiles/pmc_traffic.json: measured traffic/algorithmic = %.4f over %d launches" % (
+                    k["traffic_over_algorithmic"], k["launches"])
         mv = marks["c1"][0] - marks["c0"][0]
         gs = marks["c1"][1] - marks["c0"][1]
         strong = size > 1 and not args.weak

@@ -494,20 +494,28 @@ def test_libraries_export_declared_symbols():
 
 
 def test_pmc_traffic_file_layout():
-    """bench.py takes roofline.traffic from profiles/pmc_traffic.json: the layout it reads."""
+    """bench.py takes roofline.traffic from profiles/pmc_traffic.json, one record per workload:
+    the layout it reads, and how far measured HBM traffic may lie from the byte model."""
     import json
     import os
+    import bench
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     with open(os.path.join(root, "profiles", "pmc_traffic.json")) as f:
         pmc = json.load(f)
-    assert pmc["workload"].startswith("ex2 2-D 5-point Laplacian 4096x4096")
-    spmv = "k_spmv_rowcode" if "k_spmv_rowcode" in pmc["kernels"] else "k_spmv_tiles"
-    for k in ("k_multvec_dot", "k_dotw", spmv):
-        # the BV kernels move what the model says; the SpMV is charged with the bytes its variant
-        # streams, x counted once, and re-reads some x lines on top (the counters' factor two for
-        # wide streams overstates its narrow loads besides)
-        lo, hi = (0.4, 2.5) if k == spmv else (0.9, 1.2)
-        assert lo < pmc["kernels"][k]["traffic_over_algorithmic"] < hi and pmc["kernels"][k]["launches"] > 0
+    recs = {r["workload"]: r for r in pmc["records"]}
+    ex2 = next(r for w, r in recs.items() if w.startswith("ex2 2-D 5-point Laplacian 4096x4096"))
+    lap = next(r for w, r in recs.items() if w.startswith("3-D 7-point Laplacian 512x512x512"))
+    assert bench.pmc_record(ex2["workload"]) is ex2 or bench.pmc_record(ex2["workload"]) == ex2
+    assert bench.pmc_record("no such workload") is None
+    for rec, spmv_bounds in ((ex2, (0.9, 1.2)), (lap, (1.2, 2.0))):
+        assert "k_spmv_rowcode" in rec["kernels"]
+        for k in ("k_multvec_dot", "k_dotw", "k_spmv_rowcode"):
+            # the BV kernels move what the model says.  The row-code SpMV is charged with the bytes
+            # it streams, x counted once: on the 2-D grid that is what it moves; on the 512^3 grid the
+            # three x planes a row block touches (6 MB) exceed an XCD's L2 and the neighbouring planes
+            # come from beyond L2 again, 1.7x the model
+            lo, hi = spmv_bounds if k == "k_spmv_rowcode" else (0.9, 1.2)
+            assert lo < rec["kernels"][k]["traffic_over_algorithmic"] < hi and rec["kernels"][k]["launches"] > 0
 
 
 def test_eps_target_changed_between_solves(be):

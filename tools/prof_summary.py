@@ -9,6 +9,7 @@ timed restarts; this tool keeps the dispatches between those two markers.
                            per-kernel HBM traffic: (2*FETCH_SIZE + WRITE_SIZE) KiB per launch
                            (FETCH_SIZE reads half of a wide coalesced stream on gfx950;
                            WRITE_SIZE is exact for 16-byte-per-lane stores)
+    prof_summary.py counters <counter_collection.csv>       every counter of the pass, per kernel and launch
 """
 import csv
 import json
@@ -107,6 +108,21 @@ def main():
                       "traffic_over_algorithmic": (fb + wb) / mod if mod else None}
             print("%-22s %7d %16.0f %16.0f %16.0f %16s %7s" % (k, n, fb, wb, per, "%.0f" % (mod / n) if mod else "-",
                                                               "%.3f" % ((fb + wb) / mod) if mod else "-"))
+        print(json.dumps(res))
+    elif mode == "counters":
+        # every counter of one pass, summed over the instances and averaged over a kernel's launches
+        agg = OrderedDict()
+        for r in rows_between_markers(sys.argv[2]):
+            k = short(r["Kernel_Name"])
+            a = agg.setdefault(k, OrderedDict()).setdefault(r["Counter_Name"], [set(), 0.0])
+            a[0].add(r["Dispatch_Id"])
+            a[1] += float(r["Counter_Value"])
+        print("%-22s %-28s %9s %20s" % ("kernel", "counter", "launches", "per launch"))
+        res = OrderedDict()
+        for k, cs in agg.items():
+            for c, (ids, tot) in cs.items():
+                print("%-22s %-28s %9d %20.0f" % (k, c, len(ids), tot / len(ids)))
+                res.setdefault(k, {})[c] = {"launches": len(ids), "per_launch": tot / len(ids)}
         print(json.dumps(res))
     else:
         raise SystemExit(__doc__)

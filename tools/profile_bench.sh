@@ -14,10 +14,18 @@ export ARGS
 timeout -k 10 400 rocprofv3 --kernel-trace --stats -d $OUT -o trace --output-format csv -- python3 $R/bench.py $ARGS > $OUT/bench_trace.json 2> $OUT/trace.err
 timeout -s KILL 400 rocprofv3 --pmc FETCH_SIZE -d $OUT -o fetch --output-format csv -- python3 $R/bench.py $ARGS > $OUT/bench_fetch.json 2> $OUT/fetch.err
 timeout -s KILL 400 rocprofv3 --pmc WRITE_SIZE -d $OUT -o write --output-format csv -- python3 $R/bench.py $ARGS > $OUT/bench_write.json 2> $OUT/write.err
+# EXTRA_PMC="TCC_EA0_RDREQ_sum TCC_HIT_sum TCC_MISS_sum": one more counter pass, summed per kernel
+if [ -n "$EXTRA_PMC" ]; then
+  timeout -s KILL 400 rocprofv3 --pmc $EXTRA_PMC -d $OUT -o extra --output-format csv -- python3 $R/bench.py $ARGS > $OUT/bench_extra.json 2> $OUT/extra.err
+fi
 cd $R
+if [ -n "$EXTRA_PMC" ]; then
+  python3 tools/prof_summary.py counters $OUT/extra_counter_collection.csv > $OUT/summary_extra.txt
+  rm -f $OUT/extra_counter_collection.csv
+fi
 python3 tools/prof_summary.py trace $OUT/trace_kernel_trace.csv > $OUT/summary_trace.txt
 python3 tools/prof_summary.py pmc $OUT/fetch_counter_collection.csv $OUT/write_counter_collection.csv $OUT/bench_trace.json > $OUT/summary_pmc.txt
-# the file bench.py reads for roofline.traffic (copy it to profiles/pmc_traffic.json)
+# a record of the file bench.py reads for roofline.traffic (add it to "records" of profiles/pmc_traffic.json)
 python3 - "$OUT" <<'PY'
 import json, os, sys
 out = sys.argv[1]
