@@ -89,6 +89,9 @@ def parse_args(argv=None):
     ap.add_argument("--time-limit", type=float, default=0.0,
                     help="--to-convergence: give up after this many seconds of solve and report how far it got")
     ap.add_argument("--tol", type=float, default=0.0, help="0 = the default 1e-8")
+    ap.add_argument("--ritz-trace", default="",
+                    help="rank 0 writes the leading nev Ritz values and error estimates the solver reports after every "
+                         "restart to this JSON file (what runs on different rank counts are compared by)")
     args = ap.parse_args(argv)
     if args.workload is None:
         args.workload = "ex2" if args.gpus == 1 else "lap3d"
@@ -361,6 +364,12 @@ def main():
                 its, nconv, float(eigr[min(nconv, nest - 1)]), float(errest[min(nconv, nest - 1)]),
                 time.perf_counter() - marks.get("t0", time.perf_counter())), file=sys.stderr, flush=True)
         marks["last"] = (its, nconv, float(eigr[0]), float(errest[0]))
+        if args.ritz_trace and rank == 0 and its > 0:
+            m = min(args.nev, nest)
+            marks.setdefault("ritz", {})[str(its)] = {"nconv": int(nconv), "nest": int(nest),
+                                                      "re": [float(v) for v in eigr[:m]], "im": [float(v) for v in eigi[:m]],
+                                                      "errest": [float(v) for v in errest[:m]]}
+            print("restart %d: nconv %d, leading Ritz value %.15g" % (its, nconv, float(eigr[0])), file=sys.stderr, flush=True)
         marks["nconv_history"] = marks.get("nconv_history", [])
         if not marks["nconv_history"] or marks["nconv_history"][-1][1] != nconv:
             marks["nconv_history"].append((its, nconv, round(time.perf_counter() - marks.get("t0", time.perf_counter()), 2)))
@@ -414,6 +423,13 @@ def main():
         dist.all_reduce(b, op=dist.ReduceOp.SUM)
         nbytes, unfused = float(b[0]), float(b[1])
     value = nbytes / dt / 1e9
+    # what every rank holds: rows, entries, ghost entries of x it receives per product
+    mine = {"rank": rank, "rows": row1 - row0, "nnz": nnz_local, "ghost_in": int(dev_mat.info()["ghosts"]),
+            "ms_per_step": round(1e3 * (marks["t1"] - marks["t0"]) / Ksteps, 3)}
+    per_rank = [mine]
+    if dist:
+        per_rank = [None] * size
+        dist.all_gather_object(per_rank, mine)
 
     max_res = eig_err = None
     if args.to_convergence and eps.nconv > 0:
@@ -477,6 +493,7 @@ def main():
             "roofline": roofline, "kernels": kernels,
             "solver_state": {"restarts": eps.its, "last": marks["last"], "nconv": eps.nconv,
                              "reason": eps.reason},
+            "ranks": per_rank,
         }
         if args.to_convergence:
             out["time_to_convergence_s"] = round(dt, 3)
@@ -511,6 +528,11 @@ def main():
             else:
                 csr = (rp, ci, va)
             out["cpu_baseline"] = cpu_baseline(args, csr, args.nev, args.cpu_restarts, threads)
+        if args.ritz_trace:
+            with open(args.ritz_trace, "w") as f:
+                json.dump({"workload": wname, "n_ranks": size, "nev": args.nev, "ncv": ncv, "tol": tol_used,
+                           "restarts": marks.get("ritz", {}),
+                           "eigenvalues": [list(map(float, eps.get_eigenvalue(i))) for i in range(min(eps.nconv, args.nev))]}, f)
         print(json.dumps(out), flush=True)
 
     eps.destroy()

@@ -369,7 +369,7 @@ struct bins_block { int32_t r0, nr, piece; int64_t e0, e1; };
  * (B->nent == 0, the vectors stay empty). */
 static void bins_build_host(bins_host *B, int64_t nrows, int64_t ncols, const int64_t *rowptr, const int32_t *colidx,
                             const double *val, bool has_diag, int64_t dshift, std::vector<int32_t> &lrows, std::vector<int64_t> &lrp,
-                            std::vector<int32_t> &lci, std::vector<double> &lva, int H, int64_t E) {
+                            std::vector<int32_t> &lci, std::vector<double> &lva, int H, int64_t E, int maxW) {
   *B = bins_host();
   lrows.clear(); lrp.clear(); lci.clear(); lva.clear();
   /* R-MAT scale 26 (1.13e9 entries, E = 65536): 6.65 ms per product with H = 2048, 7.27 with 4096; before the reduce pass combined
@@ -381,6 +381,7 @@ static void bins_build_host(bins_host *B, int64_t nrows, int64_t ncols, const in
   while ((1 << wshift) < W) wshift++;
   W = 1 << wshift;
   if (W > 16384) W = 16384, wshift = 14;                   /* 128 KiB of x in LDS */
+  while (W > maxW && W > 64) { W >>= 1; wshift--; }        /* what the device's LDS holds */
   if (W < 64) W = 64, wshift = 6;
   if (H > 8192) H = 8192;                                  /* 64 KiB of sums in LDS */
   if (H < 64) H = 64;
@@ -841,7 +842,7 @@ struct bins_levels {
 
 static void bins_build_levels(bins_levels *BL, int64_t nrows, int64_t ncols, const int64_t *rowptr, const int32_t *colidx,
                               const double *val, bool has_diag, int64_t dshift, std::vector<int32_t> &lrows, std::vector<int64_t> &lrp,
-                              std::vector<int32_t> &lci, std::vector<double> &lva) {
+                              std::vector<int32_t> &lci, std::vector<double> &lva, int maxW = 16384) {
   BL->L2 = bins_host();
   BL->rows2.clear();
   const int H = env_int("KSG_BINS_H", 2048);
@@ -858,7 +859,7 @@ static void bins_build_levels(bins_levels *BL, int64_t nrows, int64_t ncols, con
     E = 65536;
     while (E < 524288 && (double)(2 * E) <= 3e-4 * (double)rowptr[nrows]) E *= 2;
   }
-  bins_build_host(&BL->L1, nrows, ncols, rowptr, colidx, val, has_diag, dshift, lrows, lrp, lci, lva, H, E);
+  bins_build_host(&BL->L1, nrows, ncols, rowptr, colidx, val, has_diag, dshift, lrows, lrp, lci, lva, H, E, maxW);
   if (!BL->L1.nent || lrows.empty()) return;
   const int levels = env_int("KSG_BINS_LEVELS", 0);
   const int H2 = std::min(env_int("KSG_BINS_H2", 4 * BL->L1.H), 8192);
@@ -868,7 +869,7 @@ static void bins_build_levels(bins_levels *BL, int64_t nrows, int64_t ncols, con
   std::vector<int64_t> rp3;
   std::vector<double> va3;
   bins_build_host(&BL->L2, (int64_t)lrows.size(), ncols, lrp.data(), lci.data(), lva.data(), false, 0, rows3, rp3, ci3, va3, H2,
-                  4 * E);
+                  4 * E, maxW);
   if (!BL->L2.nent) return;
   BL->rows2 = lrows;
   for (size_t i = 0; i < rows3.size(); i++) rows3[i] = lrows[(size_t)rows3[i]];
@@ -965,11 +966,35 @@ static int bins_to_device(ksg_ctx c, ksg_bins *B, const bins_host &Hb, const int
     hipError_t e = hipMalloc((void **)&B->xe, (size_t)(B->nent + 64) * sizeof(double));
     if (e != hipSuccess) KSG_FAIL(KSG_ERR_MEM, "binned operator: %zu bytes of products: %s", (size_t)(B->nent + 64) * sizeof(double), hipGetErrorString(e));
   }
-  /* the expand kernel's slice of x may exceed the 64 KiB a kernel gets without asking */
-  const int lds = (B->W + 1) * (int)sizeof(double);
-  KSG_HIP(hipFuncSetAttribute((const void *)k_bins_expand<0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-  KSG_HIP(hipFuncSetAttribute((const void *)k_bins_expand<1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-  KSG_HIP(hipFuncSetAttribute((const void *)k_bins_expand<2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+  return KSG_OK;
+}
+
+/* Columns per column block the device's LDS can hold (a power of two, at most 16384), and, once per
+ * device, the expand kernels' permission to use that much: the slice of x may exceed the 64 KiB a
+ * kernel gets without asking.  The attribute belongs to the kernel on the device, not to an
+ * operator, so it is set to the largest slice any operator on this device may ask for. */
+static int bins_device_max_w(ksg_ctx c, int *maxW) {
+  static int known[64];                                   /* per device: 0 = not asked yet, -1 = no binned form here */
+  *maxW = 0;
+  if (c->device < 0 || c->device >= 64) return KSG_OK;
+  if (!known[c->device]) {
+    KSG_HIP(hipSetDevice(c->device));
+    int optin = 0;
+    if (hipDeviceGetAttribute(&optin, hipDeviceAttributeSharedMemPerBlockOptin, c->device) != hipSuccess || optin <= 0)
+      if (hipDeviceGetAttribute(&optin, hipDeviceAttributeMaxSharedMemoryPerBlock, c->device) != hipSuccess) optin = 0;
+    int w = 16384;
+    while (w >= 1024 && (w + 1) * (int)sizeof(double) > optin) w >>= 1;
+    known[c->device] = -1;
+    if (w >= 1024) {
+      const int lds = (w + 1) * (int)sizeof(double);
+      if (hipFuncSetAttribute((const void *)k_bins_expand<0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) == hipSuccess &&
+          hipFuncSetAttribute((const void *)k_bins_expand<1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) == hipSuccess &&
+          hipFuncSetAttribute((const void *)k_bins_expand<2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) == hipSuccess)
+        known[c->device] = w;
+      else (void)hipGetLastError();
+    }
+  }
+  if (known[c->device] > 0) *maxW = known[c->device];
   return KSG_OK;
 }
 
@@ -979,21 +1004,33 @@ int ksg_bins_build(ksg_ctx c, ksg_bins *B, int64_t nrows, int64_t ncols, const i
                    const double *val, bool has_diag, int64_t dshift, std::vector<int32_t> &lrows, std::vector<int64_t> &lrp,
                    std::vector<int32_t> &lci, std::vector<double> &lva, const int32_t *rowmap) {
   memset(B, 0, sizeof(*B));
+  lrows.clear(); lrp.clear(); lci.clear(); lva.clear();
+  int maxW = 0;
+  KSG_CHK(bins_device_max_w(c, &maxW));
+  if (!maxW) return KSG_OK;                               /* too little LDS for a slice worth having: the block stays a CSR */
   bins_levels BL;
-  bins_build_levels(&BL, nrows, ncols, rowptr, colidx, val, has_diag, dshift, lrows, lrp, lci, lva);
+  bins_build_levels(&BL, nrows, ncols, rowptr, colidx, val, has_diag, dshift, lrows, lrp, lci, lva, maxW);
   if (!BL.L1.nent) return KSG_OK;
-  KSG_CHK(bins_to_device(c, B, BL.L1, rowmap, NULL));
+  int rc = bins_to_device(c, B, BL.L1, rowmap, NULL);
   { bins_host().col16.swap(BL.L1.col16); bins_host().rowloc.swap(BL.L1.rowloc); }    /* the host copy of level 1 is no longer needed */
-  if (BL.L2.nent) {
+  if (!rc && BL.L2.nent) {
     B->next = new (std::nothrow) ksg_bins;
-    if (!B->next) KSG_FAIL(KSG_ERR_MEM, "binned operator: out of host memory");
-    memset(B->next, 0, sizeof(*B->next));
-    std::vector<int32_t> ry(BL.rows2);
-    if (rowmap) for (size_t i = 0; i < ry.size(); i++) ry[i] = rowmap[ry[i]];
-    KSG_CHK(bins_upload(&B->next_rows_y, ry.data(), ry.size()));
-    if (rowmap) KSG_CHK(bins_upload(&B->next_rows_blk, BL.rows2.data(), BL.rows2.size()));
-    else B->next_rows_blk = B->next_rows_y;
-    KSG_CHK(bins_to_device(c, B->next, BL.L2, ry.data(), BL.L2.nent <= B->nent ? B->xe : NULL));
+    if (!B->next) { ksg_set_error("binned operator: out of host memory"); rc = KSG_ERR_MEM; }
+    else {
+      memset(B->next, 0, sizeof(*B->next));
+      std::vector<int32_t> ry(BL.rows2);
+      if (rowmap) for (size_t i = 0; i < ry.size(); i++) ry[i] = rowmap[ry[i]];
+      rc = bins_upload(&B->next_rows_y, ry.data(), ry.size());
+      if (!rc && rowmap) rc = bins_upload(&B->next_rows_blk, BL.rows2.data(), BL.rows2.size());
+      else if (!rc) B->next_rows_blk = B->next_rows_y;
+      if (!rc) rc = bins_to_device(c, B->next, BL.L2, ry.data(), BL.L2.nent <= B->nent ? B->xe : NULL);
+    }
+  }
+  if (rc) {
+    /* an upload failed: nothing of the binned form is kept, the caller holds the block as a CSR (and
+     * reports the shortage itself if that does not fit either) */
+    ksg_bins_free(B);
+    lrows.clear(); lrp.clear(); lci.clear(); lva.clear();
   }
   return KSG_OK;
 }

@@ -182,6 +182,17 @@ static int exchange_device(ksg_ctx c, const double *send, const int64_t *sendoff
   return KSG_OK;
 }
 
+/* Every rank reports whether its staging buffers are ready (rc == 0); unless all are, all
+ * return an error and none enters the collective that would follow. */
+static int staging_agreed(ksg_ctx c, int rc, const char *what) {
+  double flag = rc ? 1.0 : 0.0;
+  const int rc2 = ksg_comm_allreduce_host(c, &flag, 1, 1);
+  if (rc) return rc;
+  if (rc2) return rc2;
+  if (flag != 0.0) KSG_FAIL(KSG_ERR_COMM, "%s: another rank could not stage its buffers", what);
+  return KSG_OK;
+}
+
 /* Self-test of the communicator (collective): one sum over the ranks with a known answer, and one
  * ring exchange -- every rank sends a block to the next rank and receives the previous rank's (its
  * own, on a single rank) -- through the same all-to-all-v path, on the communication stream, that
@@ -214,8 +225,9 @@ extern "C" int ksg_ctx_comm_selftest(ksg_ctx c) {
     if (e == hipSuccess) e = hipMemcpyAsync(ds, hs.data(), (size_t)nblk * sizeof(double), hipMemcpyHostToDevice, c->comm_stream);
     if (e == hipSuccess) e = hipMemsetAsync(dr, 0xff, (size_t)nblk * sizeof(double), c->comm_stream);
     if (e != hipSuccess) { ksg_set_error("communicator self-test: staging failed: %s", hipGetErrorString(e)); rc = KSG_ERR_HIP; }
-    /* like ksg_comm_exchange_host: a rank whose staging failed still takes part in the collective */
-    if (ds && dr) { const int rc2 = exchange_device(c, ds, soff.data(), dr, roff.data(), c->comm_stream); if (!rc) rc = rc2; }
+    /* the exchange is a collective: the ranks enter it only when the staging of all of them succeeded */
+    rc = staging_agreed(c, rc, "communicator self-test");
+    if (!rc) rc = exchange_device(c, ds, soff.data(), dr, roff.data(), c->comm_stream);
     if (!rc) {
       e = hipMemcpyAsync(hr.data(), dr, (size_t)nblk * sizeof(double), hipMemcpyDeviceToHost, c->comm_stream);
       if (e != hipSuccess) { ksg_set_error("communicator self-test: copy failed: %s", hipGetErrorString(e)); rc = KSG_ERR_HIP; }
@@ -265,9 +277,10 @@ int ksg_comm_exchange_host(ksg_ctx c, const double *send, const int64_t *sendoff
   if (e == hipSuccess) e = hipMalloc(&dr, (size_t)(nr > 0 ? nr : 1) * sizeof(double));
   if (e == hipSuccess && ns) e = hipMemcpyAsync(ds, send, (size_t)ns * sizeof(double), hipMemcpyHostToDevice, c->stream);
   if (e != hipSuccess) { ksg_set_error("halo set-up staging failed: %s", hipGetErrorString(e)); rc = KSG_ERR_HIP; }
-  /* a rank whose staging failed must not leave the others alone in the exchange: it is a
-   * collective, so this rank takes part with whatever it has and reports its error afterwards */
-  if (ds && dr) { const int rc2 = exchange_device(c, ds, sendoff, dr, recvoff, c->stream); if (!rc) rc = rc2; }
+  /* the exchange is a collective: the ranks enter it only when the staging of all of them
+   * succeeded (the flag travels through the reduction buffer the context already owns) */
+  rc = staging_agreed(c, rc, "halo set-up");
+  if (!rc) rc = exchange_device(c, ds, sendoff, dr, recvoff, c->stream);
   if (!rc && nr) {
     e = hipMemcpyAsync(recv, dr, (size_t)nr * sizeof(double), hipMemcpyDeviceToHost, c->stream);
     if (e != hipSuccess) { ksg_set_error("halo set-up copy failed: %s", hipGetErrorString(e)); rc = KSG_ERR_HIP; }

@@ -1186,8 +1186,10 @@ static int mat_create(ksg_ctx c, int64_t n, int64_t N, int64_t row0, int64_t nc,
     const int64_t onz = (int64_t)o_ci.size();
     /* (KSG_GHOST_SORT=1 takes the other branch whatever the sizes, for tests) */
     const char *gs = getenv("KSG_GHOST_SORT");
-    if (!(gs && gs[0] == '1') && NC <= std::max<int64_t>((int64_t)1 << 27, 4 * onz)) {
-      /* a mark per column of the operator, then the marked columns numbered in order */
+    if (!(gs && gs[0] == '1') && NC <= 16 * onz) {
+      /* a mark per column of the operator, then the marked columns numbered in order -- 4 NC bytes
+       * and a pass over all columns, so only when the ghost entries are a fair share of them (a
+       * stencil's slab has half a million ghost entries among 1.3e8 columns: sorted instead) */
       std::vector<int32_t> num((size_t)NC, -1);
       for (int64_t p = 0; p < onz; p++) num[(size_t)o_ci[(size_t)p]] = 0;
       for (int64_t j = 0; j < NC; j++) if (num[(size_t)j] == 0) { num[(size_t)j] = (int32_t)ghosts.size(); ghosts.push_back((int32_t)j); }
@@ -1222,7 +1224,7 @@ static int mat_create(ksg_ctx c, int64_t n, int64_t N, int64_t row0, int64_t nc,
   std::vector<double> counts((size_t)P * P, 0.0);
   for (int p = 0; p < P; p++) counts[(size_t)c->rank * P + p] = (double)(A->recvoff[p + 1] - A->recvoff[p]);
   rc = ksg_comm_allreduce_host(c, counts.data(), P * P, 0);
-  if (rc) { delete A; return rc; }
+  if (rc) { delete A; return rc; }                     /* a failed collective: nothing to agree on */
   A->sendoff.assign((size_t)P + 1, 0);
   for (int p = 0; p < P; p++) A->sendoff[p + 1] = A->sendoff[p] + (int64_t)counts[(size_t)p * P + c->rank];
   A->nsend = A->sendoff[P];
@@ -1230,8 +1232,8 @@ static int mat_create(ksg_ctx c, int64_t n, int64_t N, int64_t row0, int64_t nc,
   /* ---- tell the owners which of their entries I need (indices travel as doubles) ---- */
   std::vector<double> want((size_t)std::max<int64_t>(A->nghost, 1)), asked((size_t)std::max<int64_t>(A->nsend, 1));
   for (int64_t g = 0; g < A->nghost; g++) want[g] = (double)ghosts[g];
+  /* (a rank-local failure inside the exchange is agreed upon there; what is left is a failed collective) */
   rc = ksg_comm_exchange_host(c, want.data(), A->recvoff.data(), asked.data(), A->sendoff.data());
-  if (rc) { delete A; return rc; }
   std::vector<int32_t> send_idx((size_t)std::max<int64_t>(A->nsend, 1));
   for (int64_t i = 0; i < A->nsend && !rc; i++) {
     const int64_t gidx = (int64_t)asked[i];

@@ -279,3 +279,37 @@ def test_lap3d_256_first_restarts_match_oracle(gpu_ctx):
         assert np.abs(got[i][1] - want[i][1]).max() <= 1e-7 * max(want[i][1].max(), 1e-30) + 1e-12
     eps.destroy()
     A.destroy()
+
+
+def test_lap3d_512_first_restarts_match_oracle(gpu_ctx):
+    """BASELINE configuration 3 at its full size on one GPU -- the 134M-row 7-point Laplacian on the 512^3
+    grid, nev = 32, ncv = 64, default start vector: Ritz values and error estimates after each of the first
+    two restarts against the CPU restatement on its compiled kernels (70 GB of basis on the host, about a
+    minute on 16 threads).  Offsets beyond 2^31 elements, the row-code product at 134M rows and the
+    64 -> 32+ column restart product are all on this path."""
+    from oracle import ckern, eps as oeps
+    from slepc_amd import kseps as K, matgen
+    g, nev, its = 512, 32, 2
+    rp, ci, va = matgen.laplacian3d(g, g, g)
+    n = g ** 3
+    A = K.Mat.create_aij_hip(gpu_ctx, rp, ci, va)
+    eps = K.EPS(gpu_ctx.h)
+    eps.set_operators(A)
+    eps.set_problem_type(K.EPS_HEP)
+    eps.set_dimensions(nev)
+    eps.set_tolerances(0.0, its)
+    got = {}
+    eps.set_monitor(lambda i, nconv, er, ei, ee, nest: got.__setitem__(i, (er[:nev].copy(), ee[:nev].copy(), nest)))
+    eps.solve()
+    eps.destroy()
+    A.destroy()
+    kern = ckern.Kernels(16)
+    want = {}
+    o = oeps.EPS(kern.csr(rp, ci, va).mult, n, hermitian=True, nev=nev, max_it=its, bv_factory=kern.bv,
+                 monitor=lambda i, nconv, er, ei, ee, nv: want.__setitem__(i, (er[:nev].copy(), ee[:nev].copy(), nv)))
+    o.solve()
+    assert sorted(got) == sorted(want) == [1, 2]
+    for i in (1, 2):
+        assert got[i][2] == want[i][2] == 64
+        assert np.abs(got[i][0] - want[i][0]).max() <= 1e-10 * 12.0
+        assert np.abs(got[i][1] - want[i][1]).max() <= 1e-7 * max(want[i][1].max(), 1e-30) + 1e-12

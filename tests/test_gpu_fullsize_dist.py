@@ -1,0 +1,99 @@
+"""The distributed path at the size the scaling run uses, on the one GPU of the test box: eight
+rank processes share the device (collectives over the gloo callback transport) on the real
+512^3 grid of BASELINE configuration 3 and on an R-MAT graph Laplacian, and must report the
+Ritz values of the one-rank run.  This executes the slab partition (64 planes per rank), the
+halo plan with 512^2 ghost entries per neighbour, global rows up to 1.34e8 and the per-rank
+operator forms exactly as `bench.py --gpus 8` builds them; only the transport differs.
+The rows are distributed as the reference distributes them (bvblas.c:252-260: local products,
+one sum over the ranks; ex19.c:70-86 for the operator)."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+PLAIN_ENV = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+
+
+def _bench(args, trace, timeout):
+    out = os.path.join(ROOT, "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    path = os.path.join(out, trace)
+    if os.path.exists(path):
+        os.remove(path)
+    # the ranks' progress lines go to a file next to the trace while the run lasts
+    with open(path + ".log", "wb") as log:
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args + ["--no-cpu-baseline", "--ritz-trace", path],
+                           cwd=ROOT, stdout=subprocess.PIPE, stderr=log, timeout=timeout, env=PLAIN_ENV)
+    with open(path + ".log", "rb") as log:
+        assert r.returncode == 0, log.read().decode(errors="replace")[-3000:]
+    lines = [l for l in r.stdout.decode().splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1, r.stdout.decode()[-2000:]
+    with open(path) as f:
+        return json.loads(lines[0]), json.load(f)
+
+
+def _same_ritz(a, b, restarts, scale, tol=1e-10):
+    for i in restarts:
+        x, y = a["restarts"][str(i)], b["restarts"][str(i)]
+        assert x["nest"] == y["nest"] and x["nconv"] == y["nconv"], (i, x["nconv"], y["nconv"])
+        assert np.abs(np.array(x["re"]) - np.array(y["re"])).max() <= tol * scale, i
+        ex, ey = np.array(x["errest"]), np.array(y["errest"])
+        assert np.abs(ex - ey).max() <= 1e-6 * max(ey.max(), 1e-30) + 1e-12, i
+
+
+def test_lap3d_512_eight_ranks_match_one_rank():
+    """512^3 (134M rows), nev = 32, ncv = 64, two restarts: one rank, and eight ranks sharing the device."""
+    g = 512
+    args = ["--workload", "lap3d", "--grid", str(g), "--steps", "1", "--warmup", "1"]
+    d1, t1 = _bench(["--gpus", "1"] + args, "ritz_lap3d512_1rank.json", 600)
+    d8, t8 = _bench(["--gpus", "8", "--share-device", "--transport", "gloo", "--no-kernel-timing"] + args,
+                    "ritz_lap3d512_8ranks.json", 900)
+    assert d1["config"]["rows_per_gpu"] == g ** 3 and d1["ranks"][0]["ghost_in"] == 0
+    assert d8["n_gpus"] == 8 and d8["scaling"] == "strong" and d8["config"]["transport"] == "gloo"
+    assert d8["config"]["workload"] == d1["config"]["workload"]
+    assert d8["config"]["rows_per_gpu"] == 64 * g * g
+    ranks = sorted(d8["ranks"], key=lambda r: r["rank"])
+    assert [r["rank"] for r in ranks] == list(range(8))
+    for r in ranks:
+        assert r["rows"] == 64 * g * g
+        inner = 0 < r["rank"] < 7
+        assert r["ghost_in"] == (2 if inner else 1) * g * g               # one 512^2 plane of x per neighbour
+        assert r["nnz"] == 7 * 64 * g * g - 2 * 64 * 2 * g - (0 if inner else g * g)
+    assert sum(r["nnz"] for r in ranks) == d1["config"]["nnz_per_gpu"] == 7 * g ** 3 - 6 * g * g
+    assert d8["config"]["spmv_variant"].startswith("row codes") and d1["config"]["spmv_variant"].startswith("row codes")
+    assert sorted(t1["restarts"]) == sorted(t8["restarts"]) == ["1", "2"]
+    _same_ritz(t8, t1, (1, 2), 12.0)
+    # the one-rank values of an earlier run on this hardware (committed fixture): the product is deterministic
+    with open(os.path.join(GOLD, "lap3d512_ritz_first_restarts.json")) as f:
+        gold = json.load(f)
+    assert gold["workload"] == t1["workload"]
+    _same_ritz(t1, gold, (1, 2), 12.0)
+
+
+def test_rmat_22_eight_ranks_match_one_rank():
+    """R-MAT scale 22 graph Laplacian (4.2M rows, 6.9e7 entries) solved to 1e-10 on one rank and on eight
+    ranks sharing the device, every rank with the forms the library chooses for its blocks."""
+    args = ["--workload", "rmat", "--grid", "22", "--to-convergence", "--tol", "1e-10"]
+    d1, t1 = _bench(["--gpus", "1"] + args, "ritz_rmat22_1rank.json", 600)
+    d8, t8 = _bench(["--gpus", "8", "--share-device", "--transport", "gloo", "--no-kernel-timing"] + args,
+                    "ritz_rmat22_8ranks.json", 900)
+    assert d8["n_gpus"] == 8 and sum(r["rows"] for r in d8["ranks"]) == 1 << 22
+    assert sum(r["nnz"] for r in d8["ranks"]) == d1["config"]["nnz_per_gpu"]
+    assert all(r["ghost_in"] > 0 for r in d8["ranks"])
+    assert d1["solver_state"]["nconv"] >= 32 and d8["solver_state"]["nconv"] >= 32
+    assert abs(d1["solver_state"]["restarts"] - d8["solver_state"]["restarts"]) <= 1
+    e1 = np.array([v[0] for v in t1["eigenvalues"]])
+    e8 = np.array([v[0] for v in t8["eigenvalues"]])
+    assert len(e1) == len(e8) == 32
+    assert np.abs(e1 - e8).max() <= 1e-10 * np.abs(e1).max()
+    assert np.all(np.abs(e1 - e8) <= 1e-10 * np.abs(e1))
+    both = sorted(set(t1["restarts"]) & set(t8["restarts"]), key=int)[:3]
+    _same_ritz(t8, t1, [int(i) for i in both], float(np.abs(e1).max()))
+    assert d1["max_relative_residual"] < 1e-9 and d8["max_relative_residual"] < 1e-9
