@@ -80,13 +80,6 @@ void *ksg_ctx_stream(ksg_ctx ctx);
  * its most referenced columns: each product gathers them into a dense array that stays in cache,
  * and the matrix entries of those columns index it instead of x.  Same values, same order
  * of sums: results are bit for bit those without the packing.
- * KSG_OPT_COL_GROUPS (default 0 = by size; 1 = never; G >= 2 = always G groups): a power-law
- * operator (the same test as for the packing) created afterwards on one rank, whose x is 256 MiB
- * or more, is held as groups of consecutive columns of at most 128 MiB of x each; a product
- * multiplies the groups one after the other (the first stores y, the others add into the rows
- * they touch), so that at any time the gathers fall into one slice of x whose most referenced
- * part the L2s can hold.  A row's sum is then formed group by group: the same products added
- * in another order.
  * KSG_OPT_BINS (default 0 = by size; 1 = never; 2 = always): a block of a power-law operator
  * created afterwards -- the local block of a rank, and the ghost block of a distributed operator,
  * whose x is the ghost buffer -- (x of 32 MiB or more when chosen by size) keeps the entries of its
@@ -94,11 +87,11 @@ void *ksg_ctx_stream(ksg_ctx ctx);
  * and writes the products in the order of the row blocks, a second pass sums them per row block in
  * LDS and adds the diagonal term; the remaining entries stay a CSR over the rows they touch and
  * are added afterwards.  The gathers from a large x, one memory request each, become two streams.
- * Takes precedence over the column groups.  A row's sum is formed from its binned entries by
+ * A row's sum is formed from its binned entries by
  * column block, its diagonal entry, and its remaining entries: the same products added in another
  * order, the same order in every product. */
 enum { KSG_OPT_FUSE_DOTS = 1, KSG_OPT_DOT_GRID = 2, KSG_OPT_MV_GRID = 3, KSG_OPT_LAZY_UPDATE = 4, KSG_OPT_HOT_COLS = 5,
-       KSG_OPT_COL_GROUPS = 6, KSG_OPT_BINS = 7 };
+       KSG_OPT_BINS = 7 };
 int ksg_ctx_set_option(ksg_ctx ctx, int option, int value);
 const char *ksg_last_error(void);
 

@@ -33,8 +33,8 @@ typedef struct { ksg_ctx ctx; ksg_bv bv; } BV_HIP;
 
 #define KSG(call) do { if ((call)) SETERRQ1(PETSC_COMM_SELF,PETSC_ERR_LIB,"libksgpu: %s",ksg_last_error()); } while (0)
 /* SLEPc's interface layer owns nc, l and k (svec reads them from the BV at every op) */
-#define SYNC(bv) do { KSG(ksg_bv_set_num_constraints(((BV_HIP*)(bv)->data)->bv,(int)(bv)->nc)); \
-                      KSG(ksg_bv_set_active(((BV_HIP*)(bv)->data)->bv,(int)(bv)->l,(int)(bv)->k)); } while (0)
+#define SYNC(B_) do { KSG(ksg_bv_set_num_constraints(((BV_HIP*)(B_)->data)->bv,(int)(B_)->nc)); \
+                      KSG(ksg_bv_set_active(((BV_HIP*)(B_)->data)->bv,(int)(B_)->l,(int)(B_)->k)); } while (0)
 
 static PetscErrorCode BVDotVec_HIP(BV X,Vec y,PetscScalar *q)
 {

@@ -93,8 +93,12 @@ PETSC_EXTERN PetscErrorCode KSGGetContext(MPI_Comm comm,ksg_ctx *ctx)
   if (flg) { *ctx = (ksg_ctx)attr; PetscFunctionReturn(0); }
   ierr = MPI_Comm_rank(comm,&rank);CHKERRQ(ierr);
   ierr = MPI_Comm_size(comm,&size);CHKERRQ(ierr);
-  /* one GPU per rank of a node: the rank within the shared-memory node picks the device */
-  ierr = MPI_Comm_split_type(PETSC_COMM_WORLD,MPI_COMM_TYPE_SHARED,0,MPI_INFO_NULL,&local);CHKERRQ(ierr);
+  /* one GPU per rank of a node: the rank within the shared-memory node picks the device.  The
+     split is collective over the communicator it is made from, so it is made from `comm`, whose
+     ranks are the ones that call this together (a split of the world communicator would wait for
+     ranks outside a sub-communicator for ever); ranks that share a node under `comm` get
+     consecutive devices. */
+  ierr = MPI_Comm_split_type(comm,MPI_COMM_TYPE_SHARED,0,MPI_INFO_NULL,&local);CHKERRQ(ierr);
   ierr = MPI_Comm_rank(local,&lrank);CHKERRQ(ierr);
   ierr = MPI_Comm_free(&local);CHKERRQ(ierr);
   KSG(ksg_ctx_create((int)lrank,&c));
@@ -190,9 +194,10 @@ PETSC_EXTERN PetscErrorCode VecHIPGetArray(Vec v,PetscScalar **a)
 PETSC_EXTERN PetscErrorCode VecHIPRestoreArray(Vec v,PetscScalar **a)
 {
   PetscErrorCode ierr;
-  Vec_HIP        *h = (Vec_HIP*)v->data;
+  Vec_HIP        *h;
 
   PetscFunctionBegin;
+  ierr = VecHIPCheck(v,&h);CHKERRQ(ierr);
   KSG(ksg_ctx_touch(h->ctx));
   ierr = PetscObjectStateIncrease((PetscObject)v);CHKERRQ(ierr);
   if (a) *a = NULL;

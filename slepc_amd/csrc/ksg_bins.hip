@@ -31,8 +31,7 @@
  * KSG_BINS_E (entries per row block; unless set, 3e-4 of the block's entries as a power of two
  * between 65536 and 524288), KSG_BINS_T (fewest entries of a binned cell), KSG_BINS_TASK_GROUPS
  * (groups of 64 entries per expand workgroup; unless set, up to 8192), KSG_BINS_THREADS (threads
- * of an expand workgroup), KSG_BINS_LEVELS=2 (a second level for the entries of thin cells, with
- * KSG_BINS_H2 rows per row block). */
+ * of an expand workgroup). */
 #include <algorithm>
 #include <numeric>
 #include <stdlib.h>
@@ -334,10 +333,7 @@ void ksg_bins_free(ksg_bins *B) {
   if (B->long_first) hipFree(B->long_first);
   if (B->piece_row) hipFree(B->piece_row);
   if (B->part) hipFree(B->part);
-  if (B->xe && !B->xe_shared) hipFree(B->xe);
-  if (B->next) { ksg_bins_free(B->next); delete B->next; }
-  if (B->next_rows_blk && B->next_rows_blk != B->next_rows_y) hipFree(B->next_rows_blk);
-  if (B->next_rows_y) hipFree(B->next_rows_y);
+  if (B->xe) hipFree(B->xe);
   memset(B, 0, sizeof(*B));
 }
 
@@ -825,26 +821,11 @@ static void bins_emulate(const bins_host &B, const double *x, int64_t ncols, dou
   }
 }
 
-/* The binned part of a block in one or two levels.  Level 1 as bins_build_host makes it (KSG_BINS_H
- * rows per row block, 2048 unless set).  The entries its cells were too thin for form a CSR over the
- * rows that have such entries; with KSG_BINS_LEVELS=2 that CSR is binned again with four times the
- * rows per row block (KSG_BINS_H2, at most 8192): counted in rows of the block its cells are some
- * twenty times as large, so most of those entries find a well filled cell after all.  Off unless
- * asked for: at R-MAT scale 26 the 57.8M entries left after level 1 (5 %) take 1.03 of the product's
- * 6.55 ms through the tile kernel (56 G entries/s, every one a gather beyond L2); a second level
- * bins 54.8M of them, but its reduce pass needs 64 KiB of sums per wave -- two waves per CU -- and
- * runs at 104 G products/s against 495 for level 1: 0.32 ms expand + 0.62 ms reduce + 0.10 ms for
- * the rest, 6.53 ms in all (6.51 with 4096 rows per block; profiles/r02_spmv_rmat_binned.txt). */
-struct bins_levels {
-  bins_host L1, L2;
-  std::vector<int32_t> rows2;      /* the block row of every row of level 2 */
-};
-
-static void bins_build_levels(bins_levels *BL, int64_t nrows, int64_t ncols, const int64_t *rowptr, const int32_t *colidx,
-                              const double *val, bool has_diag, int64_t dshift, std::vector<int32_t> &lrows, std::vector<int64_t> &lrp,
-                              std::vector<int32_t> &lci, std::vector<double> &lva, int maxW = 16384) {
-  BL->L2 = bins_host();
-  BL->rows2.clear();
+/* The binned part of a block with the sizes of the row blocks chosen: KSG_BINS_H rows (2048 unless
+ * set) and E entries at most. */
+static void bins_build_sized(bins_host *B, int64_t nrows, int64_t ncols, const int64_t *rowptr, const int32_t *colidx,
+                             const double *val, bool has_diag, int64_t dshift, std::vector<int32_t> &lrows, std::vector<int64_t> &lrp,
+                             std::vector<int32_t> &lci, std::vector<double> &lva, int maxW = 16384) {
   const int H = env_int("KSG_BINS_H", 2048);
   /* Most entries per row block.  Where rows are long (the hub rows of a power-law operator) it is E
    * and not H that ends a row block, and the fewer rows a block has, the thinner its cells: a larger
@@ -859,30 +840,7 @@ static void bins_build_levels(bins_levels *BL, int64_t nrows, int64_t ncols, con
     E = 65536;
     while (E < 524288 && (double)(2 * E) <= 3e-4 * (double)rowptr[nrows]) E *= 2;
   }
-  bins_build_host(&BL->L1, nrows, ncols, rowptr, colidx, val, has_diag, dshift, lrows, lrp, lci, lva, H, E, maxW);
-  if (!BL->L1.nent || lrows.empty()) return;
-  const int levels = env_int("KSG_BINS_LEVELS", 0);
-  const int H2 = std::min(env_int("KSG_BINS_H2", 4 * BL->L1.H), 8192);
-  const int64_t left = lrp.back();
-  if (levels != 2 || H2 <= BL->L1.H || left == 0) return;
-  std::vector<int32_t> rows3, ci3;
-  std::vector<int64_t> rp3;
-  std::vector<double> va3;
-  bins_build_host(&BL->L2, (int64_t)lrows.size(), ncols, lrp.data(), lci.data(), lva.data(), false, 0, rows3, rp3, ci3, va3, H2,
-                  4 * E, maxW);
-  if (!BL->L2.nent) return;
-  BL->rows2 = lrows;
-  for (size_t i = 0; i < rows3.size(); i++) rows3[i] = lrows[(size_t)rows3[i]];
-  lrows.swap(rows3); lrp.swap(rp3); lci.swap(ci3); lva.swap(va3);
-}
-
-/* y = A x of both levels on the host, the way the device forms it: level 1 stores its rows, level 2 is added. */
-static void bins_emulate_levels(const bins_levels &BL, const double *x, int64_t ncols, double *y) {
-  bins_emulate(BL.L1, x, ncols, y);
-  if (!BL.L2.nent) return;
-  std::vector<double> y2((size_t)BL.L2.nrows, 0.0);
-  bins_emulate(BL.L2, x, ncols, y2.data());
-  for (int64_t i = 0; i < BL.L2.nrows; i++) y[BL.rows2[(size_t)i]] += y2[(size_t)i];
+  bins_build_host(B, nrows, ncols, rowptr, colidx, val, has_diag, dshift, lrows, lrp, lci, lva, H, E, maxW);
 }
 
 /* Host-side check of the binned layout, no device needed: y = A x for the CSR block given, formed
@@ -902,12 +860,11 @@ extern "C" int ksg_bins_host_check(int64_t nrows, int64_t ncols, const int64_t *
       if (colidx[p] < 0 || (int64_t)colidx[p] >= ncols)
         KSG_FAIL(KSG_ERR_ARG, "ksg_bins_host_check: column %d of row %lld outside [0,%lld)", colidx[p], (long long)r, (long long)ncols);
   }
-  bins_levels BL;
+  bins_host B;
   std::vector<int32_t> lrows, lci;
   std::vector<int64_t> lrp;
   std::vector<double> lva;
-  bins_build_levels(&BL, nrows, ncols, rowptr, colidx, val, has_diag != 0, dshift, lrows, lrp, lci, lva);
-  const bins_host &B = BL.L1;
+  bins_build_sized(&B, nrows, ncols, rowptr, colidx, val, has_diag != 0, dshift, lrows, lrp, lci, lva);
   if (!B.nent) {
     for (int64_t r = 0; r < nrows; r++) {
       double s = 0.0;
@@ -915,7 +872,7 @@ extern "C" int ksg_bins_host_check(int64_t nrows, int64_t ncols, const int64_t *
       y[r] = s;
     }
   } else {
-    bins_emulate_levels(BL, x, ncols, y);
+    bins_emulate(B, x, ncols, y);
     for (size_t i = 0; i < lrows.size(); i++) {
       double s = 0.0;
       for (int64_t p = lrp[i]; p < lrp[i + 1]; p++) s += lva[(size_t)p] * x[lci[(size_t)p]];
@@ -923,15 +880,14 @@ extern "C" int ksg_bins_host_check(int64_t nrows, int64_t ncols, const int64_t *
     }
   }
   if (info) {
-    info[0] = B.nreal + BL.L2.nreal; info[1] = B.nseg + BL.L2.nseg; info[2] = B.nbins + BL.L2.nbins; info[3] = B.vmode;
+    info[0] = B.nreal; info[1] = B.nseg; info[2] = B.nbins; info[3] = B.vmode;
     info[4] = B.nent ? (int64_t)lci.size() : rowptr[nrows]; info[5] = B.fold_diag ? 1 : 0;
   }
   return KSG_OK;
 }
 
-/* One level on the device.  rowmap (may be NULL): the rows of y the level's rows stand for;
- * shared_xe: the product array of the level above, used instead of one of its own. */
-static int bins_to_device(ksg_ctx c, ksg_bins *B, const bins_host &Hb, const int32_t *rowmap, double *shared_xe) {
+/* The binned part on the device.  rowmap (may be NULL): the rows of y the block's rows stand for. */
+static int bins_to_device(ksg_ctx c, ksg_bins *B, const bins_host &Hb, const int32_t *rowmap) {
   B->threads = env_int("KSG_BINS_THREADS", 1024) / 64 * 64;
   if (B->threads < 64) B->threads = 64;
   if (B->threads > BINS_P1_THREADS) B->threads = BINS_P1_THREADS;
@@ -961,11 +917,8 @@ static int bins_to_device(ksg_ctx c, ksg_bins *B, const bins_host &Hb, const int
     hipError_t e2 = hipMalloc((void **)&B->part, (size_t)B->npieces * sizeof(double));
     if (e2 != hipSuccess) KSG_FAIL(KSG_ERR_MEM, "binned operator: sums of the pieces of long rows: %s", hipGetErrorString(e2));
   }
-  if (shared_xe) { B->xe = shared_xe; B->xe_shared = 1; }
-  else {
-    hipError_t e = hipMalloc((void **)&B->xe, (size_t)(B->nent + 64) * sizeof(double));
-    if (e != hipSuccess) KSG_FAIL(KSG_ERR_MEM, "binned operator: %zu bytes of products: %s", (size_t)(B->nent + 64) * sizeof(double), hipGetErrorString(e));
-  }
+  hipError_t e = hipMalloc((void **)&B->xe, (size_t)(B->nent + 64) * sizeof(double));
+  if (e != hipSuccess) KSG_FAIL(KSG_ERR_MEM, "binned operator: %zu bytes of products: %s", (size_t)(B->nent + 64) * sizeof(double), hipGetErrorString(e));
   return KSG_OK;
 }
 
@@ -1008,24 +961,10 @@ int ksg_bins_build(ksg_ctx c, ksg_bins *B, int64_t nrows, int64_t ncols, const i
   int maxW = 0;
   KSG_CHK(bins_device_max_w(c, &maxW));
   if (!maxW) return KSG_OK;                               /* too little LDS for a slice worth having: the block stays a CSR */
-  bins_levels BL;
-  bins_build_levels(&BL, nrows, ncols, rowptr, colidx, val, has_diag, dshift, lrows, lrp, lci, lva, maxW);
-  if (!BL.L1.nent) return KSG_OK;
-  int rc = bins_to_device(c, B, BL.L1, rowmap, NULL);
-  { bins_host().col16.swap(BL.L1.col16); bins_host().rowloc.swap(BL.L1.rowloc); }    /* the host copy of level 1 is no longer needed */
-  if (!rc && BL.L2.nent) {
-    B->next = new (std::nothrow) ksg_bins;
-    if (!B->next) { ksg_set_error("binned operator: out of host memory"); rc = KSG_ERR_MEM; }
-    else {
-      memset(B->next, 0, sizeof(*B->next));
-      std::vector<int32_t> ry(BL.rows2);
-      if (rowmap) for (size_t i = 0; i < ry.size(); i++) ry[i] = rowmap[ry[i]];
-      rc = bins_upload(&B->next_rows_y, ry.data(), ry.size());
-      if (!rc && rowmap) rc = bins_upload(&B->next_rows_blk, BL.rows2.data(), BL.rows2.size());
-      else if (!rc) B->next_rows_blk = B->next_rows_y;
-      if (!rc) rc = bins_to_device(c, B->next, BL.L2, ry.data(), BL.L2.nent <= B->nent ? B->xe : NULL);
-    }
-  }
+  bins_host Hb;
+  bins_build_sized(&Hb, nrows, ncols, rowptr, colidx, val, has_diag, dshift, lrows, lrp, lci, lva, maxW);
+  if (!Hb.nent) return KSG_OK;
+  const int rc = bins_to_device(c, B, Hb, rowmap);
   if (rc) {
     /* an upload failed: nothing of the binned form is kept, the caller holds the block as a CSR (and
      * reports the shortage itself if that does not fit either) */
@@ -1052,7 +991,6 @@ int ksg_bins_mult(const ksg_bins *B, const double *x, int64_t ncols, double *y, 
     hipLaunchKernelGGL(k_bins_long_rows, dim3((unsigned)((B->nlong + KSG_BLOCK - 1) / KSG_BLOCK)), dim3(KSG_BLOCK), 0, st, B->long_rows,
                        B->long_first, (int)B->nlong, B->part, y);
   KSG_HIP(hipGetLastError());
-  if (B->next) KSG_CHK(ksg_bins_mult(B->next, x, ncols, y, st, B->next_rows_y));
   return KSG_OK;
 }
 
@@ -1064,8 +1002,7 @@ double ksg_bins_bytes(const ksg_bins *B) {
   const double vb = B->vmode == 2 ? 8.0 : B->vmode == 1 ? 1.0 : 0.0;
   return (2.0 + vb) * (double)B->nent1 + 8.0 * (double)B->nseg + 4.0 * (double)(B->nent1 / 64) +
          (8.0 * B->W + 24.0) * (double)B->ntasks + 8.0 * (double)B->nent +
-         10.0 * (double)B->nent + 24.0 * (double)B->nbins + (B->dv ? 24.0 : 8.0) * (double)B->nrows +
-         (B->next ? ksg_bins_bytes(B->next) + 12.0 * (double)B->next->nrows : 0.0);   /* level 2 reads and writes y through its row list */
+         10.0 * (double)B->nent + 24.0 * (double)B->nbins + (B->dv ? 24.0 : 8.0) * (double)B->nrows;
 }
 
 /* The binned entries and the folded diagonal back on the host as (row, column, value) triplets,
@@ -1120,12 +1057,5 @@ int ksg_bins_to_host(const ksg_bins *B, std::vector<int32_t> &rows, std::vector<
     }
   }
   for (int64_t r = 0; r < (B->dv ? B->nrows : 0); r++) { rows.push_back((int32_t)r); cols.push_back((int32_t)(r + B->dshift)); vals.push_back(dv[(size_t)r]); }
-  if (B->next) {
-    std::vector<int32_t> r2, c2, map((size_t)B->next->nrows);
-    std::vector<double> v2;
-    KSG_CHK(ksg_bins_to_host(B->next, r2, c2, v2));
-    KSG_HIP(hipMemcpy(map.data(), B->next_rows_blk, map.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
-    for (size_t i = 0; i < r2.size(); i++) { rows.push_back(map[(size_t)r2[i]]); cols.push_back(c2[i]); vals.push_back(v2[i]); }
-  }
   return KSG_OK;
 }

@@ -59,7 +59,6 @@ extern "C" int ksg_ctx_create(int device, ksg_ctx *out) {
   c->fuse_dots = 1;
   c->lazy_update = 1;
   c->hot_cols = 1048576;
-  { const char *e = getenv("KSG_SPMV_COLGROUPS"); c->col_groups = e ? atoi(e) : 0; if (c->col_groups < 0 || c->col_groups > 4096) c->col_groups = 0; }
   { const char *e = getenv("KSG_SPMV_BINS"); c->bins = e ? atoi(e) : 0; if (c->bins < 0 || c->bins > 2) c->bins = 0; }
   c->pend.active = false;
   c->dot_grid = KSG_DOT_GRID;
@@ -104,10 +103,6 @@ extern "C" int ksg_ctx_set_option(ksg_ctx c, int option, int value) {
     case KSG_OPT_HOT_COLS:
       if (value < 0) KSG_FAIL(KSG_ERR_ARG, "ksg_ctx_set_option: negative size");
       c->hot_cols = value;
-      return KSG_OK;
-    case KSG_OPT_COL_GROUPS:
-      if (value < 0 || value > 4096) KSG_FAIL(KSG_ERR_ARG, "ksg_ctx_set_option: %d column groups", value);
-      c->col_groups = value;
       return KSG_OK;
     case KSG_OPT_BINS:
       if (value < 0 || value > 2) KSG_FAIL(KSG_ERR_ARG, "ksg_ctx_set_option: binned form %d (0: by size, 1: never, 2: always)", value);

@@ -23,6 +23,15 @@
 #define KSG_DOT_GRID   256          /* row workgroups of the read-only reductions   */
 #define KSG_MV_GRID    1024         /* row workgroups of the GEMV (read + write)    */
 
+/* row tiles of the CSR product kernel */
+#ifndef KSG_TILE_NNZ
+#define KSG_TILE_NNZ  2048     /* products held in LDS per workgroup (16 KiB: 8 workgroups per CU) */
+#endif
+#ifndef KSG_TILE_ROWS
+#define KSG_TILE_ROWS 512      /* rows per stream tile: a multiple of the workgroup size */
+#endif
+#define KSG_PC_ROWS    256     /* rows per workgroup step of the row-code kernel */
+
 void ksg_set_error(const char *fmt, ...);
 
 #define KSG_FAIL(code, ...) do { ksg_set_error(__VA_ARGS__); return (code); } while (0)
@@ -164,7 +173,6 @@ struct ksg_ctx_s {
   ksg_pending pend;
   int lazy_update;           /* 0: never defer the store of a Gram-Schmidt update */
   int hot_cols;              /* most x entries a new operator may keep packed (0: none) */
-  int col_groups;            /* column groups of a new power-law operator: 0 = chosen by size, 1 = none, >= 2 forced */
   int bins;                  /* binned form of a new power-law operator: 0 = chosen by size, 1 = never, 2 = always */
   /* communicator */
   int comm_kind, rank, nranks, cb_on_device;
@@ -215,13 +223,11 @@ struct ksg_csr_dev {
   double *pc_val;    /* 256 values */
 };
 
-/* One column group of a power-law operator: the entries whose column lies in
- * [col_first, col_first + ncols), as a CSR over only the rows that have such entries, columns
- * relative to col_first (packed hot columns: ncols + slot).  Group 0 lives in ksg_mat_s::diag
- * over all rows. */
-struct ksg_colgroup {
+/* What the binned part of a power-law block leaves: the entries of thin cells, as a CSR over only
+ * the rows that have such entries (packed hot columns: ncols + slot). */
+struct ksg_rest {
   ksg_csr_dev blk;
-  int64_t col_first, ncols, nrows;
+  int64_t ncols, nrows;
   int32_t *d_rows;           /* local row of every row of blk                  */
   int64_t nhot;
   std::vector<int32_t> hot_cols;
@@ -260,14 +266,6 @@ struct ksg_bins {
   double *part;              /* npieces sums, added to their rows after the reduce pass             */
   double *dv;                /* nrows: the block's diagonal, folded into the reduce pass (NULL: the block has none, or not one per row) */
   double *xe;                /* nent + 64 products                                               */
-  /* second level: the entries the cells of this level were too thin for, binned again over the
-   * rows that have such entries with four times the rows per row block (cells five to twenty
-   * times as large); its sums are added to y after this level has stored its rows, and it shares
-   * this level's product array */
-  ksg_bins *next;
-  int32_t *next_rows_y;      /* next->nrows: the row of y each of its rows is added to             */
-  int32_t *next_rows_blk;    /* the same in rows of this block (== next_rows_y without a row list) */
-  int xe_shared;             /* xe belongs to the level above                                      */
 };
 
 struct ksg_mat_s {
@@ -276,12 +274,11 @@ struct ksg_mat_s {
   int64_t nc, NC, col0;      /* column layout: x has nc local entries, columns [col0,col0+nc) are local */
   std::vector<int64_t> cstarts;  /* first column of every rank, nranks+1 (empty with one rank) */
   std::vector<int32_t> ghosts;   /* global column of every ghost-buffer slot */
-  ksg_csr_dev diag;          /* columns local (col - col0); entries of a packed column: diag_ncols + its slot */
-  int64_t diag_ncols;        /* nc, or the width of the first column group when there are several */
-  std::vector<ksg_colgroup> cgs;   /* the column groups after the first (one rank, power-law operators) */
-  ksg_bins bins;             /* the binned part of the local block (power-law operators); what is left of the block is then cgs[0], diag is empty */
+  ksg_csr_dev diag;          /* columns local (col - col0); entries of a packed column: nc + its slot */
+  ksg_bins bins;             /* the binned part of the local block (power-law operators); diag is then empty */
+  std::vector<ksg_rest> rest;      /* what the binned part left of the local block (none or one) */
   ksg_bins gbins;            /* the same for the ghost block: its x is the ghost buffer, its rows the list o_rows */
-  std::vector<ksg_colgroup> gcgs;  /* what is left of a binned ghost block (d_rows: local rows of y) */
+  std::vector<ksg_rest> grest;     /* what is left of a binned ghost block (d_rows: local rows of y) */
   /* packed copy of the x entries of the most referenced columns (power-law operators) */
   int64_t nhot;
   std::vector<int32_t> hot_cols; /* local column of every slot                  */

@@ -151,7 +151,6 @@ OPT_DOT_GRID = 2
 OPT_MV_GRID = 3
 OPT_LAZY_UPDATE = 4
 OPT_HOT_COLS = 5
-OPT_COL_GROUPS = 6
 OPT_BINS = 7
 
 

@@ -111,8 +111,7 @@ def test_binned_layout_random_blocks():
         x = rng.standard_normal(nc)
         env = {"KSG_BINS_W": int(rng.choice([64, 128, 256, 1024])), "KSG_BINS_H": int(rng.choice([64, 100, 256])),
                "KSG_BINS_E": int(rng.choice([40, 200, 5000])), "KSG_BINS_T": int(rng.choice([1, 2, 3])),
-               "KSG_BINS_TASK_GROUPS": int(rng.choice([1, 2, 9])), "KSG_BINS_LEVELS": int(rng.choice([1, 2, 2])),
-               "KSG_BINS_H2": int(rng.choice([128, 300, 8192]))}
+               "KSG_BINS_TASK_GROUPS": int(rng.choice([1, 2, 9]))}
         y, info = _with_env(env, lambda: ksgpu.bins_host_check(rp, cols.astype(np.int32), vals, x, ncols=nc, has_diag=(nc == n)))
         M = csr_matrix((vals, cols, rp), shape=(n, nc))
         assert np.all(np.abs(y - M @ x) <= 1e-13 * (np.abs(M) @ np.abs(x) + 1e-300)), (trial, env, info)
@@ -148,27 +147,3 @@ def test_binned_layout_same_for_any_thread_count(values):
     for y, info in out[1:]:
         assert info == out[0][1]
         assert np.array_equal(y, out[0][0])
-
-
-@pytest.mark.parametrize("values", ["laplacian", "any"])
-def test_binned_layout_second_level(values):
-    """The entries that the cells of the first level are too thin for are binned again over the rows
-    that have them, with larger row blocks (KSG_BINS_LEVELS=2; off by default): more entries end up
-    binned than with one level, the rest shrinks accordingly, and the product is A x."""
-    rp, ci, va = mg.rmat_laplacian(14, 6, seed=21)
-    n = len(rp) - 1
-    rng = np.random.default_rng(8)
-    if values == "any":
-        va = rng.standard_normal(len(va))
-    x = rng.standard_normal(n)
-    base = {"KSG_BINS_W": 512, "KSG_BINS_H": 64, "KSG_BINS_E": 2000, "KSG_BINS_T": 4}
-    y1, i1 = _with_env(dict(base, KSG_BINS_LEVELS=1), lambda: ksgpu.bins_host_check(rp, ci, va, x))
-    y2, i2 = _with_env(dict(base, KSG_BINS_LEVELS=2, KSG_BINS_H2=1024), lambda: ksgpu.bins_host_check(rp, ci, va, x))
-    y3, i3 = _with_env(base, lambda: ksgpu.bins_host_check(rp, ci, va, x))                              # one level unless asked for
-    M = csr_matrix((va, ci, rp), shape=(n, n))
-    assert i1["binned"] > 0 and i1 == i3 and np.array_equal(y1, y3)
-    assert i2["binned"] > i1["binned"] + (i1["csr_entries"] // 4), (i1, i2)
-    assert i2["binned"] + i2["csr_entries"] == i1["binned"] + i1["csr_entries"]
-    assert i2["row_blocks"] > i1["row_blocks"] and i2["runs"] > i1["runs"]
-    for y in (y1, y2):
-        assert np.all(np.abs(y - M @ x) <= 1e-14 * (np.abs(M) @ np.abs(x) + 1e-300))

@@ -68,19 +68,15 @@ def test_ghost_columns_numbered_either_way():
     assert a["values"] == b["values"]
 
 
-@pytest.mark.parametrize("ranks,levels", [(2, 1), (3, 1), (8, 1), (3, 2)])
-def test_rmat_binned_blocks_match_single(ranks, levels):
+@pytest.mark.parametrize("ranks", [2, 3, 8])
+def test_rmat_binned_blocks_match_single(ranks):
     """The same split with both blocks of every rank in the binned form (KSG_OPT_BINS forced through
     the environment, small cells): the ghost block's x is the ghost buffer and its sums are added into
-    the rows it touches; eigenvalues, the product and the rows read back against the plain single rank.
-    With two levels the second one adds through the composed row lists."""
+    the rows it touches; eigenvalues, the product and the rows read back against the plain single rank."""
     import re
     from scipy.sparse import csr_matrix
     from slepc_amd import matgen as mg
-    env = {"KSG_SPMV_BINS": "2", "KSG_BINS_W": "512", "KSG_BINS_H": "128", "KSG_BINS_E": "1024", "KSG_BINS_T": "2", "KS_CHECK_CSR": "1",
-           "KSG_BINS_LEVELS": str(levels), "KSG_BINS_H2": "1024"}   # levels = 2: what the thin cells leave is binned again (both blocks)
-    if levels == 2:
-        env["KSG_BINS_T"] = "4"
+    env = {"KSG_SPMV_BINS": "2", "KSG_BINS_W": "512", "KSG_BINS_H": "128", "KSG_BINS_E": "1024", "KSG_BINS_T": "2", "KS_CHECK_CSR": "1"}
     one = run_ranks("gpu", "rmat_nnz", 1)
     many = run_ranks("gpu", "rmat_nnz", ranks, extra_env=env)
     assert one["reason"] == many["reason"] == 1 and many["csr_ok"]

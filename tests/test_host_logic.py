@@ -569,3 +569,16 @@ def test_rmat_generator_structure_and_partition():
         rq, cq, vq = mg.rmat_laplacian(scale, row0=a, row1=b)
         assert np.array_equal(rq, rp[a:b + 1] - rp[a])
         assert np.array_equal(cq, ci[rp[a]:rp[b]]) and np.array_equal(vq, va[rp[a]:rp[b]])
+
+
+def test_shim_files_parse():
+    """The PETSc-side files of the drop-in cannot be built here (no PETSc): gcc at least parses them
+    against declarations-only stand-ins and finds every identifier they use declared (`make -C shim check`)."""
+    import os
+    import shutil
+    import subprocess
+    if not shutil.which("gcc") and not shutil.which("cc"):
+        pytest.skip("no C compiler")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run(["make", "-C", os.path.join(root, "shim"), "check"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    assert r.returncode == 0, r.stdout.decode()[-3000:]

@@ -31,7 +31,7 @@ def main():
     ctx.vec_fill_hash(x, n, 0, 5)
     y0 = None
     for setting in settings:
-        for k in ("W", "H", "E", "T", "TASK_GROUPS", "THREADS", "LEVELS", "H2"):
+        for k in ("W", "H", "E", "T", "TASK_GROUPS", "THREADS"):
             os.environ.pop("KSG_BINS_" + k, None)
         if setting == "plain":
             ctx.set_option(ksgpu.OPT_BINS, 1)
