@@ -31,7 +31,7 @@
  * KSG_BINS_E (entries per row block; unless set, 3e-4 of the block's entries as a power of two
  * between 65536 and 524288), KSG_BINS_T (fewest entries of a binned cell), KSG_BINS_TASK_GROUPS
  * (groups of 64 entries per expand workgroup; unless set, up to 8192), KSG_BINS_THREADS (threads
- * of an expand workgroup). */
+ * of an expand workgroup), KSG_BINS_ALIGN (slots a run is filled up to a multiple of; 8). */
 #include <algorithm>
 #include <numeric>
 #include <stdlib.h>
@@ -40,53 +40,107 @@
 
 #define BINS_P1_THREADS 1024    /* most threads of an expand workgroup (launch bound); KSG_BINS_THREADS sets the actual number */
 #ifndef BINS_P1_UNROLL
-#define BINS_P1_UNROLL  16
+#define BINS_P1_UNROLL  8      /* groups of 64 entries a wave of the expand pass has in flight: 16 spill registers at 1024 threads */
 #endif
 #ifndef BINS_P2_UNROLL
 #define BINS_P2_UNROLL  16
 #endif
 
-/* One step of a wave of the expand pass: BINS_P1_UNROLL groups of 64 entries from group g on.
- * FULL: all of them lie before g1 (no guards).  VM = 0: every binned entry has the same value
- * `vc`; 1: one-byte indices into vtab; 2: the 8-byte values themselves. */
+/* data-parallel-primitive move inside a row of 16 lanes: the value of the lane N places below;
+ * lanes whose source lies outside their row get `old` */
+template <int N>
+__device__ __forceinline__ double bins_row_shr(double old, double src) {
+  const long long o = __double_as_longlong(old), v = __double_as_longlong(src);
+  const int lo = __builtin_amdgcn_update_dpp((int)o, (int)v, 0x110 + N, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp((int)(o >> 32), (int)(v >> 32), 0x110 + N, 0xf, 0xf, false);
+  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+template <int N>
+__device__ __forceinline__ int bins_row_shr(int old, int src) { return __builtin_amdgcn_update_dpp(old, src, 0x110 + N, 0xf, 0xf, false); }
+
+/* Bit `lane` of a mask that is the same in every lane of the wave (it lives in scalar registers):
+ * one select with the mask as the per-lane condition, instead of a 64-bit shift per lane. */
+__device__ __forceinline__ int bins_lane_bit(uint64_t mask) {
+  int r;
+  asm("v_cndmask_b32_e64 %0, 0, 1, %1" : "=v"(r) : "s"(mask));
+  return r;
+}
+/* v where the lane's bit of the wave-uniform mask is set, +0.0 elsewhere */
+__device__ __forceinline__ double bins_keep_if(double v, uint64_t mask) {
+  const long long b = __double_as_longlong(v);
+  int lo = (int)b, hi = (int)(b >> 32);
+  asm("v_cndmask_b32_e64 %0, 0, %0, %2\n\tv_cndmask_b32_e64 %1, 0, %1, %2" : "+v"(lo), "+v"(hi) : "s"(mask));
+  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+/* number of set bits of a wave-uniform mask in the lanes below this one */
+__device__ __forceinline__ int bins_count_below(uint64_t mask) {
+  return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+}
+
+/* What a wave holds of BINS_P1_UNROLL groups of 64 entries between its loads and its stores. */
+struct bins_step {
+  uint32_t u[BINS_P1_UNROLL], vi[BINS_P1_UNROLL];       /* column within the slice, value index  */
+  double v[BINS_P1_UNROLL];                             /* value (VM = 2)                          */
+  int64_t d[BINS_P1_UNROLL];                            /* the slot the lane's stretch is written to */
+  uint64_t sm[BINS_P1_UNROLL];                          /* the groups' stretch starts (scalar)      */
+};
+
+/* The loads of one step: BINS_P1_UNROLL groups from group g on (g is the same in every lane:
+ * what a group shares comes through scalar loads).  A lane's part is the part of the group's
+ * first entry plus the part starts among the lanes up to it; the slot of its stretch is the
+ * part's entry of O plus the stretch starts among the lanes up to it (O has the starts that
+ * precede the part taken off). */
 template <int VM, bool FULL>
-__device__ __forceinline__ void bins_expand_step(int64_t g, int64_t g1, int lane, uint64_t below, const double *xs,
-                                                 const uint16_t *__restrict__ col16, const uint8_t *__restrict__ vidx,
-                                                 const double *__restrict__ vtab, const double *__restrict__ val, double vc,
-                                                 const uint32_t *__restrict__ gfirst, const int64_t *__restrict__ D,
-                                                 double *__restrict__ xe) {
-  uint32_t u[BINS_P1_UNROLL], gf[BINS_P1_UNROLL], vi[BINS_P1_UNROLL];
-  double v[BINS_P1_UNROLL], a[BINS_P1_UNROLL];
-  int64_t d[BINS_P1_UNROLL];
+__device__ __forceinline__ void bins_expand_load(bins_step &s, int64_t g, int64_t g1, int lane, const uint16_t *__restrict__ col16,
+                                                 const uint8_t *__restrict__ vidx, const double *__restrict__ val, double vc,
+                                                 const uint32_t *__restrict__ gfirst, const uint64_t *__restrict__ runmask,
+                                                 const uint64_t *__restrict__ rowmask, const int64_t *__restrict__ O) {
 #pragma unroll
   for (int j = 0; j < BINS_P1_UNROLL; j++) {
-    u[j] = 0; gf[j] = 0; vi[j] = 0; v[j] = vc;
-    if (FULL || g + j < g1) {
+    s.u[j] = 0; s.vi[j] = 0; s.v[j] = vc; s.d[j] = 0; s.sm[j] = ~0ull;
+    if (FULL || g + j < g1) {                                      /* uniform over the wave */
       const int64_t p = (g + j) * 64 + lane;
-      u[j] = __builtin_nontemporal_load(col16 + p);
-      gf[j] = gfirst[g + j];
-      if (VM == 1) vi[j] = __builtin_nontemporal_load(vidx + p);
-      if (VM == 2) v[j] = __builtin_nontemporal_load(val + p);
+      s.u[j] = __builtin_nontemporal_load(col16 + p);
+      if (VM == 1) s.vi[j] = __builtin_nontemporal_load(vidx + p);
+      if (VM == 2) s.v[j] = __builtin_nontemporal_load(val + p);
+      const uint64_t rm = runmask[g + j];
+      s.sm[j] = rowmask[g + j];
+      const int part = (int)gfirst[g + j] + bins_count_below(rm) + bins_lane_bit(rm);
+      s.d[j] = O[part] + (bins_count_below(s.sm[j]) + bins_lane_bit(s.sm[j]));
     }
   }
-  /* a lane's run: the run of the group's first entry plus the run starts among the lanes up to it */
+}
+
+/* Products, sums of the stretches, stores.  A lane forms its entry's product; the products of a
+ * stretch -- neighbouring entries of one row, within a row of 16 lanes -- are added up by a
+ * segmented scan in registers: at step N a lane adds the value of the lane N below it when no
+ * stretch starts in between (masks formed from the group's stretch starts by scalar operations),
+ * and the last lane of a stretch writes the sum.  The products are rounded one by one (no
+ * contraction with the additions), the additions come in the scan's fixed order. */
+template <int VM, bool FULL>
+__device__ __forceinline__ void bins_expand_finish(const bins_step &s, int64_t g, int64_t g1, const double *xs,
+                                                   const double *__restrict__ vtab, double *__restrict__ xe) {
+#pragma clang fp contract(off)
+  double a[BINS_P1_UNROLL];
 #pragma unroll
   for (int j = 0; j < BINS_P1_UNROLL; j++) {
-    d[j] = 0;
-    if (FULL || g + j < g1) {                                   /* uniform over the wave */
-      const uint64_t flags = __ballot((u[j] >> 15) != 0);
-      d[j] = D[(int64_t)gf[j] + __popcll(flags & below)];
-    }
+    a[j] = xs[s.u[j] & 0x7fffu];
+    if (VM == 1) a[j] *= vtab[s.vi[j]];
+    else a[j] *= s.v[j];
   }
 #pragma unroll
   for (int j = 0; j < BINS_P1_UNROLL; j++) {
-    a[j] = xs[u[j] & 0x7fffu];
-    if (VM == 1) a[j] *= vtab[vi[j]];
-    else a[j] *= v[j];
+    const uint64_t f1 = s.sm[j], f2 = f1 | (f1 << 1), f4 = f2 | (f2 << 2), f8 = f4 | (f4 << 4);
+    a[j] += bins_keep_if(bins_row_shr<1>(0.0, a[j]), ~f1);
+    a[j] += bins_keep_if(bins_row_shr<2>(0.0, a[j]), ~f2);
+    a[j] += bins_keep_if(bins_row_shr<4>(0.0, a[j]), ~f4);
+    a[j] += bins_keep_if(bins_row_shr<8>(0.0, a[j]), ~f8);
   }
 #pragma unroll
-  for (int j = 0; j < BINS_P1_UNROLL; j++)
-    if (FULL || g + j < g1) __builtin_nontemporal_store(a[j], &xe[(g + j) * 64 + lane + d[j]]);
+  for (int j = 0; j < BINS_P1_UNROLL; j++) {
+    const int tail = bins_lane_bit((s.sm[j] >> 1) | (1ull << 63));   /* the next lane starts a stretch, or there is none */
+    if ((FULL || g + j < g1) && tail) __builtin_nontemporal_store(a[j], &xe[s.d[j]]);
+  }
 }
 
 template <int VM>
@@ -96,16 +150,26 @@ __global__ __launch_bounds__(BINS_P1_THREADS) void k_bins_expand(const int64_t *
                                                                   const double *__restrict__ vtab,
                                                                   const double *__restrict__ val, double vc,
                                                                   const uint32_t *__restrict__ gfirst,
-                                                                  const int64_t *__restrict__ D,
+                                                                  const uint64_t *__restrict__ runmask,
+                                                                  const uint64_t *__restrict__ rowmask,
+                                                                  const int64_t *__restrict__ O,
                                                                   const double *__restrict__ x, int64_t ncols,
                                                                   double *__restrict__ xe, int W) {
   extern __shared__ double xs[];
   const int64_t cb = tasks[3 * (int64_t)blockIdx.x];
   const int64_t g0 = tasks[3 * (int64_t)blockIdx.x + 1], g1 = tasks[3 * (int64_t)blockIdx.x + 2];
   const int64_t cbase = cb * W;
+  const int nthreads = blockDim.x;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   /* the same in every lane: group numbers stay scalar */
+  const int64_t stride = (int64_t)(nthreads / 64) * BINS_P1_UNROLL;
+  /* the wave's first step is requested before the slice of x: its latency hides behind the slice's */
+  bins_step cur, nxt;
+  int64_t g = g0 + (int64_t)wave * BINS_P1_UNROLL;
+  if (g + BINS_P1_UNROLL <= g1) bins_expand_load<VM, true>(cur, g, g1, lane, col16, vidx, val, vc, gfirst, runmask, rowmask, O);
+  else if (g < g1) bins_expand_load<VM, false>(cur, g, g1, lane, col16, vidx, val, vc, gfirst, runmask, rowmask, O);
   /* the slice of x: all of a thread's loads in flight together (the last slice may be short:
    * the loads are clamped to the last column, what lies beyond is never looked up) */
-  const int nthreads = blockDim.x;
   for (int i0 = 0; i0 < W; i0 += 8 * nthreads) {
     double t[8];
 #pragma unroll
@@ -121,26 +185,19 @@ __global__ __launch_bounds__(BINS_P1_THREADS) void k_bins_expand(const int64_t *
   }
   if (threadIdx.x == 0) xs[W] = 0.0;                      /* the column of the entries that fill a run up to whole cache lines */
   __syncthreads();
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int NW = nthreads / 64;
-  const uint64_t below = ((2ull << lane) - 1ull) & ~1ull;          /* lanes 1..lane */
-  for (int64_t g = g0 + (int64_t)wave * BINS_P1_UNROLL; g < g1; g += (int64_t)NW * BINS_P1_UNROLL) {
-    if (g + BINS_P1_UNROLL <= g1) bins_expand_step<VM, true>(g, g1, lane, below, xs, col16, vidx, vtab, val, vc, gfirst, D, xe);
-    else bins_expand_step<VM, false>(g, g1, lane, below, xs, col16, vidx, vtab, val, vc, gfirst, D, xe);
+  /* Every step's loads are requested before the stores of the step before it are issued: loads
+   * and stores complete in the order of their issue, so a wave that stored first would wait for
+   * its stores to be written before it could use the next loads. */
+  for (; g < g1; g += stride) {
+    const int64_t gn = g + stride;
+    if (gn + BINS_P1_UNROLL <= g1) bins_expand_load<VM, true>(nxt, gn, g1, lane, col16, vidx, val, vc, gfirst, runmask, rowmask, O);
+    else if (gn < g1) bins_expand_load<VM, false>(nxt, gn, g1, lane, col16, vidx, val, vc, gfirst, runmask, rowmask, O);
+    if (g + BINS_P1_UNROLL <= g1) bins_expand_finish<VM, true>(cur, g, g1, xs, vtab, xe);
+    else bins_expand_finish<VM, false>(cur, g, g1, xs, vtab, xe);
+    cur = nxt;
   }
 }
 
-/* data-parallel-primitive moves inside a row of 16 lanes: the value of the lane N places below;
- * lanes whose source lies outside their row keep `old` */
-template <int N>
-__device__ __forceinline__ int bins_row_shr(int old, int src) { return __builtin_amdgcn_update_dpp(old, src, 0x110 + N, 0xf, 0xf, false); }
-template <int N>
-__device__ __forceinline__ double bins_row_shr(double old, double src) {
-  const long long o = __double_as_longlong(old), v = __double_as_longlong(src);
-  const int lo = __builtin_amdgcn_update_dpp((int)o, (int)v, 0x110 + N, 0xf, 0xf, false);
-  const int hi = __builtin_amdgcn_update_dpp((int)(o >> 32), (int)(v >> 32), 0x110 + N, 0xf, 0xf, false);
-  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
-}
 /* one step of a segmented scan: f = a stretch starts at or below this lane within the window so far */
 template <int N>
 __device__ __forceinline__ void bins_scan_step(double &v, int &f) {
@@ -304,8 +361,9 @@ static int env_int(const char *name, int dflt) {
   return e && atoi(e) > 0 ? atoi(e) : dflt;
 }
 
-/* A run: `real` entries of one (unit, column block) cell, filled up with zero products to `cnt`, a
- * multiple of BINS_RUN_ALIGN: every run then starts on a 64-byte boundary of the product array and
+/* A run: the entries of one (unit, column block) cell; what the expand pass writes for it -- one
+ * sum per stretch of entries of one row, a slot -- is filled up with zeros to a multiple of
+ * BINS_RUN_ALIGN slots: every run then starts on a 64-byte boundary of the array of sums and
  * covers whole 64-byte pieces.  Measured (tools/bins_stream_probe.hip, runs of 64 products scattered
  * over 2 GiB): runs that start 24 bytes off a line 1.07 ms against 0.61 ms for aligned ones; with
  * non-temporal stores whole 64-byte pieces are enough (0.58-0.67 ms), with plain stores a half
@@ -313,7 +371,7 @@ static int env_int(const char *name, int dflt) {
 #ifndef BINS_RUN_ALIGN
 #define BINS_RUN_ALIGN 8
 #endif
-struct bins_seg { int32_t c, cnt, real; int64_t pos2, pos1; };
+struct bins_seg { int32_t c, real, unit; int64_t j, praw; };   /* column block, entries, unit; number among the runs of its column block; first entry in the raw expand order */
 
 void ksg_bins_free(ksg_bins *B) {
   if (B->col16) hipFree(B->col16);
@@ -321,7 +379,9 @@ void ksg_bins_free(ksg_bins *B) {
   if (B->vtab) hipFree(B->vtab);
   if (B->val) hipFree(B->val);
   if (B->gfirst) hipFree(B->gfirst);
-  if (B->D) hipFree(B->D);
+  if (B->O) hipFree(B->O);
+  if (B->runmask) hipFree(B->runmask);
+  if (B->rowmask) hipFree(B->rowmask);
   if (B->tasks) hipFree(B->tasks);
   if (B->rowloc) hipFree(B->rowloc);
   if (B->binp0) hipFree(B->binp0);
@@ -339,7 +399,7 @@ void ksg_bins_free(ksg_bins *B) {
 
 /* The binned part on the host, array for array what the device holds. */
 struct bins_host {
-  int64_t nent = 0, nreal = 0, nent1 = 0, nseg = 0, nbins = 0, ntasks = 0, nrows = 0, dshift = 0;
+  int64_t nent = 0, nreal = 0, nent1 = 0, nseg = 0, nparts = 0, nbins = 0, ntasks = 0, nrows = 0, dshift = 0;
   int W = 0, H = 0, vmode = 2;
   bool fold_diag = false;
   double vconst = 0.0;
@@ -347,7 +407,8 @@ struct bins_host {
   ksg_hvec<uint8_t> vidx;
   ksg_hvec<double> val, dv;
   ksg_hvec<uint32_t> gfirst;
-  ksg_hvec<int64_t> D;
+  ksg_hvec<uint64_t> runmask, rowmask;
+  ksg_hvec<int64_t> O;
   std::vector<double> vtab;
   std::vector<int64_t> tasks, binp0, binp1;
   std::vector<int32_t> r0s, nrs;
@@ -488,22 +549,20 @@ static void bins_build_host(bins_host *B, int64_t nrows, int64_t ncols, const in
   tm.lap("row blocks");
 
   /* cells: per unit the entries per column block; cells of at least T entries (any cell of a
-   * piece) are binned, laid out unit by unit, within a unit by column block */
+   * piece) are binned: one run each, listed unit by unit, within a unit by column block */
   ksg_hvec<bins_seg> S;
   std::vector<int64_t> segb((size_t)NB + 1, 0);            /* runs of unit b: S[segb[b] .. segb[b+1]) */
-  std::vector<int64_t> bp0((size_t)NB), bp1((size_t)NB);
   std::vector<int64_t> sfirst((size_t)NT + 1, 0);          /* part t's runs: S[sfirst[t] .. sfirst[t+1]) */
   {
     std::vector<std::vector<bins_seg>> St((size_t)NT);
-    std::vector<int64_t> tpos((size_t)NT + 1, 0), treal((size_t)NT, 0);
+    std::vector<int64_t> treal((size_t)NT, 0);
     ksg_parallel(NT, [&](int t, int) {
       std::vector<bins_seg> &Sl = St[(size_t)t];
       std::vector<int32_t> cnt((size_t)NC, 0), touched;
-      int64_t pos2 = 0, nreal = 0;                         /* counted from the part's first product */
+      int64_t nreal = 0;
       for (int64_t b = ub[(size_t)t]; b < ub[(size_t)t + 1]; b++) {
         const bins_block &k = blocks[(size_t)b];
         touched.clear();
-        bp0[(size_t)b] = pos2;
         const size_t before = Sl.size();
         for (int64_t r = k.r0; r < (int64_t)k.r0 + k.nr; r++) {
           int64_t pa = rowptr[r], pb = rowptr[r + 1];
@@ -517,112 +576,79 @@ static void bins_build_host(bins_host *B, int64_t nrows, int64_t ncols, const in
         }
         std::sort(touched.begin(), touched.end());
         for (int32_t cb : touched) {
-          if (cnt[(size_t)cb] >= T || k.e0 >= 0) {
-            const int32_t padded = (cnt[(size_t)cb] + BINS_RUN_ALIGN - 1) / BINS_RUN_ALIGN * BINS_RUN_ALIGN;
-            Sl.push_back({cb, padded, cnt[(size_t)cb], pos2, 0}); pos2 += padded; nreal += cnt[(size_t)cb];
-          }
+          if (cnt[(size_t)cb] >= T || k.e0 >= 0) { Sl.push_back({cb, cnt[(size_t)cb], (int32_t)b, 0, 0}); nreal += cnt[(size_t)cb]; }
           cnt[(size_t)cb] = 0;
         }
         segb[(size_t)b + 1] = (int64_t)(Sl.size() - before);
-        bp1[(size_t)b] = pos2;
       }
-      tpos[(size_t)t + 1] = pos2; treal[(size_t)t] = nreal;
+      treal[(size_t)t] = nreal;
     });
     int64_t nreal = 0;
     for (int t = 0; t < NT; t++) {
-      tpos[(size_t)t + 1] += tpos[(size_t)t];
       sfirst[(size_t)t + 1] = sfirst[(size_t)t] + (int64_t)St[(size_t)t].size();
       nreal += treal[(size_t)t];
     }
     for (int64_t b = 0; b < NB; b++) segb[(size_t)b + 1] += segb[(size_t)b];
-    B->nent = tpos[(size_t)NT]; B->nreal = nreal;
-    if (B->nreal * 2 < nnz || (uint64_t)sfirst[(size_t)NT] >= (uint64_t)UINT32_MAX - (uint64_t)NC) { *B = bins_host(); return; }
+    B->nreal = nreal;
+    if (B->nreal * 2 < nnz || (uint64_t)sfirst[(size_t)NT] >= (uint64_t)UINT32_MAX / 4 - (uint64_t)NC) { *B = bins_host(); return; }
     S.resize((size_t)sfirst[(size_t)NT]);
     ksg_parallel(NT, [&](int t, int) {
-      const int64_t off = tpos[(size_t)t];
-      bins_seg *dst = S.data() + sfirst[(size_t)t];
-      const std::vector<bins_seg> &Sl = St[(size_t)t];
-      for (size_t i = 0; i < Sl.size(); i++) { dst[i] = Sl[i]; dst[i].pos2 += off; }
-      for (int64_t b = ub[(size_t)t]; b < ub[(size_t)t + 1]; b++) { bp0[(size_t)b] += off; bp1[(size_t)b] += off; }
+      if (!St[(size_t)t].empty()) memcpy(S.data() + sfirst[(size_t)t], St[(size_t)t].data(), St[(size_t)t].size() * sizeof(bins_seg));
       std::vector<bins_seg>().swap(St[(size_t)t]);
     });
   }
+  const int64_t nruns = (int64_t)S.size();
   tm.lap("cells");
   B->W = W; B->H = H; B->nrows = nrows; B->fold_diag = fold; B->dshift = dshift;
 
-  /* the expand order: by column block, within it by unit; every column block's stream is padded
-   * to whole groups of 64 entries (the padding forms a run of its own whose products land in 64
-   * spare slots behind the last product) */
-  std::vector<int64_t> centries((size_t)NC, 0), csegs((size_t)NC, 0);
-  std::vector<int64_t> cpos((size_t)NC + 1, 0), cseg((size_t)NC + 1, 0);
-  std::vector<std::vector<int64_t>> he((size_t)NT), hs((size_t)NT);   /* per part: entries and runs per column block, then where they start */
-  ksg_parallel(NT, [&](int t, int) {
-    he[(size_t)t].assign((size_t)NC, 0); hs[(size_t)t].assign((size_t)NC, 0);
-    for (int64_t i = sfirst[(size_t)t]; i < sfirst[(size_t)t + 1]; i++) { he[(size_t)t][(size_t)S[(size_t)i].c] += S[(size_t)i].cnt; hs[(size_t)t][(size_t)S[(size_t)i].c]++; }
-  });
-  for (int64_t cb = 0; cb < NC; cb++) {
-    for (int t = 0; t < NT; t++) { centries[(size_t)cb] += he[(size_t)t][(size_t)cb]; csegs[(size_t)cb] += hs[(size_t)t][(size_t)cb]; }
-    const int64_t pad = (64 - centries[(size_t)cb] % 64) % 64;
-    cpos[(size_t)cb + 1] = cpos[(size_t)cb] + centries[(size_t)cb] + pad;
-    cseg[(size_t)cb + 1] = cseg[(size_t)cb] + csegs[(size_t)cb] + (pad ? 1 : 0);
-    int64_t fe = cpos[(size_t)cb], fs = cseg[(size_t)cb];
-    for (int t = 0; t < NT; t++) {
-      const int64_t e = he[(size_t)t][(size_t)cb], s = hs[(size_t)t][(size_t)cb];
-      he[(size_t)t][(size_t)cb] = fe; hs[(size_t)t][(size_t)cb] = fs;
-      fe += e; fs += s;
+  /* the expand order: by column block, within it by unit, within a cell by row and column.  First
+   * the raw order (the entries alone): where every run starts in it, and the run's number j among
+   * the runs of its column block */
+  std::vector<int64_t> rawpos((size_t)NC + 1, 0), runpos((size_t)NC + 1, 0);
+  {
+    std::vector<std::vector<int64_t>> he((size_t)NT), hs((size_t)NT);   /* per part: entries and runs per column block, then where they start */
+    ksg_parallel(NT, [&](int t, int) {
+      he[(size_t)t].assign((size_t)NC, 0); hs[(size_t)t].assign((size_t)NC, 0);
+      for (int64_t i = sfirst[(size_t)t]; i < sfirst[(size_t)t + 1]; i++) { he[(size_t)t][(size_t)S[(size_t)i].c] += S[(size_t)i].real; hs[(size_t)t][(size_t)S[(size_t)i].c]++; }
+    });
+    for (int64_t cb = 0; cb < NC; cb++) {
+      int64_t fe = rawpos[(size_t)cb], fs = runpos[(size_t)cb];
+      for (int t = 0; t < NT; t++) {
+        const int64_t e = he[(size_t)t][(size_t)cb], s = hs[(size_t)t][(size_t)cb];
+        he[(size_t)t][(size_t)cb] = fe; hs[(size_t)t][(size_t)cb] = fs;
+        fe += e; fs += s;
+      }
+      rawpos[(size_t)cb + 1] = fe; runpos[(size_t)cb + 1] = fs;
     }
+    ksg_parallel(NT, [&](int t, int) {
+      std::vector<int64_t> &fpos = he[(size_t)t], &fseg = hs[(size_t)t];
+      for (int64_t i = sfirst[(size_t)t]; i < sfirst[(size_t)t + 1]; i++) {
+        bins_seg &s = S[(size_t)i];
+        s.j = fseg[(size_t)s.c]++;
+        s.praw = fpos[(size_t)s.c];
+        fpos[(size_t)s.c] += s.real;
+      }
+    });
   }
-  const int64_t nent1 = cpos[(size_t)NC], nseg1 = cseg[(size_t)NC], ngroups = nent1 / 64;
-  ksg_hvec<int64_t> &D = B->D;
-  D.resize((size_t)nseg1);
-  ksg_hvec<int64_t> P1((size_t)nseg1 + 1);
+  /* the runs by column block: run j is S[sof[j]] */
+  ksg_hvec<int64_t> sof((size_t)nruns);
   ksg_parallel(NT, [&](int t, int) {
-    std::vector<int64_t> &fpos = he[(size_t)t], &fseg = hs[(size_t)t];
-    for (int64_t i = sfirst[(size_t)t]; i < sfirst[(size_t)t + 1]; i++) {
-      bins_seg &s = S[(size_t)i];
-      const int64_t j = fseg[(size_t)s.c]++, p1 = fpos[(size_t)s.c];
-      fpos[(size_t)s.c] += s.cnt;
-      s.pos1 = p1;
-      D[(size_t)j] = s.pos2 - p1;
-      P1[(size_t)j] = p1;
-    }
+    for (int64_t i = sfirst[(size_t)t]; i < sfirst[(size_t)t + 1]; i++) sof[(size_t)S[(size_t)i].j] = i;
   });
-  for (int64_t cb = 0; cb < NC; cb++) {
-    const int64_t p = cpos[(size_t)cb] + centries[(size_t)cb];
-    if (p < cpos[(size_t)cb + 1]) { const int64_t j = cseg[(size_t)cb] + csegs[(size_t)cb]; D[(size_t)j] = B->nent - p; P1[(size_t)j] = p; }
-  }
-  P1[(size_t)nseg1] = nent1;
-  ksg_hvec<uint32_t> &gfirst = B->gfirst;
-  gfirst.resize((size_t)ngroups);
-  ksg_parallel(NT, [&](int t, int nt) {
-    for (int64_t j = nseg1 * t / nt; j < nseg1 * (t + 1) / nt; j++)
-      for (int64_t g = (P1[(size_t)j] + 63) / 64; g * 64 < P1[(size_t)j + 1]; g++) gfirst[(size_t)g] = (uint32_t)j;
-  });
-  { ksg_hvec<int64_t>().swap(P1); std::vector<std::vector<int64_t>>().swap(he); std::vector<std::vector<int64_t>>().swap(hs); }
-  tm.lap("expand order");
+  tm.lap("raw expand order");
 
-  /* the entries themselves: columns and values in the expand order, rows in the reduce order, the
-   * diagonal as a dense vector; what is not binned goes to the CSR of the remaining entries (the
-   * row blocks come first and in row order, so that CSR is in row order too) */
-  ksg_hvec<uint16_t> &col16 = B->col16, &rowloc = B->rowloc;
-  ksg_hvec<double> &val1 = B->val;
-  ksg_hvec<uint8_t> &vidx1 = B->vidx;
+  /* the entries in the raw order: column within the column block, row within the unit, value; what
+   * is not binned goes to the CSR of the remaining entries (the row blocks come first and in row
+   * order, so that CSR is in row order too); the diagonal as a dense vector */
+  ksg_hvec<uint16_t> rcol((size_t)B->nreal), rrow((size_t)B->nreal);
+  ksg_hvec<uint8_t> rvi;
+  ksg_hvec<double> rva;
   uint8_t nused[256] = {0};                               /* values of the table that binned entries have */
-  col16.resize((size_t)nent1); rowloc.resize((size_t)B->nent);
-  ksg_hvec<uint8_t> pad;                                  /* entries that stand for nothing: the fill of the runs and of the groups */
   const bool one = few && pretab.size() == 1;             /* a single value: nothing to store per entry */
   if (one) nused[0] = 1;
-  else if (few) vidx1.resize((size_t)nent1);
-  else { val1.resize((size_t)nent1); pad.resize((size_t)nent1); }
+  else if (few) rvi.resize((size_t)B->nreal);
+  else rva.resize((size_t)B->nreal);
   if (fold) B->dv.resize((size_t)nrows);
-  for (int64_t cb = 0; cb < NC; cb++)
-    for (int64_t p0 = cpos[(size_t)cb] + centries[(size_t)cb], p = p0; p < cpos[(size_t)cb + 1]; p++) {
-      col16[(size_t)p] = p == p0 ? 0x8000u : 0;           /* the first padding entry opens the padding run */
-      if (one) continue;
-      if (few) vidx1[(size_t)p] = 255;
-      else { val1[(size_t)p] = 0.0; pad[(size_t)p] = 1; }
-    }
-  tm.lap("allocate entry arrays");
   {
     std::vector<std::vector<int32_t>> tci((size_t)NT), trows((size_t)NT);
     std::vector<std::vector<double>> tva((size_t)NT);
@@ -651,34 +677,22 @@ static void bins_build_host(bins_host *B, int64_t nrows, int64_t ncols, const in
             const int32_t cb = colidx[p] >> wshift;
             const int64_t i = segid[(size_t)cb];
             if (i < 0) { lc.push_back(colidx[p]); lv.push_back(val[p]); continue; }
-            const int32_t f = fill[(size_t)cb]++;
-            const bins_seg &s = S[(size_t)i];
-            col16[(size_t)(s.pos1 + f)] = (uint16_t)((colidx[p] & (W - 1)) | (f == 0 ? 0x8000 : 0));
+            const int64_t q = S[(size_t)i].praw + fill[(size_t)cb]++;
+            rcol[(size_t)q] = (uint16_t)(colidx[p] & (W - 1));
+            rrow[(size_t)q] = (uint16_t)(r - k.r0);
             if (one) {
             } else if (few) {
               uint64_t bits;
               memcpy(&bits, &val[p], 8);
               if (lastcode < 0 || bits != lastbits) { lastcode = vset.find(bits); lastbits = bits; used[lastcode] = 1; }
-              vidx1[(size_t)(s.pos1 + f)] = (uint8_t)lastcode;
+              rvi[(size_t)q] = (uint8_t)lastcode;
             } else {
-              val1[(size_t)(s.pos1 + f)] = val[p];
-              pad[(size_t)(s.pos1 + f)] = 0;
+              rva[(size_t)q] = val[p];
             }
-            rowloc[(size_t)(s.pos2 + f)] = (uint16_t)(r - k.r0);
           }
           if (lc.size() > before) { lr.push_back((int32_t)r); lp.push_back((int64_t)lc.size()); }
         }
-        for (int64_t i = segb[(size_t)b]; i < segb[(size_t)b + 1]; i++) {
-          const bins_seg &s = S[(size_t)i];
-          segid[(size_t)s.c] = -1;
-          for (int32_t f = s.real; f < s.cnt; f++) {           /* the fill: column W (x = 0 there), any row of the unit */
-            col16[(size_t)(s.pos1 + f)] = (uint16_t)W;
-            if (one) { }
-            else if (few) vidx1[(size_t)(s.pos1 + f)] = 255;
-            else { val1[(size_t)(s.pos1 + f)] = 0.0; pad[(size_t)(s.pos1 + f)] = 1; }
-            rowloc[(size_t)(s.pos2 + f)] = (uint16_t)((f - s.real) % k.nr);
-          }
-        }
+        for (int64_t i = segb[(size_t)b]; i < segb[(size_t)b + 1]; i++) segid[(size_t)S[(size_t)i].c] = -1;
       }
     });
     for (int t = 0; t < NT; t++) for (int i = 0; i < 256; i++) if (tused[(size_t)t][(size_t)i]) nused[i] = 1;
@@ -699,8 +713,124 @@ static void bins_build_host(bins_host *B, int64_t nrows, int64_t ncols, const in
       }
     });
   }
-  { ksg_hvec<bins_seg>().swap(S); }
-  tm.lap("entries");
+  tm.lap("entries, raw order");
+
+  /* The expand pass adds up, before it writes, the products of neighbouring entries of one row (a
+   * stretch: the entries of a cell come sorted by row, so the entries a row has in a column block
+   * are neighbours), within the rows of 16 lanes its scan works in.  What it writes per run is one
+   * sum per stretch, a slot; a run's slots are filled up to a multiple of A with the products of
+   * fill entries (x = 0), so that a run starts and ends on whole 64-byte pieces of the array of
+   * sums.  Where the 16-lane boundaries fall in a run depends on where the run starts in its
+   * column block's stream, which depends on the fill of the runs before it: one walk per column
+   * block, in the order of its runs, counts slots and fill; a second one, once the positions of
+   * all runs in both orders are known, writes the arrays. */
+  const int A = std::min(std::max(env_int("KSG_BINS_ALIGN", BINS_RUN_ALIGN), 1), 64);
+  ksg_hvec<int32_t> rslots((size_t)nruns);                /* slots of run j, fill included */
+  ksg_hvec<uint8_t> rfill((size_t)nruns);                 /* its fill entries */
+  std::vector<int64_t> clen((size_t)NC, 0), cparts((size_t)NC, 0);
+  const int CT = (int)std::min<int64_t>(NT, NC);
+  ksg_parallel(CT, [&](int t, int nt) {
+    for (int64_t cb = NC * t / nt; cb < NC * (t + 1) / nt; cb++) {
+      int64_t q = 0, parts = 0;
+      for (int64_t j = runpos[(size_t)cb]; j < runpos[(size_t)cb + 1]; j++) {
+        const bins_seg &s = S[(size_t)sof[(size_t)j]];
+        const uint16_t *rr = rrow.data() + s.praw;
+        int64_t slots = 1;
+        for (int32_t f = 1; f < s.real; f++) slots += (((q + f) & 15) == 0) || rr[f] != rr[f - 1];
+        const int fl = (int)((A - slots % A) % A);
+        rslots[(size_t)j] = (int32_t)(slots + fl); rfill[(size_t)j] = (uint8_t)fl;
+        const int64_t cnt = s.real + fl;
+        parts += (q + cnt - 1) / 64 - q / 64 + 1;
+        q += cnt;
+      }
+      if (q % 64) parts++;                                 /* the entries that fill the last group form a run of their own */
+      clen[(size_t)cb] = q; cparts[(size_t)cb] = parts;
+    }
+  });
+  std::vector<int64_t> cpos((size_t)NC + 1, 0), partbase((size_t)NC + 1, 0);
+  for (int64_t cb = 0; cb < NC; cb++) {
+    cpos[(size_t)cb + 1] = cpos[(size_t)cb] + (clen[(size_t)cb] + 63) / 64 * 64;
+    partbase[(size_t)cb + 1] = partbase[(size_t)cb] + cparts[(size_t)cb];
+  }
+  const int64_t nent1 = cpos[(size_t)NC], nparts = partbase[(size_t)NC], ngroups = nent1 / 64;
+  /* the reduce order: unit by unit, within a unit by column block; pos2 of run S[i] */
+  ksg_hvec<int64_t> rpos2((size_t)nruns);                 /* by run number j */
+  std::vector<int64_t> bp0((size_t)NB), bp1((size_t)NB);
+  {
+    int64_t acc = 0;
+    for (int64_t b = 0; b < NB; b++) {
+      bp0[(size_t)b] = acc;
+      for (int64_t i = segb[(size_t)b]; i < segb[(size_t)b + 1]; i++) { rpos2[(size_t)S[(size_t)i].j] = acc; acc += rslots[(size_t)S[(size_t)i].j]; }
+      bp1[(size_t)b] = acc;
+    }
+    B->nent = acc;
+  }
+  if ((uint64_t)nparts >= (uint64_t)UINT32_MAX) { *B = bins_host(); lrows.clear(); lrp.clear(); lci.clear(); lva.clear(); return; }
+  tm.lap("slots, both orders");
+
+  ksg_hvec<uint16_t> &col16 = B->col16, &rowloc = B->rowloc;
+  ksg_hvec<double> &val1 = B->val;
+  ksg_hvec<uint8_t> &vidx1 = B->vidx;
+  ksg_hvec<uint8_t> pad;                                  /* entries that stand for nothing: the fill of the runs and of the groups */
+  col16.resize((size_t)nent1); rowloc.resize((size_t)B->nent);
+  if (one) { }
+  else if (few) vidx1.resize((size_t)nent1);
+  else { val1.resize((size_t)nent1); pad.resize((size_t)nent1); }
+  B->gfirst.resize((size_t)ngroups); B->runmask.resize((size_t)ngroups); B->rowmask.resize((size_t)ngroups);
+  B->O.resize((size_t)nparts);
+  ksg_parallel(CT, [&](int t, int nt) {
+    for (int64_t cb = NC * t / nt; cb < NC * (t + 1) / nt; cb++) {
+      int64_t p = cpos[(size_t)cb], part = partbase[(size_t)cb];
+      uint64_t rm = 0, sm = 0;
+      int gstarts = 0;                                     /* stretch starts of the current group so far */
+      /* one entry of the stream: `start` opens a stretch (slot `at`), `newpart` a part whose first slot is `at`
+       * (O holds that slot minus the stretch starts of the group up to and including the part's first:
+       * a lane adds the starts up to itself) */
+      auto put = [&](bool start, bool newpart, int64_t at, uint16_t c16, int vi, double vv, bool isfill) {
+        const int lane = (int)(p & 63);
+        const int64_t g = p >> 6;
+        if (lane == 0) { rm = 0; sm = 0; gstarts = 0; newpart = true; start = true; }
+        if ((lane & 15) == 0) start = true;
+        if (start) gstarts++;
+        if (newpart) {
+          B->O[(size_t)part] = at - gstarts;
+          if (lane == 0) B->gfirst[(size_t)g] = (uint32_t)part; else rm |= 1ull << lane;
+          part++;
+        }
+        if (start) sm |= 1ull << lane;
+        col16[(size_t)p] = c16;
+        if (one) { }
+        else if (few) vidx1[(size_t)p] = (uint8_t)vi;
+        else { val1[(size_t)p] = vv; pad[(size_t)p] = isfill ? 1 : 0; }
+        if (lane == 63) { B->runmask[(size_t)g] = rm; B->rowmask[(size_t)g] = sm; }
+        p++;
+      };
+      for (int64_t j = runpos[(size_t)cb]; j < runpos[(size_t)cb + 1]; j++) {
+        const bins_seg &s = S[(size_t)sof[(size_t)j]];
+        const uint16_t *rr = rrow.data() + s.praw, *rc = rcol.data() + s.praw;
+        const int32_t unr = blocks[(size_t)s.unit].nr;
+        const int64_t base = rpos2[(size_t)j];
+        int64_t slot = -1;
+        for (int32_t f = 0; f < s.real; f++) {
+          const bool start = f == 0 || (p & 15) == 0 || rr[f] != rr[f - 1];
+          if (start) { slot++; rowloc[(size_t)(base + slot)] = rr[f]; }
+          put(start, f == 0, base + slot, rc[f], one || !few ? 0 : rvi[(size_t)(s.praw + f)], few ? 0.0 : rva[(size_t)(s.praw + f)], false);
+        }
+        for (int f = 0; f < (int)rfill[(size_t)j]; f++) {     /* the fill: column W (x = 0 there), a slot each, any row of the unit */
+          slot++;
+          rowloc[(size_t)(base + slot)] = (uint16_t)(f % unr);
+          put(true, false, base + slot, (uint16_t)W, 255, 0.0, true);
+        }
+      }
+      /* the fill of the column block's last group: a run of its own whose sums land in the spare slots behind the last */
+      for (int f = 0; p < cpos[(size_t)cb + 1]; f++) put(true, f == 0, B->nent + f, (uint16_t)W, 255, 0.0, true);
+    }
+  });
+  { ksg_hvec<bins_seg>().swap(S); ksg_hvec<int64_t>().swap(sof); ksg_hvec<uint16_t>().swap(rcol); ksg_hvec<uint16_t>().swap(rrow);
+    ksg_hvec<uint8_t>().swap(rvi); ksg_hvec<double>().swap(rva); }
+  B->nparts = nparts;
+  tm.lap("entries, final order");
+
 
   /* every unit stores its rows of y (or its piece's sum); the units with the most products are
    * started first */
@@ -766,7 +896,7 @@ static void bins_build_host(bins_host *B, int64_t nrows, int64_t ncols, const in
     B->ntasks = nt;
   }
   tm.lap("tasks");
-  B->nent1 = nent1; B->nseg = nseg1;
+  B->nent1 = nent1; B->nseg = nruns;
 }
 
 /* y = B x + d .* x on the host, walking the arrays the way the two kernels do (the lanes of a
@@ -779,15 +909,28 @@ static void bins_emulate(const bins_host &B, const double *x, int64_t ncols, dou
     const int64_t cb = B.tasks[3 * t];
     for (int i = 0; i < B.W; i++) xs[i] = cb * B.W + i < ncols ? x[cb * B.W + i] : 0.0;
     for (int64_t g = B.tasks[3 * t + 1]; g < B.tasks[3 * t + 2]; g++) {
-      uint64_t flags = 0;
-      for (int l = 0; l < 64; l++) if (B.col16[(size_t)(g * 64 + l)] & 0x8000u) flags |= 1ull << l;
+      const uint64_t rm = B.runmask[(size_t)g], sm = B.rowmask[(size_t)g];
+      double a[64], a0[64];
       for (int l = 0; l < 64; l++) {
         const int64_t p = g * 64 + l;
-        const uint64_t below = l == 63 ? ~1ull : (((2ull << l) - 1ull) & ~1ull);
-        const int64_t d = B.D[(size_t)((int64_t)B.gfirst[(size_t)g] + __builtin_popcountll(flags & below))];
-        double a = xs[B.col16[(size_t)p] & 0x7fffu];
-        a *= B.vmode == 0 ? B.vconst : B.vmode == 1 ? B.vtab[B.vidx[(size_t)p]] : B.val[(size_t)p];
-        xe[(size_t)(p + d)] = a;
+        volatile double prod = xs[B.col16[(size_t)p] & 0x7fffu] * (B.vmode == 0 ? B.vconst : B.vmode == 1 ? B.vtab[B.vidx[(size_t)p]] : B.val[(size_t)p]);
+        a[l] = prod;
+      }
+      uint64_t F = sm;                                       /* a stretch starts in the window of N lanes that ends at the lane */
+      for (int N = 1; N < 16; N *= 2) {                      /* the segmented scan over rows of 16 lanes, step by step as the lanes do it */
+        memcpy(a0, a, sizeof(a));
+        for (int l = 0; l < 64; l++) {
+          const bool take = (l & 15) >= N && !((F >> l) & 1ull);
+          volatile double sum = a0[l] + (take ? a0[l - N] : 0.0);
+          a[l] = sum;
+        }
+        F |= F << N;
+      }
+      for (int l = 0; l < 64; l++) {
+        if (l != 63 && !((sm >> (l + 1)) & 1ull)) continue;  /* not the last lane of its stretch */
+        const uint64_t upto = l == 63 ? ~0ull : ((2ull << l) - 1ull);   /* lanes 0..l */
+        const int64_t part = (int64_t)B.gfirst[(size_t)g] + __builtin_popcountll(rm & upto);   /* bit 0 of rm is never set */
+        xe[(size_t)(B.O[(size_t)part] + __builtin_popcountll(sm & upto))] = a[l];
       }
     }
   }
@@ -891,14 +1034,16 @@ static int bins_to_device(ksg_ctx c, ksg_bins *B, const bins_host &Hb, const int
   B->threads = env_int("KSG_BINS_THREADS", 1024) / 64 * 64;
   if (B->threads < 64) B->threads = 64;
   if (B->threads > BINS_P1_THREADS) B->threads = BINS_P1_THREADS;
-  B->nent = Hb.nent; B->nreal = Hb.nreal; B->nent1 = Hb.nent1; B->nseg = Hb.nseg; B->nbins = Hb.nbins; B->ntasks = Hb.ntasks;
+  B->nent = Hb.nent; B->nreal = Hb.nreal; B->nent1 = Hb.nent1; B->nseg = Hb.nseg; B->nparts = Hb.nparts; B->nbins = Hb.nbins; B->ntasks = Hb.ntasks;
   B->nrows = Hb.nrows; B->dshift = Hb.dshift; B->W = Hb.W; B->H = Hb.H; B->vmode = Hb.vmode; B->vconst = Hb.vconst;
   KSG_HIP(hipSetDevice(c->device));
   KSG_CHK(bins_upload(&B->col16, Hb.col16.data(), Hb.col16.size()));
   if (B->vmode == 1) { KSG_CHK(bins_upload(&B->vidx, Hb.vidx.data(), Hb.vidx.size())); KSG_CHK(bins_upload(&B->vtab, Hb.vtab.data(), Hb.vtab.size())); }
   if (B->vmode == 2) KSG_CHK(bins_upload(&B->val, Hb.val.data(), Hb.val.size()));
   KSG_CHK(bins_upload(&B->gfirst, Hb.gfirst.data(), Hb.gfirst.size()));
-  KSG_CHK(bins_upload(&B->D, Hb.D.data(), Hb.D.size()));
+  KSG_CHK(bins_upload(&B->O, Hb.O.data(), Hb.O.size()));
+  KSG_CHK(bins_upload(&B->runmask, Hb.runmask.data(), Hb.runmask.size()));
+  KSG_CHK(bins_upload(&B->rowmask, Hb.rowmask.data(), Hb.rowmask.size()));
   KSG_CHK(bins_upload(&B->tasks, Hb.tasks.data(), Hb.tasks.size()));
   KSG_CHK(bins_upload(&B->rowloc, Hb.rowloc.data(), Hb.rowloc.size()));
   KSG_CHK(bins_upload(&B->binp0, Hb.binp0.data(), Hb.binp0.size()));
@@ -980,11 +1125,11 @@ int ksg_bins_mult(const ksg_bins *B, const double *x, int64_t ncols, double *y, 
   const size_t lds1 = ((size_t)B->W + 1) * sizeof(double), lds2 = (size_t)B->H * sizeof(double);
   const dim3 g1((unsigned)B->ntasks), b1((unsigned)B->threads);
   if (B->vmode == 0)
-    hipLaunchKernelGGL(k_bins_expand<0>, g1, b1, lds1, st, B->tasks, B->col16, B->vidx, B->vtab, B->val, B->vconst, B->gfirst, B->D, x, ncols, B->xe, B->W);
+    hipLaunchKernelGGL(k_bins_expand<0>, g1, b1, lds1, st, B->tasks, B->col16, B->vidx, B->vtab, B->val, B->vconst, B->gfirst, B->runmask, B->rowmask, B->O, x, ncols, B->xe, B->W);
   else if (B->vmode == 1)
-    hipLaunchKernelGGL(k_bins_expand<1>, g1, b1, lds1, st, B->tasks, B->col16, B->vidx, B->vtab, B->val, 1.0, B->gfirst, B->D, x, ncols, B->xe, B->W);
+    hipLaunchKernelGGL(k_bins_expand<1>, g1, b1, lds1, st, B->tasks, B->col16, B->vidx, B->vtab, B->val, 1.0, B->gfirst, B->runmask, B->rowmask, B->O, x, ncols, B->xe, B->W);
   else
-    hipLaunchKernelGGL(k_bins_expand<2>, g1, b1, lds1, st, B->tasks, B->col16, B->vidx, B->vtab, B->val, 1.0, B->gfirst, B->D, x, ncols, B->xe, B->W);
+    hipLaunchKernelGGL(k_bins_expand<2>, g1, b1, lds1, st, B->tasks, B->col16, B->vidx, B->vtab, B->val, 1.0, B->gfirst, B->runmask, B->rowmask, B->O, x, ncols, B->xe, B->W);
   hipLaunchKernelGGL(k_bins_reduce, dim3((unsigned)B->nbins), dim3(64), lds2, st, B->binp0, B->binp1, B->bin_r0, B->bin_nr, B->rowloc, B->xe,
                      B->dv, x, B->dshift, y, B->nrows, B->part, d_rowmap);
   if (B->nlong)
@@ -994,13 +1139,14 @@ int ksg_bins_mult(const ksg_bins *B, const double *x, int64_t ncols, double *y, 
   return KSG_OK;
 }
 
-/* Bytes one binned product moves: expand reads the 2-byte columns (+ value bytes), one offset
- * per run, 4 bytes per group of 64 and the slice of x per task, and writes the products; reduce
- * reads products and 2-byte rows, the diagonal and x at the rows, and writes y. */
+/* Bytes one binned product moves: expand reads the 2-byte columns (+ value bytes), 20 bytes per
+ * group of 64 (first part, part starts, stretch starts), one offset per part and the slice of x
+ * per task, and writes one sum per slot; reduce reads the sums and their 2-byte rows, the diagonal
+ * and x at the rows, and writes y. */
 double ksg_bins_bytes(const ksg_bins *B) {
   if (!B->nent) return 0.0;
   const double vb = B->vmode == 2 ? 8.0 : B->vmode == 1 ? 1.0 : 0.0;
-  return (2.0 + vb) * (double)B->nent1 + 8.0 * (double)B->nseg + 4.0 * (double)(B->nent1 / 64) +
+  return (2.0 + vb) * (double)B->nent1 + 8.0 * (double)B->nparts + 20.0 * (double)(B->nent1 / 64) +
          (8.0 * B->W + 24.0) * (double)B->ntasks + 8.0 * (double)B->nent +
          10.0 * (double)B->nent + 24.0 * (double)B->nbins + (B->dv ? 24.0 : 8.0) * (double)B->nrows;
 }
@@ -1012,20 +1158,21 @@ int ksg_bins_to_host(const ksg_bins *B, std::vector<int32_t> &rows, std::vector<
   if (!B->nent) return KSG_OK;
   std::vector<uint16_t> col16((size_t)B->nent1), rowloc((size_t)B->nent);
   std::vector<uint32_t> gfirst((size_t)(B->nent1 / 64));
-  std::vector<int64_t> D((size_t)B->nseg), tasks((size_t)B->ntasks * 3), binp0((size_t)B->nbins);
+  std::vector<uint64_t> runmask((size_t)(B->nent1 / 64)), rowmask((size_t)(B->nent1 / 64));
+  std::vector<int64_t> O((size_t)B->nparts), tasks((size_t)B->ntasks * 3), binp0((size_t)B->nbins);
   std::vector<int32_t> r0s((size_t)B->nbins);
   std::vector<uint8_t> vidx;
   std::vector<double> tab, val1, dv;
 #define DL(dst, src) KSG_HIP(hipMemcpy((dst).data(), (src), (dst).size() * sizeof((dst)[0]), hipMemcpyDeviceToHost))
-  DL(col16, B->col16); DL(rowloc, B->rowloc); DL(gfirst, B->gfirst); DL(D, B->D); DL(tasks, B->tasks);
-  DL(binp0, B->binp0); DL(r0s, B->bin_r0);
+  DL(col16, B->col16); DL(rowloc, B->rowloc); DL(gfirst, B->gfirst); DL(runmask, B->runmask); DL(rowmask, B->rowmask); DL(O, B->O);
+  DL(tasks, B->tasks); DL(binp0, B->binp0); DL(r0s, B->bin_r0);
   if (B->vmode == 1) { vidx.resize((size_t)B->nent1); tab.resize(256); DL(vidx, B->vidx); DL(tab, B->vtab); }
   if (B->vmode == 2) { val1.resize((size_t)B->nent1); DL(val1, B->val); }
   if (B->dv) { dv.resize((size_t)B->nrows); DL(dv, B->dv); }
   std::vector<int32_t> piece_row((size_t)B->npieces);
   if (B->npieces) DL(piece_row, B->piece_row);
 #undef DL
-  /* the row blocks that hold products, by their first product */
+  /* the row blocks that hold sums, by their first slot */
   std::vector<int64_t> binp1((size_t)B->nbins);
   KSG_HIP(hipMemcpy(binp1.data(), B->binp1, binp1.size() * sizeof(int64_t), hipMemcpyDeviceToHost));
   std::vector<int64_t> order;
@@ -1033,18 +1180,19 @@ int ksg_bins_to_host(const ksg_bins *B, std::vector<int32_t> &rows, std::vector<
   std::sort(order.begin(), order.end(), [&](int64_t a, int64_t b) { return binp0[(size_t)a] < binp0[(size_t)b]; });
   std::vector<int64_t> starts(order.size());
   for (size_t i = 0; i < order.size(); i++) starts[i] = binp0[(size_t)order[i]];
-  rows.reserve((size_t)(B->nent + (B->dv ? B->nrows : 0))); cols.reserve(rows.capacity()); vals.reserve(rows.capacity());
+  rows.reserve((size_t)(B->nreal + (B->dv ? B->nrows : 0))); cols.reserve(rows.capacity()); vals.reserve(rows.capacity());
   int64_t cur_lo = 0, cur_hi = 0, cur_r0 = 0;
   for (int64_t t = 0; t < B->ntasks; t++) {
     const int64_t cb = tasks[3 * t];
     for (int64_t g = tasks[3 * t + 1]; g < tasks[3 * t + 2]; g++) {
-      int64_t seg = gfirst[(size_t)g];
+      int64_t part = gfirst[(size_t)g], nst = 0;
       for (int l = 0; l < 64; l++) {
         const int64_t p = g * 64 + l;
-        if (l && (col16[(size_t)p] & 0x8000u)) seg++;
-        const int64_t q = p + D[(size_t)seg];
+        if (l && ((runmask[(size_t)g] >> l) & 1ull)) part++;
+        if ((rowmask[(size_t)g] >> l) & 1ull) nst++;            /* lane 0 and every first lane of a part start a stretch */
+        const int64_t q = O[(size_t)part] + nst;
         if (q >= B->nent || (col16[(size_t)p] & 0x7fffu) == (unsigned)B->W) continue;   /* fill of a group or of a run */
-        /* the block that holds product q (consecutive products mostly share it) */
+        /* the block that holds slot q (consecutive slots mostly share it) */
         if (q < cur_lo || q >= cur_hi) {
           const int64_t i = (int64_t)(std::upper_bound(starts.begin(), starts.end(), q) - starts.begin()) - 1;
           cur_lo = starts[(size_t)i]; cur_hi = binp1[(size_t)order[(size_t)i]]; cur_r0 = r0s[(size_t)order[(size_t)i]];

@@ -239,10 +239,11 @@ struct ksg_rest {
  * block) cells, held in the order the expand pass streams them (by column block) and, for their
  * rows, in the order the reduce pass streams the products (by row block). */
 struct ksg_bins {
-  int64_t nent;              /* products of the binned part, the fill of the runs included; 0: the block has no binned part */
-  int64_t nreal;             /* matrix entries among them                                       */
-  int64_t nent1;             /* entries of the expand stream, padding included (a multiple of 64) */
-  int64_t nseg;              /* runs of the expand stream that are consecutive in the reduce order */
+  int64_t nent;              /* slots: the sums the expand pass writes, one per stretch of entries of one row, the fill of the runs included; 0: the block has no binned part */
+  int64_t nreal;             /* matrix entries of the binned part                               */
+  int64_t nent1;             /* entries of the expand stream, fill included (a multiple of 64)  */
+  int64_t nseg;              /* runs: the entries of one (row block, column block) cell, consecutive in both orders */
+  int64_t nparts;            /* parts: the pieces of the runs that lie in one group of 64 entries */
   int64_t nbins;             /* row blocks (all of them: the reduce pass stores every row of y)  */
   int64_t ntasks;            /* workgroups of the expand pass                                    */
   int64_t nrows;             /* rows of the block                                                */
@@ -251,21 +252,23 @@ struct ksg_bins {
   int threads;               /* threads of an expand workgroup                                   */
   int vmode;                 /* 0: one value (vconst), 1: one-byte indices into vtab, 2: 8-byte values */
   double vconst;
-  uint16_t *col16;           /* nent1: column within the column block; bit 15: first entry of a run */
+  uint16_t *col16;           /* nent1: column within the column block (W: a fill entry, x = 0)   */
   uint8_t *vidx;             /* nent1 (vmode 1)                                                  */
   double *vtab;              /* 256 (vmode 1)                                                    */
   double *val;               /* nent1 (vmode 2)                                                  */
-  uint32_t *gfirst;          /* per group of 64 entries: the run its first entry belongs to      */
-  int64_t *D;                /* per run: position in the reduce order minus position in the expand order */
+  uint32_t *gfirst;          /* per group of 64 entries: the part its first entry belongs to     */
+  uint64_t *runmask;         /* per group: bit l = entry l opens a part (a run starts there)     */
+  uint64_t *rowmask;         /* per group: bit l = entry l opens a stretch (another row, a part, a row of 16 lanes) */
+  int64_t *O;                /* per part: the slot of its first stretch                          */
   int64_t *tasks;            /* 3 per task: column block, first group, end group                 */
-  uint16_t *rowloc;          /* nent: row within the row block, in the reduce order              */
+  uint16_t *rowloc;          /* nent: row within the row block of every slot, in the reduce order */
   int64_t *binp0, *binp1;    /* nbins each: the products of a row block, in the reduce order; the blocks with the most products first */
   int32_t *bin_r0, *bin_nr;  /* first row and row count of every row block                       */
   int64_t nlong, npieces;    /* rows longer than a unit of the reduce pass may be, and the pieces they are cut into */
   int32_t *long_rows, *long_first, *piece_row;   /* those rows; their pieces long_first[j] .. long_first[j+1]; the row of every piece */
   double *part;              /* npieces sums, added to their rows after the reduce pass             */
   double *dv;                /* nrows: the block's diagonal, folded into the reduce pass (NULL: the block has none, or not one per row) */
-  double *xe;                /* nent + 64 products                                               */
+  double *xe;                /* nent + 64 sums                                                   */
 };
 
 struct ksg_mat_s {

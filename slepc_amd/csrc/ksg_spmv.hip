@@ -616,10 +616,10 @@ extern "C" int ksg_mat_describe(ksg_mat A, char *buf, size_t len) {
   if (A->bins.nent && k > 0 && (size_t)k < len) {
     long long rows = 0, ent = 0, hot = 0;
     for (const ksg_rest &cg : A->rest) { rows += cg.nrows; ent += cg.blk.nnz; hot += cg.nhot; }
-    k = snprintf(buf, len, "binned part: %lld of %lld entries in cells of %d-column blocks x row blocks of <= %d rows (%lld runs, %lld row blocks, "
-                 "values: %s), expanded through LDS slices of x and summed per row block in LDS%s; remaining entries: %lld in %lld rows through "
+    k = snprintf(buf, len, "binned part: %lld of %lld entries in cells of %d-column blocks x row blocks of <= %d rows (%lld runs, %lld sums of "
+                 "neighbouring entries of a row, %lld row blocks, values: %s), expanded through LDS slices of x and summed per row block in LDS%s; remaining entries: %lld in %lld rows through "
                  "the tile kernel (row tiles of <= %d entries, %lld packed hot columns), added afterwards",
-                 (long long)A->bins.nreal, (long long)A->nnz, A->bins.W, A->bins.H, (long long)A->bins.nseg, (long long)A->bins.nbins,
+                 (long long)A->bins.nreal, (long long)A->nnz, A->bins.W, A->bins.H, (long long)A->bins.nseg, (long long)A->bins.nent, (long long)A->bins.nbins,
                  A->bins.vmode == 0 ? "one" : A->bins.vmode == 1 ? "1-byte indices" : "8-byte stream",
                  A->bins.dv ? ", the diagonal as a dense vector in the same pass" : "", ent, rows, KSG_TILE_NNZ, hot);
   }

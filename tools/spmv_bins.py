@@ -10,6 +10,8 @@ import time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from slepc_amd import ksgpu, matgen
+if os.environ.get("KSGPU_LIB"):                       # a build of the device library with other compile-time settings
+    ksgpu.LIB_PATH = os.environ["KSGPU_LIB"]
 
 
 def main():
@@ -31,7 +33,7 @@ def main():
     ctx.vec_fill_hash(x, n, 0, 5)
     y0 = None
     for setting in settings:
-        for k in ("W", "H", "E", "T", "TASK_GROUPS", "THREADS"):
+        for k in ("W", "H", "E", "T", "TASK_GROUPS", "THREADS", "ALIGN"):
             os.environ.pop("KSG_BINS_" + k, None)
         if setting == "plain":
             ctx.set_option(ksgpu.OPT_BINS, 1)
