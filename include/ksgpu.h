@@ -82,7 +82,7 @@ void *ksg_ctx_stream(ksg_ctx ctx);
  * of sums: results are bit for bit those without the packing.
  * KSG_OPT_BINS (default 0 = by size; 1 = never; 2 = always): a block of a power-law operator
  * created afterwards -- the local block of a rank, and the ghost block of a distributed operator,
- * whose x is the ghost buffer -- (x of 32 MiB or more when chosen by size) keeps the entries of its
+ * whose x is the ghost buffer -- (x of 16 MiB or more when chosen by size) keeps the entries of its
  * well filled (row block, column block) cells in a binned form: one pass looks x up in LDS slices
  * and writes the products in the order of the row blocks, a second pass sums them per row block in
  * LDS and adds the diagonal term; the remaining entries stay a CSR over the rows they touch and

@@ -7,16 +7,21 @@
  *
  *   expand : the columns are cut into blocks of W; a workgroup holds one block's slice of x in
  *            LDS and streams the entries of those columns (2 bytes of column within the block
- *            per entry), looks x up in LDS and writes the product where the second pass wants
- *            it.  The entries of one (row block, column block) cell form a run that is
- *            consecutive in both orders, so the writes are runs, not scatters; every run is
- *            filled up with zero products to whole 64-byte pieces and written with non-temporal
- *            stores (a partly written piece costs the memory system a read of the rest).
+ *            per entry) and looks x up in LDS.  The entries of one (row block, column block)
+ *            cell form a run that is consecutive in both orders, and within a run the entries
+ *            come sorted by row, so the entries a row has in a column block are neighbours: a
+ *            stretch.  The wave adds up the products of a stretch in registers (a segmented
+ *            scan over rows of 16 lanes) and writes one sum per stretch, a slot, where the
+ *            second pass wants it -- on a power-law operator half of the products or fewer.
+ *            The writes are runs, not scatters; every run's slots are filled up with zeros to
+ *            whole 64-byte pieces and written with non-temporal stores (a partly written piece
+ *            costs the memory system a read of the rest).
  *   reduce : the rows are cut into blocks of at most H rows and E entries; one wave holds a
- *            block's partial sums in LDS, streams the block's products (8 bytes) and row
+ *            block's partial sums in LDS, streams the block's slots (8 bytes) and their row
  *            numbers within the block (2 bytes), adds them up with LDS atomics (one wave per
- *            block: the order of the additions is fixed; stretches of lanes that share a row are
- *            added up in registers first), adds the diagonal term and stores y.
+ *            block: the order of the additions is fixed; lanes that still share a row -- a
+ *            stretch cut at a 16-lane boundary -- are added up in registers first), adds the
+ *            diagonal term and stores y.
  *            A row longer than E is cut into pieces, each summed by a wave of its own in
  *            registers; the sums of the pieces are added to the row afterwards, in their order.
  *
@@ -27,9 +32,9 @@
  * src/sys/classes/st/impls/shift/shift.c:38) in another order, the same order in every product.
  *
  * Tuning variables, read when an operator is created: KSG_BINS_W (columns per column block, a
- * power of two up to 16384 = 128 KiB of LDS), KSG_BINS_H (rows per row block, up to 8192),
- * KSG_BINS_E (entries per row block; unless set, 3e-4 of the block's entries as a power of two
- * between 65536 and 524288), KSG_BINS_T (fewest entries of a binned cell), KSG_BINS_TASK_GROUPS
+ * power of two up to 16384 = 128 KiB of LDS), KSG_BINS_H (rows per row block, up to 8192; 4096),
+ * KSG_BINS_E (entries per row block; unless set, 1e-3 of the block's entries as a power of two
+ * between 65536 and 1048576), KSG_BINS_T (fewest entries of a binned cell), KSG_BINS_TASK_GROUPS
  * (groups of 64 entries per expand workgroup; unless set, up to 8192), KSG_BINS_THREADS (threads
  * of an expand workgroup), KSG_BINS_ALIGN (slots a run is filled up to a multiple of; 8). */
 #include <algorithm>
@@ -394,6 +399,7 @@ void ksg_bins_free(ksg_bins *B) {
   if (B->piece_row) hipFree(B->piece_row);
   if (B->part) hipFree(B->part);
   if (B->xe) hipFree(B->xe);
+  free(B->task_stage);
   memset(B, 0, sizeof(*B));
 }
 
@@ -410,7 +416,7 @@ struct bins_host {
   ksg_hvec<uint64_t> runmask, rowmask;
   ksg_hvec<int64_t> O;
   std::vector<double> vtab;
-  std::vector<int64_t> tasks, binp0, binp1;
+  std::vector<int64_t> tasks, binp0, binp1, task_stage;
   std::vector<int32_t> r0s, nrs;
   std::vector<int32_t> long_rows, long_first, piece_row;   /* rows cut into pieces; their pieces long_first[j] .. long_first[j+1]; row of every piece */
 };
@@ -426,7 +432,8 @@ struct bins_block { int32_t r0, nr, piece; int64_t e0, e1; };
  * (B->nent == 0, the vectors stay empty). */
 static void bins_build_host(bins_host *B, int64_t nrows, int64_t ncols, const int64_t *rowptr, const int32_t *colidx,
                             const double *val, bool has_diag, int64_t dshift, std::vector<int32_t> &lrows, std::vector<int64_t> &lrp,
-                            std::vector<int32_t> &lci, std::vector<double> &lva, int H, int64_t E, int maxW) {
+                            std::vector<int32_t> &lci, std::vector<double> &lva, int H, int64_t E, int maxW,
+                            const ksg_colstages *colstage) {
   *B = bins_host();
   lrows.clear(); lrp.clear(); lci.clear(); lva.clear();
   /* R-MAT scale 26 (1.13e9 entries, E = 65536): 6.65 ms per product with H = 2048, 7.27 with 4096; before the reduce pass combined
@@ -889,11 +896,34 @@ static void bins_build_host(bins_host *B, int64_t nrows, int64_t ncols, const in
     const int64_t nt = (int64_t)t3.size() / 3;
     std::vector<int64_t> order((size_t)nt);
     std::iota(order.begin(), order.end(), (int64_t)0);
-    std::stable_sort(order.begin(), order.end(), [&](int64_t a, int64_t b) { return t3[3 * a + 2] - t3[3 * a + 1] > t3[3 * b + 2] - t3[3 * b + 1]; });
+    /* with column stages: the tasks of a stage together, stage by stage -- a column block belongs to
+     * the last stage any of its columns needs; within a stage the longest first */
+    std::vector<int> tstage((size_t)nt, 0);
+    if (colstage && colstage->nstages > 1) {
+      for (int64_t i = 0; i < nt; i++) {
+        const int64_t c0 = t3[(size_t)(3 * i)] * W, c1 = std::min<int64_t>(c0 + W, ncols);
+        int st = 0;
+        for (size_t k = 0; k + 1 < colstage->bound.size(); k++)
+          if (colstage->bound[k] < c1 && colstage->bound[k + 1] > c0) st = std::max(st, colstage->stage[k]);
+        tstage[(size_t)i] = st;
+      }
+    }
+    std::stable_sort(order.begin(), order.end(), [&](int64_t a, int64_t b) {
+      if (tstage[(size_t)a] != tstage[(size_t)b]) return tstage[(size_t)a] < tstage[(size_t)b];
+      return t3[3 * a + 2] - t3[3 * a + 1] > t3[3 * b + 2] - t3[3 * b + 1];
+    });
     B->tasks.resize(t3.size());
     for (int64_t i = 0; i < nt; i++)
       for (int k = 0; k < 3; k++) B->tasks[(size_t)(3 * i + k)] = t3[(size_t)(3 * order[(size_t)i] + k)];
     B->ntasks = nt;
+    if (colstage && colstage->nstages > 1) {
+      B->task_stage.assign((size_t)colstage->nstages + 1, nt);
+      B->task_stage[0] = 0;
+      for (int64_t i = nt - 1; i >= 0; i--) B->task_stage[(size_t)tstage[(size_t)order[(size_t)i]]] = i;
+      for (int st = colstage->nstages - 1; st >= 1; st--)      /* a stage without tasks starts where the next one does */
+        if (B->task_stage[(size_t)st] > B->task_stage[(size_t)st + 1]) B->task_stage[(size_t)st] = B->task_stage[(size_t)st + 1];
+      B->task_stage[0] = 0;
+    }
   }
   tm.lap("tasks");
   B->nent1 = nent1; B->nseg = nruns;
@@ -964,26 +994,31 @@ static void bins_emulate(const bins_host &B, const double *x, int64_t ncols, dou
   }
 }
 
-/* The binned part of a block with the sizes of the row blocks chosen: KSG_BINS_H rows (2048 unless
+/* The binned part of a block with the sizes of the row blocks chosen: KSG_BINS_H rows (4096 unless
  * set) and E entries at most. */
 static void bins_build_sized(bins_host *B, int64_t nrows, int64_t ncols, const int64_t *rowptr, const int32_t *colidx,
                              const double *val, bool has_diag, int64_t dshift, std::vector<int32_t> &lrows, std::vector<int64_t> &lrp,
-                             std::vector<int32_t> &lci, std::vector<double> &lva, int maxW = 16384) {
-  const int H = env_int("KSG_BINS_H", 2048);
+                             std::vector<int32_t> &lci, std::vector<double> &lva, int maxW = 16384,
+                             const ksg_colstages *colstage = NULL) {
+  /* Rows per row block: the reduce pass keeps a block's sums in LDS, 8 H bytes per wave.  With the
+   * sums of neighbouring entries formed in the expand pass the reduce pass has little to add per
+   * row, and larger blocks -- fewer, better filled cells, fewer runs -- pay although only five
+   * waves fit a CU: R-MAT scale 26 4.93 ms per product with H = 2048, 4.79 with 4096, 5.51 with
+   * 8192; scale 24 1.116 / 1.100 / 1.37 ms; scale 22 0.258 ms either way. */
+  const int H = env_int("KSG_BINS_H", 4096);
   /* Most entries per row block.  Where rows are long (the hub rows of a power-law operator) it is E
    * and not H that ends a row block, and the fewer rows a block has, the thinner its cells: a larger
-   * E bins more entries in longer runs.  But one wave sums a row block, at some 0.3e9 products per
-   * second, so the largest blocks must stay well below the time of the whole pass (all products at
-   * some 500e9 per second).  Unless set: 3e-4 of the block's entries, as a power of two between 65536
-   * and 524288.  R-MAT scale 26 (1.13e9 entries): 6.54 ms per product with E = 65536, 6.16 with 131072,
-   * 5.97 with 262144 (5.88 with the larger tasks above), 5.86 / 5.91 with 393216 / 524288, 7.24 with
-   * 1048576; scale 24 (2.8e8 entries): 1.41 ms with 65536 or 131072, 1.73 with 262144, 2.46 with 524288. */
+   * E bins more entries in longer runs.  But one wave sums a row block, so the largest blocks must
+   * stay well below the time of the whole pass.  Unless set: 1e-3 of the block's entries, as a power
+   * of two between 65536 and 1048576.  R-MAT scale 26 (1.13e9 entries, H = 4096): 4.87 ms per product
+   * with E = 262144, 4.79 with 524288, 4.77 with 1048576; scale 24 (2.8e8 entries): 1.165 ms with
+   * 65536, 1.127 with 131072, 1.100 with 262144. */
   int64_t E = env_int("KSG_BINS_E", 0);
   if (E <= 0) {
     E = 65536;
-    while (E < 524288 && (double)(2 * E) <= 3e-4 * (double)rowptr[nrows]) E *= 2;
+    while (E < 1048576 && (double)(2 * E) <= 1e-3 * (double)rowptr[nrows]) E *= 2;
   }
-  bins_build_host(B, nrows, ncols, rowptr, colidx, val, has_diag, dshift, lrows, lrp, lci, lva, H, E, maxW);
+  bins_build_host(B, nrows, ncols, rowptr, colidx, val, has_diag, dshift, lrows, lrp, lci, lva, H, E, maxW, colstage);
 }
 
 /* Host-side check of the binned layout, no device needed: y = A x for the CSR block given, formed
@@ -1034,7 +1069,14 @@ static int bins_to_device(ksg_ctx c, ksg_bins *B, const bins_host &Hb, const int
   B->threads = env_int("KSG_BINS_THREADS", 1024) / 64 * 64;
   if (B->threads < 64) B->threads = 64;
   if (B->threads > BINS_P1_THREADS) B->threads = BINS_P1_THREADS;
-  B->nent = Hb.nent; B->nreal = Hb.nreal; B->nent1 = Hb.nent1; B->nseg = Hb.nseg; B->nparts = Hb.nparts; B->nbins = Hb.nbins; B->ntasks = Hb.ntasks;
+  B->nent = Hb.nent; B->nreal = Hb.nreal; B->nent1 = Hb.nent1;
+  if (!Hb.task_stage.empty()) {
+    B->nstages = (int)Hb.task_stage.size() - 1;
+    B->task_stage = (int64_t *)malloc(Hb.task_stage.size() * sizeof(int64_t));
+    if (!B->task_stage) KSG_FAIL(KSG_ERR_MEM, "binned operator: out of host memory");
+    memcpy(B->task_stage, Hb.task_stage.data(), Hb.task_stage.size() * sizeof(int64_t));
+  }
+  B->nseg = Hb.nseg; B->nparts = Hb.nparts; B->nbins = Hb.nbins; B->ntasks = Hb.ntasks;
   B->nrows = Hb.nrows; B->dshift = Hb.dshift; B->W = Hb.W; B->H = Hb.H; B->vmode = Hb.vmode; B->vconst = Hb.vconst;
   KSG_HIP(hipSetDevice(c->device));
   KSG_CHK(bins_upload(&B->col16, Hb.col16.data(), Hb.col16.size()));
@@ -1100,14 +1142,14 @@ static int bins_device_max_w(ksg_ctx c, int *maxW) {
  * block's rows stand for (ksg_bins_mult is then given the same list on the device). */
 int ksg_bins_build(ksg_ctx c, ksg_bins *B, int64_t nrows, int64_t ncols, const int64_t *rowptr, const int32_t *colidx,
                    const double *val, bool has_diag, int64_t dshift, std::vector<int32_t> &lrows, std::vector<int64_t> &lrp,
-                   std::vector<int32_t> &lci, std::vector<double> &lva, const int32_t *rowmap) {
+                   std::vector<int32_t> &lci, std::vector<double> &lva, const int32_t *rowmap, const ksg_colstages *colstage) {
   memset(B, 0, sizeof(*B));
   lrows.clear(); lrp.clear(); lci.clear(); lva.clear();
   int maxW = 0;
   KSG_CHK(bins_device_max_w(c, &maxW));
   if (!maxW) return KSG_OK;                               /* too little LDS for a slice worth having: the block stays a CSR */
   bins_host Hb;
-  bins_build_sized(&Hb, nrows, ncols, rowptr, colidx, val, has_diag, dshift, lrows, lrp, lci, lva, maxW);
+  bins_build_sized(&Hb, nrows, ncols, rowptr, colidx, val, has_diag, dshift, lrows, lrp, lci, lva, maxW, colstage);
   if (!Hb.nent) return KSG_OK;
   const int rc = bins_to_device(c, B, Hb, rowmap);
   if (rc) {
@@ -1119,17 +1161,34 @@ int ksg_bins_build(ksg_ctx c, ksg_bins *B, int64_t nrows, int64_t ncols, const i
   return KSG_OK;
 }
 
-/* y = B x + d .* x on `st` (every row of the block is stored); with a row list, y[list] += B x. */
-int ksg_bins_mult(const ksg_bins *B, const double *x, int64_t ncols, double *y, hipStream_t st, const int32_t *d_rowmap) {
+/* The expand tasks of one stage of the block's column stages (stage < 0, or a block built without
+ * stages: all of them) on `st`. */
+int ksg_bins_expand(const ksg_bins *B, const double *x, int64_t ncols, hipStream_t st, int stage) {
   if (!B->nent) return KSG_OK;
-  const size_t lds1 = ((size_t)B->W + 1) * sizeof(double), lds2 = (size_t)B->H * sizeof(double);
-  const dim3 g1((unsigned)B->ntasks), b1((unsigned)B->threads);
+  int64_t t0 = 0, t1 = B->ntasks;
+  if (stage >= 0 && B->task_stage) {
+    if (stage >= B->nstages) return KSG_OK;
+    t0 = B->task_stage[stage]; t1 = B->task_stage[stage + 1];
+  } else if (stage > 0) return KSG_OK;
+  if (t1 <= t0) return KSG_OK;
+  const size_t lds1 = ((size_t)B->W + 1) * sizeof(double);
+  const dim3 g1((unsigned)(t1 - t0)), b1((unsigned)B->threads);
+  const int64_t *tasks = B->tasks + 3 * t0;
   if (B->vmode == 0)
-    hipLaunchKernelGGL(k_bins_expand<0>, g1, b1, lds1, st, B->tasks, B->col16, B->vidx, B->vtab, B->val, B->vconst, B->gfirst, B->runmask, B->rowmask, B->O, x, ncols, B->xe, B->W);
+    hipLaunchKernelGGL(k_bins_expand<0>, g1, b1, lds1, st, tasks, B->col16, B->vidx, B->vtab, B->val, B->vconst, B->gfirst, B->runmask, B->rowmask, B->O, x, ncols, B->xe, B->W);
   else if (B->vmode == 1)
-    hipLaunchKernelGGL(k_bins_expand<1>, g1, b1, lds1, st, B->tasks, B->col16, B->vidx, B->vtab, B->val, 1.0, B->gfirst, B->runmask, B->rowmask, B->O, x, ncols, B->xe, B->W);
+    hipLaunchKernelGGL(k_bins_expand<1>, g1, b1, lds1, st, tasks, B->col16, B->vidx, B->vtab, B->val, 1.0, B->gfirst, B->runmask, B->rowmask, B->O, x, ncols, B->xe, B->W);
   else
-    hipLaunchKernelGGL(k_bins_expand<2>, g1, b1, lds1, st, B->tasks, B->col16, B->vidx, B->vtab, B->val, 1.0, B->gfirst, B->runmask, B->rowmask, B->O, x, ncols, B->xe, B->W);
+    hipLaunchKernelGGL(k_bins_expand<2>, g1, b1, lds1, st, tasks, B->col16, B->vidx, B->vtab, B->val, 1.0, B->gfirst, B->runmask, B->rowmask, B->O, x, ncols, B->xe, B->W);
+  KSG_HIP(hipGetLastError());
+  return KSG_OK;
+}
+
+/* The sums of the slots the expand tasks wrote, per row block, on `st`: every row of the block is
+ * stored (y = B x + d .* x); with a row list, y[list] += B x. */
+int ksg_bins_finish(const ksg_bins *B, const double *x, double *y, hipStream_t st, const int32_t *d_rowmap) {
+  if (!B->nent) return KSG_OK;
+  const size_t lds2 = (size_t)B->H * sizeof(double);
   hipLaunchKernelGGL(k_bins_reduce, dim3((unsigned)B->nbins), dim3(64), lds2, st, B->binp0, B->binp1, B->bin_r0, B->bin_nr, B->rowloc, B->xe,
                      B->dv, x, B->dshift, y, B->nrows, B->part, d_rowmap);
   if (B->nlong)
@@ -1137,6 +1196,11 @@ int ksg_bins_mult(const ksg_bins *B, const double *x, int64_t ncols, double *y, 
                        B->long_first, (int)B->nlong, B->part, y);
   KSG_HIP(hipGetLastError());
   return KSG_OK;
+}
+
+int ksg_bins_mult(const ksg_bins *B, const double *x, int64_t ncols, double *y, hipStream_t st, const int32_t *d_rowmap) {
+  KSG_CHK(ksg_bins_expand(B, x, ncols, st, -1));
+  return ksg_bins_finish(B, x, y, st, d_rowmap);
 }
 
 /* Bytes one binned product moves: expand reads the 2-byte columns (+ value bytes), 20 bytes per

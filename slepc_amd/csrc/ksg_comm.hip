@@ -260,6 +260,39 @@ int ksg_comm_exchange(ksg_ctx c, ksg_mat A) {
   return exchange_device(c, A->d_send, A->sendoff.data(), A->d_ghost, A->recvoff.data(), c->comm_stream);
 }
 
+/* The halo exchange of one multiply in rounds: in round r every rank sends to rank + r and receives
+ * from rank - r (one matched pair per rank and round, the same order on all ranks), and the event of
+ * the source is recorded behind the round, so that work on that rank's share of the ghost buffer can
+ * start while the later rounds are still under way (MatMult_MPIAIJ's scatter-begin / diagonal /
+ * scatter-end / off-diagonal pattern behind src/sys/classes/st/impls/shift/shift.c:38, one step finer).
+ * Transports that deliver everything in one call record all events after it. */
+int ksg_comm_exchange_rounds(ksg_ctx c, ksg_mat A) {
+  const int P = c->nranks, me = c->rank;
+  if (P <= 1) return KSG_OK;
+  while ((int)c->ev_peer.size() < P) {
+    hipEvent_t e;
+    KSG_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    c->ev_peer.push_back(e);
+  }
+  if (c->comm_kind != KSG_COMM_RCCL) {
+    KSG_CHK(ksg_comm_exchange(c, A));
+    for (int p = 0; p < P; p++) if (p != me) KSG_HIP(hipEventRecord(c->ev_peer[(size_t)p], c->comm_stream));
+    return KSG_OK;
+  }
+  for (int r = 1; r < P; r++) {
+    const int to = (me + r) % P, from = (me - r + P) % P;
+    const int64_t ns = A->sendoff[(size_t)to + 1] - A->sendoff[(size_t)to], nr = A->recvoff[(size_t)from + 1] - A->recvoff[(size_t)from];
+    if (ns > 0 || nr > 0) {
+      KSG_NCCL(g_rccl.GroupStart());
+      if (ns > 0) KSG_NCCL(g_rccl.Send(A->d_send + A->sendoff[(size_t)to], (size_t)ns, k_ncclDouble, to, c->rccl_comm, c->comm_stream));
+      if (nr > 0) KSG_NCCL(g_rccl.Recv(A->d_ghost + A->recvoff[(size_t)from], (size_t)nr, k_ncclDouble, from, c->rccl_comm, c->comm_stream));
+      KSG_NCCL(g_rccl.GroupEnd());
+    }
+    KSG_HIP(hipEventRecord(c->ev_peer[(size_t)from], c->comm_stream));
+  }
+  return KSG_OK;
+}
+
 /* Set-up time exchange of host arrays (index lists encoded as doubles). */
 int ksg_comm_exchange_host(ksg_ctx c, const double *send, const int64_t *sendoff, double *recv,
                            const int64_t *recvoff) {

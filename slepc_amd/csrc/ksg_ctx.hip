@@ -135,6 +135,8 @@ extern "C" int ksg_ctx_destroy(ksg_ctx c) {
   if (c->h_red) hipHostFree(c->h_red);
   if (c->ev_x_ready) hipEventDestroy(c->ev_x_ready);
   if (c->ev_halo_done) hipEventDestroy(c->ev_halo_done);
+  for (hipEvent_t e : c->ev_peer) hipEventDestroy(e);
+  c->ev_peer.clear();
   if (c->comm_stream) hipStreamDestroy(c->comm_stream);
   if (c->stream) hipStreamDestroy(c->stream);
   delete c;

@@ -152,6 +152,7 @@ struct ksg_ctx_s {
   hipStream_t stream;        /* compute */
   hipStream_t comm_stream;   /* halo pack + exchange */
   hipEvent_t ev_x_ready, ev_halo_done;
+  std::vector<hipEvent_t> ev_peer;   /* one per rank: that rank's share of a halo has arrived (exchange in rounds) */
   double *d_red;             /* device reduction buffer, KSG_RED_MAX doubles */
   double *h_red;             /* pinned host mirror */
   double *d_partial;         /* per-workgroup partial sums */
@@ -261,6 +262,8 @@ struct ksg_bins {
   uint64_t *rowmask;         /* per group: bit l = entry l opens a stretch (another row, a part, a row of 16 lanes) */
   int64_t *O;                /* per part: the slot of its first stretch                          */
   int64_t *tasks;            /* 3 per task: column block, first group, end group                 */
+  int64_t *task_stage;       /* host array, nstages + 1: the tasks of stage s of the column stages the block was built with are task_stage[s] .. task_stage[s+1] (NULL: one stage) */
+  int nstages;
   uint16_t *rowloc;          /* nent: row within the row block of every slot, in the reduce order */
   int64_t *binp0, *binp1;    /* nbins each: the products of a row block, in the reduce order; the blocks with the most products first */
   int32_t *bin_r0, *bin_nr;  /* first row and row count of every row block                       */
@@ -304,6 +307,7 @@ struct ksg_mat_s {
   double *h_ghost, *h_send;  /* pinned host staging (callback transport)       */
   int32_t *d_send_idx;       /* local indices to gather into d_send            */
   std::vector<int64_t> sendoff, recvoff;   /* nranks+1 each                    */
+  int halo_rounds;           /* the halo travels in rounds and the ghost block's expand tasks start as their sources arrive */
 };
 
 /* statistics / timing brackets */
@@ -317,15 +321,26 @@ int ksg_op_end(ksg_ctx ctx, int ev, double bytes, double flops);
 /* communicator primitives (ksg_comm.hip) */
 int ksg_comm_allreduce(ksg_ctx ctx, double *d_buf, double *h_out, int count, int op);
 int ksg_comm_exchange(ksg_ctx ctx, ksg_mat A);
+/* the same exchange in rounds, one source rank per round; ev_peer[source] is recorded on the
+ * communication stream when that rank's share of the ghost buffer has arrived.  Source of round r
+ * (1 .. nranks-1): (rank - r + nranks) % nranks. */
+int ksg_comm_exchange_rounds(ksg_ctx ctx, ksg_mat A);
 int ksg_comm_allreduce_host(ksg_ctx ctx, double *h_buf, int count, int op);
 int ksg_comm_exchange_host(ksg_ctx ctx, const double *send, const int64_t *sendoff,
                            double *recv, const int64_t *recvoff);
 
 /* binned part of a power-law block (ksg_bins.hip) */
+/* colstage (may be NULL): the stage in which every column of x becomes available, ascending
+ * column boundaries paired with stage numbers (column c with bound[i] <= c < bound[i+1] has stage
+ * stage[i]); the expand tasks are then grouped by the last stage their column block needs */
+struct ksg_colstages { std::vector<int64_t> bound; std::vector<int> stage; int nstages; };
 int ksg_bins_build(ksg_ctx c, ksg_bins *B, int64_t nrows, int64_t ncols, const int64_t *rowptr, const int32_t *colidx,
                    const double *val, bool has_diag, int64_t dshift, std::vector<int32_t> &lrows, std::vector<int64_t> &lrp,
-                   std::vector<int32_t> &lci, std::vector<double> &lva, const int32_t *rowmap);
+                   std::vector<int32_t> &lci, std::vector<double> &lva, const int32_t *rowmap, const ksg_colstages *colstage = NULL);
 int ksg_bins_mult(const ksg_bins *B, const double *x, int64_t ncols, double *y, hipStream_t st, const int32_t *d_rowmap);
+/* the two halves of ksg_bins_mult: the expand tasks of one stage (stage < 0: all), then the sums */
+int ksg_bins_expand(const ksg_bins *B, const double *x, int64_t ncols, hipStream_t st, int stage);
+int ksg_bins_finish(const ksg_bins *B, const double *x, double *y, hipStream_t st, const int32_t *d_rowmap);
 double ksg_bins_bytes(const ksg_bins *B);
 int ksg_bins_to_host(const ksg_bins *B, std::vector<int32_t> &rows, std::vector<int32_t> &cols, std::vector<double> &vals);
 void ksg_bins_free(ksg_bins *B);

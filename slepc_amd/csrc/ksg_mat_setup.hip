@@ -410,13 +410,13 @@ static bool is_power_law(int64_t ncols, int64_t nnz, const int32_t *colidx, col_
 
 /* Whether a block of a new operator (the local block, or the ghost block with the ghost buffer
  * as its x) gets a binned part (KSG_OPT_BINS): a
- * power-law operator (the test of the packing), and by default an x of 32 MiB or more (R-MAT scale 21,
- * 16 MiB: 0.26 ms per product as a CSR, 0.32 ms binned -- too few column blocks to fill the device;
- * scale 22: 0.51 and 0.44 ms; scale 23: 0.98 and 0.70 ms; scale 24: 2.09 and 1.42 ms; scale 26: 10.8 ms
- * and 5.89 ms; profiles/r02_spmv_rmat_binned.txt). */
+ * power-law operator (the test of the packing), and by default an x of 16 MiB or more (R-MAT scale 20,
+ * 8 MiB: 0.128 ms per product as a CSR and binned alike -- too few column blocks to fill the device;
+ * scale 21: 0.256 and 0.160 ms; scale 22: 0.504 and 0.258 ms; scale 24: 2.09 and 1.10 ms; scale 26:
+ * 10.8 and 4.79 ms; profiles/r03_spmv_rmat_binned.txt). */
 static bool bins_wanted(ksg_ctx c, int64_t ncols, int64_t nnz, const int32_t *colidx, col_counts *cc = NULL) {
   if (c->bins == 1 || ncols < 64 || ncols > (int64_t)INT32_MAX) return false;
-  if (c->bins == 0 && ncols < ((int64_t)32 << 20) / 8) return false;
+  if (c->bins == 0 && ncols < ((int64_t)16 << 20) / 8) return false;
   /* from 2^27 entries on the test is first made on every eighth stretch of 4096 entries (the same
    * entries whatever the number of host threads): a block that passes it needs no exact count at
    * all -- at R-MAT scale 26 the count is 1.0 s of a 4.3 s set-up -- and for one that fails it the
@@ -572,6 +572,7 @@ static int mat_create(ksg_ctx c, int64_t n, int64_t N, int64_t row0, int64_t nc,
   memset(&A->gbins, 0, sizeof(A->gbins));
   A->g_nhot = 0; A->d_g_hot_idx = NULL; A->d_g_xhot = NULL;
   A->nghost = A->nsend = 0;
+  A->halo_rounds = 0;
   A->d_ghost = A->d_send = A->h_ghost = A->h_send = NULL; A->d_send_idx = NULL;
   A->nhot = 0; A->d_hot_idx = NULL; A->d_xhot = NULL;
   const int P = c->nranks;
@@ -692,7 +693,21 @@ static int mat_create(ksg_ctx c, int64_t n, int64_t N, int64_t row0, int64_t nc,
     std::vector<int32_t> lrows, lci;
     std::vector<int64_t> lrp;
     std::vector<double> lva;
-    rc = ksg_bins_build(c, &A->gbins, A->no_rows, A->nghost, o_rp.data(), o_ci.data(), o_v.data(), false, 0, lrows, lrp, lci, lva, o_rows.data());
+    /* the slots of the ghost buffer arrive source by source (ksg_comm_exchange_rounds): source s in
+     * round (rank - s) mod P, which is the stage of its columns (KSG_HALO_ROUNDS=0: one exchange, one stage) */
+    ksg_colstages cst;
+    const char *hr = getenv("KSG_HALO_ROUNDS");
+    A->halo_rounds = !(hr && hr[0] == '0') && P > 2;
+    if (A->halo_rounds) {
+      cst.nstages = P - 1;
+      for (int p = 0; p < P; p++) {
+        cst.bound.push_back(A->recvoff[(size_t)p]);
+        cst.stage.push_back(p == c->rank ? 0 : (c->rank - p + P) % P - 1);
+      }
+      cst.bound.push_back(A->recvoff[(size_t)P]);
+    }
+    rc = ksg_bins_build(c, &A->gbins, A->no_rows, A->nghost, o_rp.data(), o_ci.data(), o_v.data(), false, 0, lrows, lrp, lci, lva, o_rows.data(),
+                        A->halo_rounds ? &cst : NULL);
     if (!rc && A->gbins.nent && !lrows.empty()) {
       for (size_t i = 0; i < lrows.size(); i++) lrows[i] = o_rows[(size_t)lrows[i]];      /* local rows of y */
       rc = rest_to_device(c, A->grest, A->nghost, lrows, lrp, lci, lva);

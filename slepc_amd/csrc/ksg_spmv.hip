@@ -539,7 +539,23 @@ static int mat_mult_raw(ksg_mat A, const double *x, double *y) {
     launch_tiles<2>(c->stream, cg.blk, xg, y, 0.0, 0.0, NULL, NULL, cg.nhot ? cg.d_xhot : NULL, (int32_t)cg.ncols, cg.d_rows);
   }
   KSG_HIP(hipGetLastError());
-  if (halo) {
+  if (halo && A->halo_rounds && A->gbins.nent) {
+    /* a ghost block that outweighs the local one (power-law operators): the halo travels in rounds,
+     * one source rank per round, and the expand tasks whose slices of the ghost buffer are complete
+     * start behind their round while the later rounds are still under way; the sums wait for all */
+    KSG_CHK(ksg_comm_exchange_rounds(c, A));
+    for (int r = 1; r < c->nranks; r++) {
+      const int from = (c->rank - r + c->nranks) % c->nranks;
+      KSG_HIP(hipStreamWaitEvent(c->stream, c->ev_peer[(size_t)from], 0));
+      KSG_CHK(ksg_bins_expand(&A->gbins, A->d_ghost, A->nghost, c->stream, r - 1));
+    }
+    KSG_CHK(ksg_bins_finish(&A->gbins, A->d_ghost, y, c->stream, A->o_rows));
+    for (const ksg_rest &cg : A->grest) {
+      if (cg.nhot) hipLaunchKernelGGL(k_gather, dim3(ksg_grid_for(cg.nhot)), dim3(KSG_BLOCK), 0, c->stream, (const double *)A->d_ghost, cg.d_hot_idx, cg.d_xhot, cg.nhot);
+      launch_tiles<2>(c->stream, cg.blk, A->d_ghost, y, 0.0, 0.0, NULL, NULL, cg.nhot ? cg.d_xhot : NULL, (int32_t)cg.ncols, cg.d_rows);
+    }
+    KSG_HIP(hipGetLastError());
+  } else if (halo) {
     KSG_CHK(ksg_comm_exchange(c, A));
     KSG_HIP(hipEventRecord(c->ev_halo_done, c->comm_stream));
     KSG_HIP(hipStreamWaitEvent(c->stream, c->ev_halo_done, 0));
@@ -627,8 +643,9 @@ extern "C" int ksg_mat_describe(ksg_mat A, char *buf, size_t len) {
     long long rows = 0, ent = 0;
     for (const ksg_rest &cg : A->grest) { rows += cg.nrows; ent += cg.blk.nnz; }
     snprintf(buf + k, len - (size_t)k, "; ghost block: %lld entries in %lld rows, %lld of them binned (LDS slices of the ghost buffer, %lld runs, %lld row blocks), "
-             "%lld remaining entries in %lld rows through the tile kernel", (long long)A->o_nnz, (long long)A->no_rows, (long long)A->gbins.nreal,
-             (long long)A->gbins.nseg, (long long)A->gbins.nbins, ent, rows);
+             "%lld remaining entries in %lld rows through the tile kernel%s", (long long)A->o_nnz, (long long)A->no_rows, (long long)A->gbins.nreal,
+             (long long)A->gbins.nseg, (long long)A->gbins.nbins, ent, rows,
+             A->halo_rounds ? "; halo in rounds by source rank, the expand tasks of a source start when its share has arrived" : "");
   } else if (A->ctx->nranks > 1 && k > 0 && (size_t)k < len)
     snprintf(buf + k, len - (size_t)k, "; ghost block: %lld entries in %lld rows through the same tile kernel (%lld/%lld/%lld tiles, %lld packed)",
              (long long)A->o_nnz, (long long)A->no_rows, (long long)A->ghost.n_stream, (long long)A->ghost.n_group, (long long)A->ghost.n_long,

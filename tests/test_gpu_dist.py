@@ -95,6 +95,22 @@ def test_rmat_binned_blocks_match_single(ranks):
     assert any(m and int(m.group(3)) > 0.5 * int(m.group(1)) for m in binned_ghost), many["variant"]
 
 
+def test_halo_in_rounds_gives_the_same_bits():
+    """A binned ghost block on three or more ranks gets its halo in rounds, one source rank per round, and
+    starts the expand tasks of a source when that source's share of the ghost buffer has arrived; the sums
+    are formed afterwards as ever, so the product and the solve are bit for bit those of the single
+    exchange (KSG_HALO_ROUNDS=0)."""
+    env = {"KSG_SPMV_BINS": "2", "KSG_BINS_W": "512", "KSG_BINS_H": "128", "KSG_BINS_E": "1024", "KSG_BINS_T": "2"}
+    for ranks in (3, 8):
+        a = run_ranks("gpu", "rmat_nnz", ranks, extra_env=env)
+        b = run_ranks("gpu", "rmat_nnz", ranks, extra_env=dict(env, KSG_HALO_ROUNDS="0"))
+        assert any("halo in rounds" in d for d in a["variant"]), a["variant"]
+        assert not any("halo in rounds" in d for d in b["variant"])
+        assert a["reason"] == b["reason"] == 1
+        assert np.array_equal(np.array(a["y"]), np.array(b["y"]))
+        assert a["values"] == b["values"]
+
+
 @pytest.mark.parametrize("case,ranks", [("svd_tall", 2), ("svd_wide", 3)])
 def test_svd_ranks_match_single(case, ranks):
     """Rectangular operator with rows and columns split over the ranks, its transpose built

@@ -78,3 +78,64 @@ def test_noalloc_limits(gpu_ctx):
         ctx.vec_free(p)
     G.destroy()
     G2.destroy()
+
+
+def test_noalloc_under_stream_capture(gpu_ctx):
+    """The entry point inside hipStreamBeginCapture ... hipStreamEndCapture on the library's stream, in the
+    global capture mode in which any hipMalloc (from any thread) is an error that ends the capture: the
+    call is captured, the graph replays it, and the result is X^T y -- against numpy to rounding and
+    against the allocating path bit for bit.  Free device memory is the same before and after."""
+    import ctypes as C
+    from slepc_amd import ksgpu
+    ctx = gpu_ctx
+    hip = C.CDLL("libamdhip64.so")
+    n, m = 200003, 40
+    rng = np.random.default_rng(21)
+    Xa, ya = rng.standard_normal((n, m)), rng.standard_normal(n)
+    G = ksgpu.DeviceBV(ctx, n, m)
+    G.from_numpy(Xa)
+    G.set_active(2, 37)
+    yd, qd = ctx.vec_alloc(n), ctx.vec_alloc(64)
+    ctx.upload(yd, ya)
+    want = G.dotvec(yd, local=True)
+    ctx.vec_set(qd, np.nan, 64)
+    ctx.sync()
+    stream = C.c_void_p(ctx.lib.ksg_ctx_stream(ctx.h))
+
+    def free_bytes():
+        f, t = C.c_size_t(), C.c_size_t()
+        assert hip.hipMemGetInfo(C.byref(f), C.byref(t)) == 0
+        return f.value
+
+    before = free_bytes()
+    assert hip.hipStreamBeginCapture(stream, 0) == 0          # hipStreamCaptureModeGlobal
+    try:
+        G.dotvec_noalloc(yd, qd)                              # raises if anything in it is illegal under capture
+    finally:
+        graph = C.c_void_p()
+        rc_end = hip.hipStreamEndCapture(stream, C.byref(graph))
+    assert rc_end == 0 and graph.value
+    assert free_bytes() == before                            # the captured call took no device memory
+    assert np.isnan(ctx.download(qd, 64)).all()              # captured, not executed
+    gexec = C.c_void_p()
+    assert hip.hipGraphInstantiate(C.byref(gexec), graph, None, None, C.c_size_t(0)) == 0
+    for _ in range(2):
+        ctx.vec_set(qd, np.nan, 64)
+        ctx.sync()
+        assert hip.hipGraphLaunch(gexec, stream) == 0
+        ctx.sync()
+        got = ctx.download(qd, 64)
+        assert np.array_equal(got[:35], want)
+        assert np.isnan(got[35:]).all()
+    ref = Xa[:, 2:37].T @ ya
+    assert np.all(np.abs(got[:35] - ref) <= 1e-12 * (np.abs(Xa[:, 2:37]).T @ np.abs(ya)))
+    hip.hipGraphExecDestroy(gexec)
+    hip.hipGraphDestroy(graph)
+    # outside a capture: free memory unchanged by a call
+    b2 = free_bytes()
+    G.dotvec_noalloc(yd, qd)
+    ctx.sync()
+    assert free_bytes() == b2
+    for p in (yd, qd):
+        ctx.vec_free(p)
+    G.destroy()
