@@ -173,7 +173,7 @@ def workload_rows(args, size, rank):
     return "R-MAT scale %d graph Laplacian (%d rows)" % (g, N), N, row0, row1, None, part
 
 
-def generate(args, N, row0, row1, dims, rank):
+def generate(args, N, row0, row1, dims, rank, size=1, dist=None):
     from slepc_amd import matgen
     if args.workload == "ex2":
         return matgen.laplacian2d(dims[0], dims[1], row0, row1)
@@ -182,6 +182,10 @@ def generate(args, N, row0, row1, dims, rank):
     if args.workload == "markov":
         return matgen.markov(args.grid, row0, row1)
     progress = (lambda t: print(t, file=sys.stderr, flush=True)) if rank == 0 and args.grid > 23 else None
+    if size > 1:
+        # every rank draws an eighth (1/size) of the edge list and the edges travel to the owners of their rows
+        starts = matgen.balanced_row_blocks(matgen.rmat_row_weights(args.grid), size, args.rmat_row_weight)
+        return matgen.rmat_laplacian_distributed(args.grid, starts, rank, dist, progress=progress)
     return matgen.rmat_laplacian(args.grid, row0=row0, row1=row1, progress=progress)
 
 
@@ -288,7 +292,7 @@ def main():
     if args.eps_type != "krylovschur":
         solver = "explicitly restarted " + args.eps_type.capitalize()
     wname = "%s, %s nev=%d" % (wname, solver, args.nev)
-    rp, ci, va = generate(args, N, row0, row1, dims, rank)
+    rp, ci, va = generate(args, N, row0, row1, dims, rank, size, dist)
     if rank == 0:
         print("operator: %s, %d local rows, %d local entries, generated in %.1f s" % (
             wname, row1 - row0, int(rp[-1]), time.perf_counter() - t_gen), file=sys.stderr, flush=True)

@@ -104,42 +104,40 @@ def markov(m, row0=0, row1=None):
     return _finish(row1 - row0, rows, np.concatenate(cols), np.concatenate(vals))
 
 
-def rmat_laplacian(scale, edge_factor=8, a=0.57, b=0.19, c=0.19, seed=0x5EED, row0=0, row1=None,
-                   chunk=1 << 24, progress=None):
-    """Graph Laplacian D - A of a symmetrised R-MAT graph with 2**scale vertices:
-    power-law row lengths, unit weights, duplicates and self-loops removed.
-    `progress(text)` is called every few seconds of work (large scales take minutes)."""
+def rmat_chunk_edges(scale, chunk_index, edge_factor=8, a=0.57, b=0.19, c=0.19, seed=0x5EED, chunk=1 << 24):
+    """Edges number chunk_index*chunk .. of the R-MAT edge list (source, destination; self-loops
+    removed), each chunk from its own place in the one Philox stream the whole list is drawn from:
+    chunk k starts scale*chunk*k draws into it, and the generator skips there (4 draws per counter
+    step), so any subset of the chunks can be drawn on its own -- by another rank, in any order --
+    and the list is the same."""
     N = 1 << scale
-    row1 = N if row1 is None else row1
     ne = edge_factor * N
-    rng = np.random.Generator(np.random.Philox(key=seed))
-    src_l, dst_l = [], []
-    done = 0
-    while done < ne:
-        cnt = min(chunk, ne - done)
-        src = np.zeros(cnt, dtype=np.int64)
-        dst = np.zeros(cnt, dtype=np.int64)
-        for _ in range(scale):
-            u = rng.random(cnt)
-            right = u >= a + c          # quadrant b or d: column bit set
-            down = ((u >= a) & (u < a + c)) | (u >= a + b + c)   # quadrant c or d: row bit set
-            src = (src << 1) | down
-            dst = (dst << 1) | right
-        keep = src != dst
-        src, dst = src[keep], dst[keep]
-        s2 = np.concatenate((src, dst))
-        d2 = np.concatenate((dst, src))
-        mine = (s2 >= row0) & (s2 < row1)
-        src_l.append(s2[mine])
-        dst_l.append(d2[mine])
-        done += cnt
-        if progress:
-            progress("R-MAT: %d of %d edges drawn" % (done, ne))
-    src = np.concatenate(src_l)
-    dst = np.concatenate(dst_l)
-    del src_l, dst_l
-    key = src * N + dst
-    del src, dst
+    done = chunk_index * chunk
+    cnt = min(chunk, ne - done)
+    if cnt <= 0:
+        return np.zeros(0, dtype=np.int64), np.zeros(0, dtype=np.int64)
+    bg = np.random.Philox(key=seed)
+    bg.advance(chunk_index * scale * chunk // 4)
+    rng = np.random.Generator(bg)
+    src = np.zeros(cnt, dtype=np.int64)
+    dst = np.zeros(cnt, dtype=np.int64)
+    for _ in range(scale):
+        u = rng.random(cnt)
+        right = u >= a + c          # quadrant b or d: column bit set
+        down = ((u >= a) & (u < a + c)) | (u >= a + b + c)   # quadrant c or d: row bit set
+        src = (src << 1) | down
+        dst = (dst << 1) | right
+    keep = src != dst
+    return src[keep], dst[keep]
+
+
+def rmat_num_chunks(scale, edge_factor=8, chunk=1 << 24):
+    return -(-(edge_factor << scale) // chunk)
+
+
+def _rmat_csr_from_keys(key, N, row0, row1, progress=None):
+    """CSR of rows [row0, row1) of the graph Laplacian from the keys source*N + destination of the
+    directed edges of those rows (duplicates allowed, any order)."""
     # duplicates removed bucket by bucket of the row range (the same sorted result as one
     # np.unique over everything, in pieces small enough to report progress between them)
     nbuck = max(1, min(16, key.size >> 26))
@@ -178,6 +176,80 @@ def rmat_laplacian(scale, edge_factor=8, a=0.57, b=0.19, c=0.19, seed=0x5EED, ro
     if progress:
         progress("R-MAT: CSR of %d rows, %d entries built" % (n_local, total))
     return rowptr, colidx, val
+
+
+def rmat_laplacian(scale, edge_factor=8, a=0.57, b=0.19, c=0.19, seed=0x5EED, row0=0, row1=None,
+                   chunk=1 << 24, progress=None):
+    """Graph Laplacian D - A of a symmetrised R-MAT graph with 2**scale vertices:
+    power-law row lengths, unit weights, duplicates and self-loops removed.
+    `progress(text)` is called every few seconds of work (large scales take minutes)."""
+    N = 1 << scale
+    row1 = N if row1 is None else row1
+    ne = edge_factor * N
+    keys = []
+    for k in range(rmat_num_chunks(scale, edge_factor, chunk)):
+        src, dst = rmat_chunk_edges(scale, k, edge_factor, a, b, c, seed, chunk)
+        s2 = np.concatenate((src, dst))
+        d2 = np.concatenate((dst, src))
+        mine = (s2 >= row0) & (s2 < row1)
+        keys.append(s2[mine] * N + d2[mine])
+        if progress:
+            progress("R-MAT: %d of %d edges drawn" % (min((k + 1) * chunk, ne), ne))
+    key = np.concatenate(keys)
+    del keys
+    return _rmat_csr_from_keys(key, N, row0, row1, progress)
+
+
+def rmat_laplacian_distributed(scale, starts, rank, dist, edge_factor=8, a=0.57, b=0.19, c=0.19, seed=0x5EED,
+                               chunk=1 << 24, progress=None):
+    """The rows starts[rank] .. starts[rank+1] of `rmat_laplacian(scale)` when all ranks of the
+    torch.distributed group `dist` call this together: every rank draws a share of the chunks of
+    the edge list (chunk k on rank k mod P), sorts its edges by the rank that owns their row and
+    sends them there, so nobody draws the whole list.  The matrix is the one a single process
+    generates (duplicates are removed after the exchange, and sorting makes the order of arrival
+    irrelevant)."""
+    import torch
+    N = 1 << scale
+    P = len(starts) - 1
+    bounds = np.asarray(starts, dtype=np.int64)
+    out = [[] for _ in range(P)]
+    nch = rmat_num_chunks(scale, edge_factor, chunk)
+    for k in range(rank, nch, P):
+        src, dst = rmat_chunk_edges(scale, k, edge_factor, a, b, c, seed, chunk)
+        s2 = np.concatenate((src, dst))
+        d2 = np.concatenate((dst, src))
+        owner = np.searchsorted(bounds, s2, side="right") - 1
+        order = np.argsort(owner, kind="stable")
+        key = (s2 * N + d2)[order]
+        cuts = np.searchsorted(owner[order], np.arange(P + 1))
+        for p in range(P):
+            if cuts[p + 1] > cuts[p]:
+                out[p].append(key[cuts[p]:cuts[p + 1]])
+        if progress:
+            progress("R-MAT: chunk %d of %d drawn on rank %d" % (k + 1, nch, rank))
+    send = [np.concatenate(o) if o else np.zeros(0, dtype=np.int64) for o in out]
+    del out
+    counts = torch.tensor([len(x) for x in send], dtype=torch.int64)
+    allc = [torch.zeros(P, dtype=torch.int64) for _ in range(P)]
+    dist.all_gather(allc, counts)
+    recv = [np.empty(int(allc[p][rank]), dtype=np.int64) for p in range(P)]
+    recv[rank] = send[rank]
+    reqs = []
+    for p in range(P):
+        if p == rank:
+            continue
+        if recv[p].size:
+            reqs.append(dist.irecv(torch.from_numpy(recv[p]), src=p))
+        if send[p].size:
+            reqs.append(dist.isend(torch.from_numpy(send[p]), dst=p))
+    for r in reqs:
+        r.wait()
+    del send
+    key = np.concatenate(recv)
+    del recv
+    if progress:
+        progress("R-MAT: rank %d received %d edges of its rows" % (rank, key.size))
+    return _rmat_csr_from_keys(key, N, int(starts[rank]), int(starts[rank + 1]), progress)
 
 
 def slab_rows(dims, nranks, rank):

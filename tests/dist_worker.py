@@ -34,6 +34,8 @@ def run():
     rank, _, size = kdist.env_rank()
     dist = kdist.init_process_group() if size > 1 else None
 
+    if case == "rmat_gen":
+        return rmat_gen_main(out, rank, size, dist)
     if case.startswith("svd_"):
         return svd_main(mode, case, out, rank, size, dist)
     if case == "bv_ip":
@@ -194,6 +196,29 @@ def run():
     Am.destroy()
     if ctx:
         ctx.close()
+
+
+def rmat_gen_main(out, rank, size, dist):
+    """Every rank draws its share of the chunks of the R-MAT edge list and receives the edges of its
+    rows: the rows must be those a single process generates, whatever the chunk size."""
+    import numpy as np
+    import torch
+    from slepc_amd import matgen as mg
+    scale = 12
+    starts = mg.balanced_row_blocks(mg.rmat_row_weights(scale), size, 4.0)
+    same = 1
+    for chunk in (1 << 12, 1 << 13, 1 << 24):
+        got = mg.rmat_laplacian_distributed(scale, starts, rank, dist, chunk=chunk)
+        want = mg.rmat_laplacian(scale, row0=starts[rank], row1=starts[rank + 1], chunk=chunk)
+        same &= int(all(np.array_equal(a, b) and a.dtype == b.dtype for a, b in zip(got, want)))
+    whole = mg.rmat_laplacian(scale)                       # the chunk size does not change the matrix either
+    a, b = starts[rank], starts[rank + 1]
+    same &= int(np.array_equal(got[0], whole[0][a:b + 1] - whole[0][a]) and np.array_equal(got[1], whole[1][whole[0][a]:whole[0][b]]))
+    flag = torch.tensor([same], dtype=torch.int64)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    if rank == 0:
+        with open(out, "w") as f:
+            json.dump({"same": int(flag[0]), "ranks": size, "rows": [int(starts[r + 1] - starts[r]) for r in range(size)]}, f)
 
 
 def bv_ip_main(mode, out, rank, size, dist):

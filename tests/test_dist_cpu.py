@@ -27,3 +27,12 @@ def test_three_ranks_uneven_rows():
     three = run_ranks("cpu", "lap3d", 3)
     for a, b in zip(one["values"][:5], three["values"][:5]):
         assert abs(a[0] - b[0]) <= 1e-10 * abs(a[0])
+
+
+@pytest.mark.parametrize("ranks", [2, 3])
+def test_rmat_rows_generated_by_all_ranks_together(ranks):
+    """`bench.py --workload rmat --gpus N`: every rank draws 1/N of the edge list (chunks of the one
+    random stream, each reached by skipping ahead) and the edges travel to the owners of their rows;
+    the rows are bit for bit those of the single-process generator."""
+    r = run_ranks("cpu", "rmat_gen", ranks)
+    assert r["same"] == 1 and r["ranks"] == ranks and sum(r["rows"]) == 1 << 12
