@@ -4,8 +4,11 @@ reference path (``oracle.eps.EPS``: the control flow of krylovschur.c:169-288 / 
 on the compiled row-parallel kernels of ``oracle/ckern.c``), written as fixtures the GPU tests
 compare the product with (``tests/test_gpu_converged.py``).  CPU only; run in the build container:
 
-    python tests/golden/make_converged_fixtures.py markov 3000 [threads]
-    python tests/golden/make_converged_fixtures.py rmat 24 [threads]
+    python tests/golden/make_converged_fixtures.py markov 3000 [threads [output directory]]
+    python tests/golden/make_converged_fixtures.py rmat 24 [threads [output directory]]
+
+(The scale-26 fixture was made by the same script on the host cores of the GPU box -- no GPU involved -- because
+the build container's sessions did not last the twelve minutes it takes; the output directory is for that.)
 
 * markov m: ex5's Markov chain (ex5.c:150-193), nonsymmetric, largest real part, nev = 16
   (ncv = 32), start vector e0 + e1 (ex5.c:86-94), tol 1e-12 -- the tolerance at which the
@@ -94,7 +97,7 @@ def main():
            "nconv_history": hist,
            "made_by": "tests/golden/make_converged_fixtures.py %s %d: oracle.eps.EPS on oracle/ckern.c, %d threads, %.0f s" % (
                kind, size, threads, secs)}
-    path = os.path.join(HERE, "converged_%s%d.json" % (kind, size))
+    path = os.path.join(sys.argv[4] if len(sys.argv) > 4 else HERE, "converged_%s%d.json" % (kind, size))
     with open(path, "w") as f:
         json.dump(out, f, indent=1)
     print("wrote %s: %d restarts, %d converged, max residual %.3e, %.0f s" % (path, o.its, o.nconv, max(errs or [0]), secs))
