@@ -65,13 +65,14 @@ def test_markov_3000_converged_eigenvalues(gpu_ctx):
     A.destroy()
 
 
-def test_rmat_24_converged_eigenvalues(gpu_ctx):
-    """The graph Laplacian of the symmetrised R-MAT graph of scale 24 (16.7M rows, 2.8e8 entries: the largest
-    scale whose CPU solve fits the build container; the benchmark's matrix is the same generator at scale 26),
-    nev = 32, ncv = 64, tol 1e-10, hashed start vector; the operator is binned by the library's own choice."""
+@pytest.mark.parametrize("scale", [24, 26])
+def test_rmat_converged_eigenvalues(gpu_ctx, scale):
+    """The graph Laplacian of the symmetrised R-MAT graph of scale 24 (16.7M rows, 2.8e8 entries) and of scale 26
+    (67.1M rows, 1.13e9 entries: BASELINE configuration 5's own matrix), nev = 32, ncv = 64, tol 1e-10, hashed start
+    vector; the operator is binned by the library's own choice.  Generating the scale-26 matrix takes two minutes."""
     from slepc_amd import ksgpu, kseps as K, matgen
-    fx = _fixture("converged_rmat24.json")
-    rp, ci, va = matgen.rmat_laplacian(24)
+    fx = _fixture("converged_rmat%d.json" % scale)
+    rp, ci, va = matgen.rmat_laplacian(scale)
     n = len(rp) - 1
     assert n == fx["rows"] and int(rp[-1]) == fx["entries"] and _checksum(rp, ci) == fx["colidx_checksum"]
     A = K.Mat.create_aij_hip(gpu_ctx, rp, ci, va)
