@@ -135,11 +135,19 @@ __device__ __forceinline__ void bins_expand_finish(const bins_step &s, int64_t g
   }
 #pragma unroll
   for (int j = 0; j < BINS_P1_UNROLL; j++) {
+    /* a step in which no lane would take anything is left out, and with it the steps after it (a
+     * group of the cold columns has nothing but stretches of one entry: no step at all) */
     const uint64_t f1 = s.sm[j], f2 = f1 | (f1 << 1), f4 = f2 | (f2 << 2), f8 = f4 | (f4 << 4);
-    a[j] += bins_keep_if(bins_row_shr<1>(0.0, a[j]), ~f1);
-    a[j] += bins_keep_if(bins_row_shr<2>(0.0, a[j]), ~f2);
-    a[j] += bins_keep_if(bins_row_shr<4>(0.0, a[j]), ~f4);
-    a[j] += bins_keep_if(bins_row_shr<8>(0.0, a[j]), ~f8);
+    if (~f1) {
+      a[j] += bins_keep_if(bins_row_shr<1>(0.0, a[j]), ~f1);
+      if (~f2) {
+        a[j] += bins_keep_if(bins_row_shr<2>(0.0, a[j]), ~f2);
+        if (~f4) {
+          a[j] += bins_keep_if(bins_row_shr<4>(0.0, a[j]), ~f4);
+          if (~f8) a[j] += bins_keep_if(bins_row_shr<8>(0.0, a[j]), ~f8);
+        }
+      }
+    }
   }
 #pragma unroll
   for (int j = 0; j < BINS_P1_UNROLL; j++) {
@@ -735,9 +743,15 @@ static void bins_build_host(bins_host *B, int64_t nrows, int64_t ncols, const in
   ksg_hvec<int32_t> rslots((size_t)nruns);                /* slots of run j, fill included */
   ksg_hvec<uint8_t> rfill((size_t)nruns);                 /* its fill entries */
   std::vector<int64_t> clen((size_t)NC, 0), cparts((size_t)NC, 0);
+  /* the column blocks in CT consecutive parts of about as many entries each (the blocks of the hub
+   * columns hold many times the entries of the others) */
   const int CT = (int)std::min<int64_t>(NT, NC);
-  ksg_parallel(CT, [&](int t, int nt) {
-    for (int64_t cb = NC * t / nt; cb < NC * (t + 1) / nt; cb++) {
+  std::vector<int64_t> cbnd((size_t)CT + 1, NC);
+  for (int t = 0; t <= CT; t++)
+    cbnd[(size_t)t] = t == 0 ? 0 : t == CT ? NC : (int64_t)(std::lower_bound(rawpos.begin(), rawpos.end(), B->nreal / CT * t) - rawpos.begin());
+  for (int t = 1; t <= CT; t++) cbnd[(size_t)t] = std::max(std::min(cbnd[(size_t)t], NC), cbnd[(size_t)t - 1]);
+  ksg_parallel(CT, [&](int t, int) {
+    for (int64_t cb = cbnd[(size_t)t]; cb < cbnd[(size_t)t + 1]; cb++) {
       int64_t q = 0, parts = 0;
       for (int64_t j = runpos[(size_t)cb]; j < runpos[(size_t)cb + 1]; j++) {
         const bins_seg &s = S[(size_t)sof[(size_t)j]];
@@ -785,8 +799,8 @@ static void bins_build_host(bins_host *B, int64_t nrows, int64_t ncols, const in
   else { val1.resize((size_t)nent1); pad.resize((size_t)nent1); }
   B->gfirst.resize((size_t)ngroups); B->runmask.resize((size_t)ngroups); B->rowmask.resize((size_t)ngroups);
   B->O.resize((size_t)nparts);
-  ksg_parallel(CT, [&](int t, int nt) {
-    for (int64_t cb = NC * t / nt; cb < NC * (t + 1) / nt; cb++) {
+  ksg_parallel(CT, [&](int t, int) {
+    for (int64_t cb = cbnd[(size_t)t]; cb < cbnd[(size_t)t + 1]; cb++) {
       int64_t p = cpos[(size_t)cb], part = partbase[(size_t)cb];
       uint64_t rm = 0, sm = 0;
       int gstarts = 0;                                     /* stretch starts of the current group so far */
@@ -947,7 +961,7 @@ static void bins_emulate(const bins_host &B, const double *x, int64_t ncols, dou
         a[l] = prod;
       }
       uint64_t F = sm;                                       /* a stretch starts in the window of N lanes that ends at the lane */
-      for (int N = 1; N < 16; N *= 2) {                      /* the segmented scan over rows of 16 lanes, step by step as the lanes do it */
+      for (int N = 1; N < 16 && ~F; N *= 2) {                /* the segmented scan over rows of 16 lanes, step by step as the lanes do it; a step no lane takes part in is left out */
         memcpy(a0, a, sizeof(a));
         for (int l = 0; l < 64; l++) {
           const bool take = (l & 15) >= N && !((F >> l) & 1ull);
