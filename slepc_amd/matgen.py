@@ -8,7 +8,20 @@ These follow the matrix-filling loops of the reference's example programs
 134M-row cases are practical; every generator takes the range of rows
 ``[row0, row1)`` owned by the caller, like ``MatGetOwnershipRange`` does there.
 """
+import os
+from concurrent.futures import ThreadPoolExecutor
+
 import numpy as np
+
+
+def _threads():
+    """Host threads for the generators' passes (numpy releases the interpreter lock in them):
+    OMP_NUM_THREADS when set, else the machine's, at most 16."""
+    try:
+        n = int(os.environ.get("OMP_NUM_THREADS", "0"))
+    except ValueError:
+        n = 0
+    return max(1, min(16, n or (os.cpu_count() or 1)))
 
 
 def _finish(n_local, rows, cols, vals):
@@ -135,23 +148,42 @@ def rmat_num_chunks(scale, edge_factor=8, chunk=1 << 24):
     return -(-(edge_factor << scale) // chunk)
 
 
-def _rmat_csr_from_keys(key, N, row0, row1, progress=None):
-    """CSR of rows [row0, row1) of the graph Laplacian from the keys source*N + destination of the
-    directed edges of those rows (duplicates allowed, any order)."""
-    # duplicates removed bucket by bucket of the row range (the same sorted result as one
-    # np.unique over everything, in pieces small enough to report progress between them)
-    nbuck = max(1, min(16, key.size >> 26))
+def _rmat_bucket_edges(N, row0, row1, nbuck):
+    return np.array([(row0 + (row1 - row0) * i // nbuck) * N for i in range(nbuck + 1)], dtype=np.int64)
+
+
+def _rmat_split_keys(key, edges):
+    """The keys cut into the row ranges edges[i] .. edges[i+1] (a list of arrays, any order within)."""
+    nbuck = len(edges) - 1
     if nbuck == 1:
-        key = np.unique(key)
-    else:
-        edges = [(row0 + (row1 - row0) * i // nbuck) * N for i in range(nbuck + 1)]
-        parts = []
-        for i in range(nbuck):
-            parts.append(np.unique(key[(key >= edges[i]) & (key < edges[i + 1])]))
-            if progress:
-                progress("R-MAT: duplicates removed in %d of %d row ranges" % (i + 1, nbuck))
-        key = np.concatenate(parts)
-        del parts
+        return [key]
+    which = np.searchsorted(edges, key, side="right") - 1
+    order = np.argsort(which, kind="stable")
+    key = key[order]
+    cuts = np.searchsorted(which[order], np.arange(nbuck + 1))
+    return [key[cuts[i]:cuts[i + 1]] for i in range(nbuck)]
+
+
+def _rmat_csr_from_keys(pieces, N, row0, row1, progress=None):
+    """CSR of rows [row0, row1) of the graph Laplacian from the keys source*N + destination of the
+    directed edges of those rows (duplicates allowed, any order).  `pieces`: a list of lists of key
+    arrays, pieces[j][i] holding keys of row range i (`_rmat_split_keys`), or one array of keys."""
+    if isinstance(pieces, np.ndarray):
+        nbuck = max(1, min(64, pieces.size >> 24))
+        pieces = [_rmat_split_keys(pieces, _rmat_bucket_edges(N, row0, row1, nbuck))]
+    nbuck = len(pieces[0])
+
+    # duplicates removed row range by row range (the same sorted result as one np.unique over
+    # everything), the ranges on host threads
+    def dedup(i):
+        return np.unique(np.concatenate([p[i] for p in pieces]))
+    with ThreadPoolExecutor(_threads()) as ex:
+        parts = list(ex.map(dedup, range(nbuck)))
+    del pieces
+    if progress:
+        progress("R-MAT: duplicates removed in %d row ranges" % nbuck)
+    key = np.concatenate(parts) if nbuck > 1 else parts[0]
+    del parts
     # key is sorted by (row, column): the CSR follows without another sort, the diagonal entry
     # of each row (its degree) slipped in at its place among the columns
     n_local = row1 - row0
@@ -186,18 +218,25 @@ def rmat_laplacian(scale, edge_factor=8, a=0.57, b=0.19, c=0.19, seed=0x5EED, ro
     N = 1 << scale
     row1 = N if row1 is None else row1
     ne = edge_factor * N
-    keys = []
-    for k in range(rmat_num_chunks(scale, edge_factor, chunk)):
+    # row ranges the duplicates are removed in: every chunk's keys are cut into them where they are
+    # drawn, so that nothing but the chunks and the ranges -- both on host threads -- is ever sorted
+    expected = 2 * ne * (row1 - row0) // N
+    edges = _rmat_bucket_edges(N, row0, row1, max(1, min(64, expected >> 23)))
+
+    def chunk_keys(k):
         src, dst = rmat_chunk_edges(scale, k, edge_factor, a, b, c, seed, chunk)
         s2 = np.concatenate((src, dst))
         d2 = np.concatenate((dst, src))
-        mine = (s2 >= row0) & (s2 < row1)
-        keys.append(s2[mine] * N + d2[mine])
-        if progress:
-            progress("R-MAT: %d of %d edges drawn" % (min((k + 1) * chunk, ne), ne))
-    key = np.concatenate(keys)
-    del keys
-    return _rmat_csr_from_keys(key, N, row0, row1, progress)
+        if row0 != 0 or row1 != N:
+            mine = (s2 >= row0) & (s2 < row1)
+            s2, d2 = s2[mine], d2[mine]
+        return _rmat_split_keys(s2 * N + d2, edges)
+    nch = rmat_num_chunks(scale, edge_factor, chunk)
+    with ThreadPoolExecutor(_threads()) as ex:             # the chunks are independent: any order, the same list
+        keys = list(ex.map(chunk_keys, range(nch)))
+    if progress:
+        progress("R-MAT: %d edges drawn in %d chunks" % (ne, nch))
+    return _rmat_csr_from_keys(keys, N, row0, row1, progress)
 
 
 def rmat_laplacian_distributed(scale, starts, rank, dist, edge_factor=8, a=0.57, b=0.19, c=0.19, seed=0x5EED,
