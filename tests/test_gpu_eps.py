@@ -109,9 +109,9 @@ def test_eps_ex7_generalized_nonsymmetric(be):
 
 def test_eps_shift_sinvert_standard(be):
     from slepc_amd import matgen as mg
-    csr = mg.laplacian2d(23, 17)
-    a = np.arange(1, 24) * np.pi / 24
-    b = np.arange(1, 18) * np.pi / 18
+    csr = mg.laplacian2d(13, 11)
+    a = np.arange(1, 14) * np.pi / 14
+    b = np.arange(1, 12) * np.pi / 12
     lam = np.sort((4 - 2 * np.cos(a)[:, None] - 2 * np.cos(b)[None, :]).ravel())
     target = 2.2
     want = lam[np.argsort(np.abs(lam - target))][:5]
