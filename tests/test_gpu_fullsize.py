@@ -2,6 +2,8 @@
 where the oracle cannot run a whole solve in test time: known answers and
 size-independent properties for the kernels, and a short oracle-vs-product run of the
 first restarts with a narrower basis."""
+import os
+
 import numpy as np
 import pytest
 
@@ -284,14 +286,17 @@ def test_lap3d_256_first_restarts_match_oracle(gpu_ctx):
 def test_lap3d_512_first_restarts_match_oracle(gpu_ctx):
     """BASELINE configuration 3 at its full size on one GPU -- the 134M-row 7-point Laplacian on the 512^3
     grid, nev = 32, ncv = 64, default start vector: Ritz values and error estimates after each of the first
-    two restarts against the CPU restatement on its compiled kernels (70 GB of basis on the host, about a
-    minute on 16 threads).  Offsets beyond 2^31 elements, the row-code product at 134M rows and the
-    64 -> 32+ column restart product are all on this path."""
-    from oracle import ckern, eps as oeps
+    two restarts against those of the CPU restatement on its compiled kernels, kept as a fixture
+    (tests/golden/make_first_restarts_fixture.py: 70 GB of basis on the host and more than a minute on 16
+    threads, so it is not run inside the test).  Offsets beyond 2^31 elements, the row-code product at
+    134M rows and the 64 -> 32+ column restart product are all on this path."""
+    import json
     from slepc_amd import kseps as K, matgen
     g, nev, its = 512, 32, 2
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "lap3d512_oracle_first_restarts.json")) as f:
+        want = json.load(f)
     rp, ci, va = matgen.laplacian3d(g, g, g)
-    n = g ** 3
+    assert want["rows"] == g ** 3 and want["entries"] == int(rp[-1]) and want["nev"] == nev
     A = K.Mat.create_aij_hip(gpu_ctx, rp, ci, va)
     eps = K.EPS(gpu_ctx.h)
     eps.set_operators(A)
@@ -299,17 +304,14 @@ def test_lap3d_512_first_restarts_match_oracle(gpu_ctx):
     eps.set_dimensions(nev)
     eps.set_tolerances(0.0, its)
     got = {}
-    eps.set_monitor(lambda i, nconv, er, ei, ee, nest: got.__setitem__(i, (er[:nev].copy(), ee[:nev].copy(), nest)))
+    eps.set_monitor(lambda i, nconv, er, ei, ee, nest: got.__setitem__(i, (er[:nev].copy(), ee[:nev].copy(), nest, nconv)))
     eps.solve()
     eps.destroy()
     A.destroy()
-    kern = ckern.Kernels(16)
-    want = {}
-    o = oeps.EPS(kern.csr(rp, ci, va).mult, n, hermitian=True, nev=nev, max_it=its, bv_factory=kern.bv,
-                 monitor=lambda i, nconv, er, ei, ee, nv: want.__setitem__(i, (er[:nev].copy(), ee[:nev].copy(), nv)))
-    o.solve()
-    assert sorted(got) == sorted(want) == [1, 2]
+    assert sorted(got) == [1, 2] and sorted(want["restarts"]) == ["1", "2"]
     for i in (1, 2):
-        assert got[i][2] == want[i][2] == 64
-        assert np.abs(got[i][0] - want[i][0]).max() <= 1e-10 * 12.0
-        assert np.abs(got[i][1] - want[i][1]).max() <= 1e-7 * max(want[i][1].max(), 1e-30) + 1e-12
+        w = want["restarts"][str(i)]
+        wre, wee = np.array(w["re"]), np.array(w["errest"])
+        assert got[i][2] == w["nest"] == 64 and got[i][3] == w["nconv"]
+        assert np.abs(got[i][0] - wre).max() <= 1e-10 * 12.0
+        assert np.abs(got[i][1] - wee).max() <= 1e-7 * max(wee.max(), 1e-30) + 1e-12
