@@ -70,48 +70,57 @@ __device__ __forceinline__ int bins_lane_bit(uint64_t mask) {
   asm("v_cndmask_b32_e64 %0, 0, 1, %1" : "=v"(r) : "s"(mask));
   return r;
 }
-/* v where the lane's bit of the wave-uniform mask is set, +0.0 elsewhere */
-__device__ __forceinline__ double bins_keep_if(double v, uint64_t mask) {
-  const long long b = __double_as_longlong(v);
-  int lo = (int)b, hi = (int)(b >> 32);
-  asm("v_cndmask_b32_e64 %0, 0, %0, %2\n\tv_cndmask_b32_e64 %1, 0, %1, %2" : "+v"(lo), "+v"(hi) : "s"(mask));
-  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
-}
 /* number of set bits of a wave-uniform mask in the lanes below this one */
-__device__ __forceinline__ int bins_count_below(uint64_t mask) {
-  return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+__device__ __forceinline__ uint32_t bins_count_below(uint64_t mask) {
+  return __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+}
+/* One step of the segmented scan: the value of the lane N below within the lane's row of 16 lanes,
+ * +0.0 where that lane lies outside the row or where the lane's bit of the wave-uniform mask `stop`
+ * is set.  The move across lanes and the select are one instruction per half: the select takes its
+ * first operand through the data-parallel-primitive path (lanes without a source get zero) and the
+ * mask as its condition.  The operand may have been written by the instruction before: the two wait
+ * states such a read needs stand in front. */
+template <int N>
+__device__ __forceinline__ double bins_below_unless(double v, uint64_t stop) {
+  const long long b = __double_as_longlong(v);
+  const int lo = (int)b, hi = (int)(b >> 32), zero = 0;
+  int rlo, rhi;
+  asm("s_nop 1\n\t"
+      "s_mov_b64 vcc, %5\n\t"
+      "v_cndmask_b32_dpp %0, %2, %4, vcc row_shr:%6 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_cndmask_b32_dpp %1, %3, %4, vcc row_shr:%6 row_mask:0xf bank_mask:0xf bound_ctrl:1"
+      : "=&v"(rlo), "=&v"(rhi) : "v"(lo), "v"(hi), "v"(zero), "s"(stop), "n"(N) : "vcc");
+  return __longlong_as_double(((long long)rhi << 32) | (unsigned int)rlo);
 }
 
 /* What a wave holds of BINS_P1_UNROLL groups of 64 entries between its loads and its stores. */
 struct bins_step {
-  uint32_t u[BINS_P1_UNROLL], vi[BINS_P1_UNROLL];       /* column within the slice, value index  */
+  uint32_t u[BINS_P1_UNROLL];                           /* columns within the slice of the lane's entry and of its neighbour (one 4-byte load per pair of lanes) */
+  uint8_t vi[BINS_P1_UNROLL];                           /* value index (VM = 1)                    */
   double v[BINS_P1_UNROLL];                             /* value (VM = 2)                          */
-  int64_t d[BINS_P1_UNROLL];                            /* the slot the lane's stretch is written to */
+  int64_t o[BINS_P1_UNROLL];                            /* O of the lane's part */
   uint64_t sm[BINS_P1_UNROLL];                          /* the groups' stretch starts (scalar)      */
 };
 
 /* The loads of one step: BINS_P1_UNROLL groups from group g on (g is the same in every lane:
  * what a group shares comes through scalar loads).  A lane's part is the part of the group's
- * first entry plus the part starts among the lanes up to it; the slot of its stretch is the
- * part's entry of O plus the stretch starts among the lanes up to it (O has the starts that
- * precede the part taken off). */
+ * first entry plus the part starts among the lanes up to it (lane 0 never counts as one: the
+ * starts at lanes 1..lane are the bits below the lane of the mask moved down by one). */
 template <int VM, bool FULL>
 __device__ __forceinline__ void bins_expand_load(bins_step &s, int64_t g, int64_t g1, int lane, const uint16_t *__restrict__ col16,
-                                                 const uint8_t *__restrict__ vidx, const double *__restrict__ val, double vc,
+                                                 const uint8_t *__restrict__ vidx, const double *__restrict__ val,
                                                  const uint32_t *__restrict__ gfirst, const uint64_t *__restrict__ runmask,
                                                  const uint64_t *__restrict__ rowmask, const int64_t *__restrict__ O) {
 #pragma unroll
   for (int j = 0; j < BINS_P1_UNROLL; j++) {
-    s.u[j] = 0; s.vi[j] = 0; s.v[j] = vc; s.d[j] = 0; s.sm[j] = ~0ull;
+    s.u[j] = 0; s.vi[j] = 0; s.v[j] = 0.0; s.o[j] = 0; s.sm[j] = ~0ull;
     if (FULL || g + j < g1) {                                      /* uniform over the wave */
       const int64_t p = (g + j) * 64 + lane;
-      s.u[j] = __builtin_nontemporal_load(col16 + p);
+      s.u[j] = __builtin_nontemporal_load(reinterpret_cast<const uint32_t *>(col16) + (p >> 1));
       if (VM == 1) s.vi[j] = __builtin_nontemporal_load(vidx + p);
       if (VM == 2) s.v[j] = __builtin_nontemporal_load(val + p);
-      const uint64_t rm = runmask[g + j];
       s.sm[j] = rowmask[g + j];
-      const int part = (int)gfirst[g + j] + bins_count_below(rm) + bins_lane_bit(rm);
-      s.d[j] = O[part] + (bins_count_below(s.sm[j]) + bins_lane_bit(s.sm[j]));
+      s.o[j] = (O + gfirst[g + j])[bins_count_below(runmask[g + j] >> 1)];
     }
   }
 }
@@ -120,17 +129,21 @@ __device__ __forceinline__ void bins_expand_load(bins_step &s, int64_t g, int64_
  * stretch -- neighbouring entries of one row, within a row of 16 lanes -- are added up by a
  * segmented scan in registers: at step N a lane adds the value of the lane N below it when no
  * stretch starts in between (masks formed from the group's stretch starts by scalar operations),
- * and the last lane of a stretch writes the sum.  The products are rounded one by one (no
- * contraction with the additions), the additions come in the scan's fixed order. */
+ * and the last lane of a stretch writes the sum: slot O[part] + the stretch starts among the lanes
+ * up to it (O has the starts that precede the part taken off; lane 0 always starts a stretch, so
+ * the count is one plus the bits below the lane of the mask moved down by one -- the one is in xe1).
+ * The products are rounded one by one (no contraction with the additions), the additions come in
+ * the scan's fixed order. */
 template <int VM, bool FULL>
-__device__ __forceinline__ void bins_expand_finish(const bins_step &s, int64_t g, int64_t g1, const double *xs,
-                                                   const double *__restrict__ vtab, double *__restrict__ xe) {
+__device__ __forceinline__ void bins_expand_finish(const bins_step &s, int64_t g, int64_t g1, int half, const double *xs,
+                                                   const double *__restrict__ vtab, double vc, double *__restrict__ xe1) {
 #pragma clang fp contract(off)
   double a[BINS_P1_UNROLL];
 #pragma unroll
   for (int j = 0; j < BINS_P1_UNROLL; j++) {
-    a[j] = xs[s.u[j] & 0x7fffu];
-    if (VM == 1) a[j] *= vtab[s.vi[j]];
+    a[j] = xs[(s.u[j] >> half) & 0xffffu];
+    if (VM == 0) a[j] *= vc;
+    else if (VM == 1) a[j] *= vtab[s.vi[j]];
     else a[j] *= s.v[j];
   }
 #pragma unroll
@@ -139,20 +152,23 @@ __device__ __forceinline__ void bins_expand_finish(const bins_step &s, int64_t g
      * group of the cold columns has nothing but stretches of one entry: no step at all) */
     const uint64_t f1 = s.sm[j], f2 = f1 | (f1 << 1), f4 = f2 | (f2 << 2), f8 = f4 | (f4 << 4);
     if (~f1) {
-      a[j] += bins_keep_if(bins_row_shr<1>(0.0, a[j]), ~f1);
+      a[j] += bins_below_unless<1>(a[j], f1);
       if (~f2) {
-        a[j] += bins_keep_if(bins_row_shr<2>(0.0, a[j]), ~f2);
+        a[j] += bins_below_unless<2>(a[j], f2);
         if (~f4) {
-          a[j] += bins_keep_if(bins_row_shr<4>(0.0, a[j]), ~f4);
-          if (~f8) a[j] += bins_keep_if(bins_row_shr<8>(0.0, a[j]), ~f8);
+          a[j] += bins_below_unless<4>(a[j], f4);
+          if (~f8) a[j] += bins_below_unless<8>(a[j], f8);
         }
       }
     }
   }
 #pragma unroll
   for (int j = 0; j < BINS_P1_UNROLL; j++) {
-    const int tail = bins_lane_bit((s.sm[j] >> 1) | (1ull << 63));   /* the next lane starts a stretch, or there is none */
-    if ((FULL || g + j < g1) && tail) __builtin_nontemporal_store(a[j], &xe[s.d[j]]);
+    /* the last lanes of the stretches store: the lanes whose next lane starts one, and lane 63 --
+     * a mask in scalar registers, taken as the execution mask as it is */
+    const uint64_t above = s.sm[j] >> 1;
+    if ((FULL || g + j < g1) && __builtin_amdgcn_inverse_ballot_w64(above | (1ull << 63)))
+      __builtin_nontemporal_store(a[j], xe1 + (s.o[j] + (int64_t)bins_count_below(above)));
   }
 }
 
@@ -176,11 +192,12 @@ __global__ __launch_bounds__(BINS_P1_THREADS) void k_bins_expand(const int64_t *
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   /* the same in every lane: group numbers stay scalar */
   const int64_t stride = (int64_t)(nthreads / 64) * BINS_P1_UNROLL;
+  const int half = (lane & 1) << 4;                        /* where the lane's column stands in the four bytes it loads */
   /* the wave's first step is requested before the slice of x: its latency hides behind the slice's */
-  bins_step cur, nxt;
+  bins_step sa, sb;
   int64_t g = g0 + (int64_t)wave * BINS_P1_UNROLL;
-  if (g + BINS_P1_UNROLL <= g1) bins_expand_load<VM, true>(cur, g, g1, lane, col16, vidx, val, vc, gfirst, runmask, rowmask, O);
-  else if (g < g1) bins_expand_load<VM, false>(cur, g, g1, lane, col16, vidx, val, vc, gfirst, runmask, rowmask, O);
+  if (g + BINS_P1_UNROLL <= g1) bins_expand_load<VM, true>(sa, g, g1, lane, col16, vidx, val, gfirst, runmask, rowmask, O);
+  else if (g < g1) bins_expand_load<VM, false>(sa, g, g1, lane, col16, vidx, val, gfirst, runmask, rowmask, O);
   /* the slice of x: all of a thread's loads in flight together (the last slice may be short:
    * the loads are clamped to the last column, what lies beyond is never looked up) */
   for (int i0 = 0; i0 < W; i0 += 8 * nthreads) {
@@ -200,14 +217,25 @@ __global__ __launch_bounds__(BINS_P1_THREADS) void k_bins_expand(const int64_t *
   __syncthreads();
   /* Every step's loads are requested before the stores of the step before it are issued: loads
    * and stores complete in the order of their issue, so a wave that stored first would wait for
-   * its stores to be written before it could use the next loads. */
-  for (; g < g1; g += stride) {
+   * its stores to be written before it could use the next loads.  The two steps in flight take
+   * turns in two sets of registers (a copy from one set to the other would wait for the loads). */
+  while (g + 2 * stride + BINS_P1_UNROLL <= g1) {          /* sa holds the groups from g on; these and the next two steps are whole */
+    bins_expand_load<VM, true>(sb, g + stride, g1, lane, col16, vidx, val, gfirst, runmask, rowmask, O);
+    __builtin_amdgcn_sched_barrier(0);                      /* nothing of the step before moves in front of these loads (it would wait for its own) */
+    bins_expand_finish<VM, true>(sa, g, g1, half, xs, vtab, vc, xe + 1);
+    __builtin_amdgcn_sched_barrier(0);
+    bins_expand_load<VM, true>(sa, g + 2 * stride, g1, lane, col16, vidx, val, gfirst, runmask, rowmask, O);
+    __builtin_amdgcn_sched_barrier(0);
+    bins_expand_finish<VM, true>(sb, g + stride, g1, half, xs, vtab, vc, xe + 1);
+    __builtin_amdgcn_sched_barrier(0);
+    g += 2 * stride;
+  }
+  while (g < g1) {                                          /* the last steps, whole or not */
     const int64_t gn = g + stride;
-    if (gn + BINS_P1_UNROLL <= g1) bins_expand_load<VM, true>(nxt, gn, g1, lane, col16, vidx, val, vc, gfirst, runmask, rowmask, O);
-    else if (gn < g1) bins_expand_load<VM, false>(nxt, gn, g1, lane, col16, vidx, val, vc, gfirst, runmask, rowmask, O);
-    if (g + BINS_P1_UNROLL <= g1) bins_expand_finish<VM, true>(cur, g, g1, xs, vtab, xe);
-    else bins_expand_finish<VM, false>(cur, g, g1, xs, vtab, xe);
-    cur = nxt;
+    if (gn < g1) bins_expand_load<VM, false>(sb, gn, g1, lane, col16, vidx, val, gfirst, runmask, rowmask, O);
+    bins_expand_finish<VM, false>(sa, g, g1, half, xs, vtab, vc, xe + 1);
+    sa = sb;
+    g = gn;
   }
 }
 
