@@ -48,7 +48,7 @@
 #define BINS_P1_UNROLL  8      /* groups of 64 entries a wave of the expand pass has in flight: 16 spill registers at 1024 threads */
 #endif
 #ifndef BINS_P2_UNROLL
-#define BINS_P2_UNROLL  16
+#define BINS_P2_UNROLL  32     /* loads a reduce wave has in flight (16: 4.58 ms per product at R-MAT scale 26, 24: 4.51, 32: 4.50) */
 #endif
 
 /* data-parallel-primitive move inside a row of 16 lanes: the value of the lane N places below;
