@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """SpMV timing on the stencil operators of the benchmark configurations.
 
-    python tools/spmv_bench.py ex2:4096 lap3d:256 lap3d:512
+    python tools/spmv_bench.py ex2:4096 lap3d:256 lap3d:512 lap1d:134217728 lap2d:512:262144
 
 Prints the HIP-event time per product, the algorithmic GB/s and a checksum of y
 (equal between runs with different kernel options when the results are bit-identical)."""
@@ -13,20 +13,32 @@ import time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from slepc_amd import ksgpu, matgen
+if os.environ.get("KSGPU_LIB"):                       # a build of the device library with other compile-time settings
+    ksgpu.LIB_PATH = os.environ["KSGPU_LIB"]
 
 
 def main():
     ctx = ksgpu.Context(0)
     for spec in sys.argv[1:] or ["ex2:4096"]:
-        kind, g = spec.split(":")
-        g = int(g)
+        kind, g = spec.split(":", 1)
         t0 = time.time()
-        rp, ci, va = matgen.laplacian2d(g) if kind == "ex2" else matgen.laplacian3d(g, g, g)
+        if kind == "lap1d":                                  # lap1d:N -- three entries per row, offsets +-1
+            rp, ci, va = matgen.laplacian1d(int(g))
+        elif kind == "lap2d":                                # lap2d:n:m -- n x m grid, offsets +-1, +-n
+            a, b = (int(v) for v in g.split(":"))
+            rp, ci, va = matgen.laplacian2d(a, b)
+        else:
+            g = int(g)
+            rp, ci, va = matgen.laplacian2d(g) if kind == "ex2" else matgen.laplacian3d(g, g, g)
         n = len(rp) - 1
         A = ksgpu.DeviceCSR(ctx, rp, ci, va)
         nnz = int(rp[-1])
         del rp, ci, va
-        x, y = ctx.vec_alloc(n), ctx.vec_alloc(n)
+        # KSG_VEC_SKEW=a,b: x and y start a and b bytes into their allocations (where three streams of
+        # the same power-of-two length meet the memory channels)
+        skew = [int(v) for v in os.environ.get("KSG_VEC_SKEW", "0,0").split(",")]
+        x0, y0 = ctx.vec_alloc(n + skew[0] // 8), ctx.vec_alloc(n + skew[1] // 8)
+        x, y = x0 + skew[0], y0 + skew[1]
         ctx.vec_fill_hash(x, n, 0, 7)
         for _ in range(3):
             A.mult(x, y)
@@ -44,8 +56,8 @@ def main():
             spec, n, nnz, s["ms"] / s["calls"], s["bytes"] / s["ms"] / 1e6,
             hashlib.sha1(h.tobytes()).hexdigest()[:12], time.time() - t0), flush=True)
         A.destroy()
-        ctx.vec_free(x)
-        ctx.vec_free(y)
+        ctx.vec_free(x0)
+        ctx.vec_free(y0)
 
 
 if __name__ == "__main__":
