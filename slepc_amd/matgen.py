@@ -16,12 +16,21 @@ import numpy as np
 
 def _threads():
     """Host threads for the generators' passes (numpy releases the interpreter lock in them):
-    OMP_NUM_THREADS when set, else the machine's, at most 16."""
+    KSG_GEN_THREADS, else OMP_NUM_THREADS when it asks for more than one (the launcher of
+    torch.distributed sets it to 1 when it finds it unset), else the machine's cores shared among
+    the ranks of this node; at most 16."""
+    for name in ("KSG_GEN_THREADS", "OMP_NUM_THREADS"):
+        try:
+            n = int(os.environ.get(name, "0"))
+        except ValueError:
+            n = 0
+        if n > 1 or (n == 1 and name == "KSG_GEN_THREADS"):
+            return min(16, n)
     try:
-        n = int(os.environ.get("OMP_NUM_THREADS", "0"))
+        ranks = max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1")))
     except ValueError:
-        n = 0
-    return max(1, min(16, n or (os.cpu_count() or 1)))
+        ranks = 1
+    return max(1, min(16, (os.cpu_count() or 1) // ranks))
 
 
 def _finish(n_local, rows, cols, vals):
@@ -157,7 +166,7 @@ def _rmat_split_keys(key, edges):
     nbuck = len(edges) - 1
     if nbuck == 1:
         return [key]
-    which = np.searchsorted(edges, key, side="right") - 1
+    which = (np.searchsorted(edges, key, side="right") - 1).astype(np.uint8 if nbuck <= 256 else np.uint16)   # small integers: a radix sort
     order = np.argsort(which, kind="stable")
     key = key[order]
     cuts = np.searchsorted(which[order], np.arange(nbuck + 1))
@@ -251,23 +260,24 @@ def rmat_laplacian_distributed(scale, starts, rank, dist, edge_factor=8, a=0.57,
     N = 1 << scale
     P = len(starts) - 1
     bounds = np.asarray(starts, dtype=np.int64)
-    out = [[] for _ in range(P)]
     nch = rmat_num_chunks(scale, edge_factor, chunk)
-    for k in range(rank, nch, P):
+
+    def draw(k):                                            # chunk k, its keys sorted by the rank that owns their row
         src, dst = rmat_chunk_edges(scale, k, edge_factor, a, b, c, seed, chunk)
         s2 = np.concatenate((src, dst))
         d2 = np.concatenate((dst, src))
-        owner = np.searchsorted(bounds, s2, side="right") - 1
+        owner = (np.searchsorted(bounds, s2, side="right") - 1).astype(np.uint16)     # small integers: a radix sort
         order = np.argsort(owner, kind="stable")
         key = (s2 * N + d2)[order]
         cuts = np.searchsorted(owner[order], np.arange(P + 1))
-        for p in range(P):
-            if cuts[p + 1] > cuts[p]:
-                out[p].append(key[cuts[p]:cuts[p + 1]])
-        if progress:
-            progress("R-MAT: chunk %d of %d drawn on rank %d" % (k + 1, nch, rank))
-    send = [np.concatenate(o) if o else np.zeros(0, dtype=np.int64) for o in out]
-    del out
+        return [key[cuts[p]:cuts[p + 1]] for p in range(P)]
+    mine = list(range(rank, nch, P))
+    with ThreadPoolExecutor(max(1, min(_threads(), len(mine) or 1))) as ex:
+        drawn = list(ex.map(draw, mine))
+    if progress:
+        progress("R-MAT: %d of %d chunks drawn on rank %d" % (len(mine), nch, rank))
+    send = [np.concatenate([d[p] for d in drawn]) if drawn else np.zeros(0, dtype=np.int64) for p in range(P)]
+    del drawn
     counts = torch.tensor([len(x) for x in send], dtype=torch.int64)
     allc = [torch.zeros(P, dtype=torch.int64) for _ in range(P)]
     dist.all_gather(allc, counts)
@@ -284,11 +294,16 @@ def rmat_laplacian_distributed(scale, starts, rank, dist, edge_factor=8, a=0.57,
     for r in reqs:
         r.wait()
     del send
-    key = np.concatenate(recv)
-    del recv
+    nkeys = sum(x.size for x in recv)
     if progress:
-        progress("R-MAT: rank %d received %d edges of its rows" % (rank, key.size))
-    return _rmat_csr_from_keys(key, N, int(starts[rank]), int(starts[rank + 1]), progress)
+        progress("R-MAT: rank %d received %d edges of its rows" % (rank, nkeys))
+    # what every source sent is cut into the row ranges the duplicates are removed in, on host threads
+    row0, row1 = int(starts[rank]), int(starts[rank + 1])
+    edges = _rmat_bucket_edges(N, row0, row1, max(1, min(64, nkeys >> 23, max(1, row1 - row0))))
+    with ThreadPoolExecutor(_threads()) as ex:
+        pieces = list(ex.map(lambda x: _rmat_split_keys(x, edges), recv))
+    del recv
+    return _rmat_csr_from_keys(pieces, N, row0, row1, progress)
 
 
 def slab_rows(dims, nranks, rank):
