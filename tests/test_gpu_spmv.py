@@ -455,6 +455,49 @@ def test_binned_product(gpu_ctx, W, H, E, T, values):
         ctx.vec_free(p_)
 
 
+@pytest.mark.parametrize("values", ["one", "few", "any"])
+def test_binned_product_whole_steps_integer_exact(gpu_ctx, values):
+    """The binned product with the library's own task sizes on an operator large enough that the
+    expand pass runs its main loop (two whole steps of 16 waves x 8 groups in flight per workgroup:
+    tasks of several hundred groups), for the three ways the values are held: on integer-valued data
+    every product and partial sum is exact, so the result must equal the sequential CSR loop bit for
+    bit, and the rows read back must be the input's."""
+    from oracle.matgen import csr_matvec_fast
+    from slepc_amd import ksgpu, matgen as mg
+    ctx = gpu_ctx
+    rp, ci, va = mg.rmat_laplacian(20)
+    n = len(rp) - 1
+    rng = np.random.default_rng(99)
+    offd = ci != np.repeat(np.arange(n), np.diff(rp))
+    va = va.copy()
+    if values == "few":
+        va[offd] = rng.choice(np.array([-1.0, -2.0, 3.0, 5.0]), size=int(offd.sum()))
+    elif values == "any":
+        va[offd] = rng.integers(-1000, 1001, size=int(offd.sum())).astype(np.float64)
+    try:
+        ctx.set_option(ksgpu.OPT_BINS, 2)
+        A = ksgpu.DeviceCSR(ctx, rp, ci, va)
+    finally:
+        ctx.set_option(ksgpu.OPT_BINS, 0)
+    d = A.describe()
+    assert "binned part" in d, d
+    assert {"one": "values: one", "few": "1-byte indices", "any": "8-byte stream"}[values] in d.split("binned part")[1], d
+    xi = (np.arange(n, dtype=np.int64) * 2654435761 % 1021 - 510).astype(np.float64)
+    want = np.zeros(n)
+    csr_matvec_fast(rp, ci, va, xi, want)
+    xd, yd = ctx.vec_alloc(n), ctx.vec_alloc(n)
+    ctx.upload(xd, xi)
+    for _ in range(2):
+        ctx.upload(yd, np.full(n, np.nan))
+        A.mult(xd, yd)
+        assert np.array_equal(ctx.download(yd, n), want)
+    r1, c1, v1 = A.get_csr()
+    assert np.array_equal(r1, rp) and np.array_equal(c1, ci) and np.array_equal(v1, va)
+    A.destroy()
+    ctx.vec_free(xd)
+    ctx.vec_free(yd)
+
+
 def test_binned_random_blocks(gpu_ctx):
     """Random small operators with skewed columns, hub rows, empty rows, with and without a complete
     diagonal, square and rectangular, under random settings of the tuning variables: whatever form
