@@ -559,6 +559,74 @@ def test_binned_random_blocks(gpu_ctx):
     assert binned >= 10, binned
 
 
+def test_binned_random_large_blocks(gpu_ctx):
+    """Random operators of 10^5 .. 10^6 rows and 10^6 .. 10^7 entries with skewed columns, hub rows
+    (some longer than a row block may be: cut into pieces), empty rows, square and rectangular, integer
+    values of the three kinds, under the library's own task sizes and some odd ones: with integer x the
+    binned product must equal the sequential CSR loop bit for bit (every workgroup of the expand pass runs
+    whole double steps, single steps and a ragged end here), and the rows read back are the input's."""
+    import os
+    from oracle.matgen import csr_matvec_fast
+    from slepc_amd import ksgpu
+    ctx = gpu_ctx
+    rng = np.random.default_rng(20261)
+    keys = ("KSG_BINS_W", "KSG_BINS_H", "KSG_BINS_E", "KSG_BINS_T", "KSG_BINS_TASK_GROUPS")
+    old = {k: os.environ.get(k) for k in keys}
+    binned = 0
+    try:
+        ctx.set_option(ksgpu.OPT_BINS, 2)
+        for trial in range(6):
+            n = int(rng.integers(100_000, 1_000_000))
+            nc = n if trial % 3 else int(rng.integers(100_000, 1_500_000))
+            nnz_t = int(rng.choice([6.0, 12.0, 20.0]) * n)
+            rows = np.minimum((n * rng.random(nnz_t) ** rng.choice([1.0, 2.0, 3.0])).astype(np.int64), n - 1)
+            cols = np.minimum((nc * rng.random(nnz_t) ** rng.choice([3.0, 4.0, 6.0])).astype(np.int64), nc - 1)
+            hubs = rng.integers(0, n, 3)                                   # three hub rows, the first very long
+            for h, length in zip(hubs, (int(min(nc, 400_000)), 60_000, 5_000)):
+                extra = rng.choice(nc, size=length, replace=False)
+                rows = np.concatenate([rows, np.full(length, h)])
+                cols = np.concatenate([cols, extra])
+            if nc == n and trial % 2:
+                rows = np.concatenate([rows, np.arange(n)])
+                cols = np.concatenate([cols, np.arange(n)])
+            key = np.unique(rows * nc + cols)
+            rows, cols = key // nc, (key % nc).astype(np.int32)
+            kind = trial % 3
+            vals = (rng.integers(-1000, 1001, len(key)).astype(np.float64) if kind == 0 else
+                    np.full(len(key), -1.0) if kind == 1 else rng.choice(np.array([3.0, -2.0, 0.0, 7.0]), len(key)))
+            rp = np.concatenate([[0], np.cumsum(np.bincount(rows, minlength=n))]).astype(np.int64)
+            for k in keys:
+                os.environ.pop(k, None)
+            if trial >= 3:                                                 # odd shapes: short tasks, low rows blocks, small E (more pieces)
+                os.environ.update({"KSG_BINS_W": str(rng.choice([4096, 16384])), "KSG_BINS_H": str(rng.choice([1000, 4096])),
+                                   "KSG_BINS_E": str(rng.choice([30_000, 100_000])), "KSG_BINS_T": str(rng.choice([1, 2, 4])),
+                                   "KSG_BINS_TASK_GROUPS": str(rng.choice([129, 300, 777]))})
+            A = ksgpu.DeviceCSR(ctx, rp, cols, vals, cols=None if nc == n else (nc, nc, 0))
+            binned += "binned part" in A.describe()              # the library keeps a block whose columns are not skewed enough as it is
+            xi = (np.arange(nc, dtype=np.int64) * 2654435761 % 1021 - 510).astype(np.float64)
+            want = np.zeros(n)
+            csr_matvec_fast(rp, cols, vals, xi, want)
+            xd, yd = ctx.vec_alloc(nc), ctx.vec_alloc(n)
+            ctx.upload(xd, xi)
+            ctx.upload(yd, np.full(n, np.nan))
+            A.mult(xd, yd)
+            got = ctx.download(yd, n)
+            assert np.array_equal(got, want), (trial, int((got != want).sum()), A.describe())
+            r1, c1, v1 = A.get_csr()
+            assert np.array_equal(r1, rp) and np.array_equal(c1, cols) and np.array_equal(v1, vals), (trial, A.describe())
+            A.destroy()
+            ctx.vec_free(xd)
+            ctx.vec_free(yd)
+    finally:
+        ctx.set_option(ksgpu.OPT_BINS, 0)
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    assert binned >= 4, binned
+
+
 @pytest.mark.parametrize("gen", ["lap1d", "lap2d", "lap3d", "band"])
 def test_row_code_kernel_equals_tile_kernel(gpu_ctx, gen):
     """Stencils and other banded operators with few distinct (column - row, value) pairs are
