@@ -36,6 +36,8 @@ def run():
 
     if case == "rmat_gen":
         return rmat_gen_main(out, rank, size, dist)
+    if case == "rmat_exact":
+        return rmat_exact_main(mode, out, rank, size, dist)
     if case.startswith("svd_"):
         return svd_main(mode, case, out, rank, size, dist)
     if case == "bv_ip":
@@ -219,6 +221,58 @@ def rmat_gen_main(out, rank, size, dist):
     if rank == 0:
         with open(out, "w") as f:
             json.dump({"same": int(flag[0]), "ranks": size, "rows": [int(starts[r + 1] - starts[r]) for r in range(size)]}, f)
+
+
+def rmat_exact_main(mode, out, rank, size, dist):
+    """The distributed product of an R-MAT graph Laplacian of 10^6 rows with the library's own cell and
+    task sizes (both blocks of a rank binned where it chooses so: KSG_SPMV_BINS=2 from the test) on
+    integer-valued data: every rank's rows of y must equal the sequential CSR loop over its rows bit
+    for bit, and the rows read back from the device are the input's."""
+    import numpy as np
+    import torch
+    from oracle.matgen import csr_matvec_fast
+    from slepc_amd import kseps as K, ksgpu, matgen as mg, dist as kdist
+    assert mode == "gpu"
+    scale = int(os.environ.get("KS_EXACT_SCALE", "20"))
+    N = 1 << scale
+    starts = mg.balanced_row_blocks(mg.rmat_row_weights(scale), size, 0.0)
+    row0, row1 = int(starts[rank]), int(starts[rank + 1])
+    rp, ci, va = mg.rmat_laplacian(scale, row0=row0, row1=row1)
+    ctx = ksgpu.Context(0)
+    if size > 1:
+        kdist.init_comm(ctx, transport=os.environ.get("KS_TRANSPORT", "gloo"))
+    Am = K.Mat.create_aij_hip(ctx, rp, ci, va, N=N, row0=row0)
+    xg = (np.arange(N, dtype=np.int64) * 2654435761 % 1021 - 510).astype(np.float64)
+    want = np.zeros(row1 - row0)
+    csr_matvec_fast(rp, ci, va, xg, want)
+    xv, yv = Am.create_vecs(), Am.create_vecs()
+    xv.set_values(xg[row0:row1])
+    same = 1
+    for _ in range(2):
+        yv.set_values(np.full(row1 - row0, np.nan))
+        Am.mult(xv, yv)
+        same &= int(np.array_equal(yv.get_values(), want))
+    dev = ksgpu.DeviceCSR.__new__(ksgpu.DeviceCSR)
+    dev.ctx, dev.lib, dev.h = ctx, ctx.lib, Am.p.contents.data
+    descr = dev.describe()
+    dev._adopt(dev.h)
+    r2, c2, v2 = dev.get_csr()
+    same &= int(np.array_equal(r2, rp) and np.array_equal(c2, ci) and np.array_equal(v2, va))
+    flag = torch.tensor([same], dtype=torch.int64)
+    variants = [descr]
+    if size > 1:
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        variants = [None] * size
+        dist.all_gather_object(variants, descr)
+    if rank == 0:
+        with open(out, "w") as f:
+            json.dump({"same": int(flag[0]), "ranks": size, "variant": variants}, f)
+    if dist:
+        dist.barrier()
+    for o in (xv, yv):
+        o.destroy()
+    Am.destroy()
+    ctx.close()
 
 
 def bv_ip_main(mode, out, rank, size, dist):

@@ -68,6 +68,21 @@ def test_ghost_columns_numbered_either_way():
     assert a["values"] == b["values"]
 
 
+@pytest.mark.parametrize("ranks", [1, 3, 8])
+def test_rmat_product_exact_on_integer_data(ranks):
+    """R-MAT scale 20 (10^6 rows, 1.7e7 entries) on 1, 3 and 8 ranks sharing the device, binned forms
+    forced with the library's own cell and task sizes (the expand pass of the local and of the ghost
+    blocks runs its main loop, the ghost block's tasks in the stages of the halo rounds): with
+    integer-valued x and values every rank's rows of y equal the sequential CSR loop bit for bit."""
+    import re
+    r = run_ranks("gpu", "rmat_exact", ranks, extra_env={"KSG_SPMV_BINS": "2"})
+    assert r["same"] == 1 and r["ranks"] == ranks, r["variant"]
+    assert any(d.startswith("binned part") for d in r["variant"]), r["variant"]
+    if ranks > 1:
+        binned_ghost = [re.search(r"ghost block: (\d+) entries in (\d+) rows, (\d+) of them binned", d) for d in r["variant"]]
+        assert any(m and int(m.group(3)) > 0 for m in binned_ghost), r["variant"]
+
+
 @pytest.mark.parametrize("ranks", [2, 3, 8])
 def test_rmat_binned_blocks_match_single(ranks):
     """The same split with both blocks of every rank in the binned form (KSG_OPT_BINS forced through
