@@ -67,6 +67,12 @@ def parse_args(argv=None):
                     help="driver on the same kernels (default: the Krylov-Schur path of the metric)")
     ap.add_argument("--transport", default="rccl", choices=["rccl", "gloo"],
                     help="gloo (host-staged collectives) is for rehearsals with --share-device only")
+    ap.add_argument("--rmat-partition", default="hashed", choices=["hashed", "contiguous"],
+                    help="R-MAT on several ranks: 'hashed' (default) relabels the graph so that a hash of the vertex number "
+                         "picks its rank (each rank's vertices keep their order): equal rows AND about equal entries per "
+                         "rank, the operator P A P^T with the start vector permuted alike, the same eigenvalues; "
+                         "'contiguous' cuts the graph in its natural order into row blocks balanced by expected entries "
+                         "(+ --rmat-row-weight per row)")
     ap.add_argument("--rmat-row-weight", type=float, default=0.0,
                     help="rmat on several GPUs: cost of a row in matrix entries added to its entry count when the "
                          "row blocks are balanced (0: balanced by entries alone)")
@@ -165,12 +171,31 @@ def workload_rows(args, size, rank):
     if size == 1:
         row0, row1 = 0, N
         part = "one rank"
+    elif args.rmat_partition == "hashed":
+        starts = rmat_relabeling(args, size)[2]
+        row0, row1 = int(starts[rank]), int(starts[rank + 1])
+        part = ("vertices dealt to the ranks by a hash of their number, each rank's in their original order "
+                "(the graph relabelled: P A P^T, start vector permuted alike), %d rank(s)" % size)
     else:
         starts = matgen.balanced_row_blocks(matgen.rmat_row_weights(g), size, args.rmat_row_weight)
         row0, row1 = starts[rank], starts[rank + 1]
         part = "contiguous row blocks balanced by expected entries%s, %d rank(s)" % (
             " + %g per row" % args.rmat_row_weight if args.rmat_row_weight else "", size)
     return "R-MAT scale %d graph Laplacian (%d rows)" % (g, N), N, row0, row1, None, part
+
+
+_RELABEL = {}
+
+
+def rmat_relabeling(args, size):
+    """(new label of every vertex, vertex behind every new label, first new label of every rank) of the
+    hashed partition; the same tables on every rank, made once."""
+    from slepc_amd import matgen
+    key = (args.grid, size)
+    if key not in _RELABEL:
+        _RELABEL.clear()
+        _RELABEL[key] = matgen.hashed_relabeling(1 << args.grid, size)
+    return _RELABEL[key]
 
 
 def generate(args, N, row0, row1, dims, rank, size=1, dist=None):
@@ -184,6 +209,9 @@ def generate(args, N, row0, row1, dims, rank, size=1, dist=None):
     progress = (lambda t: print(t, file=sys.stderr, flush=True)) if rank == 0 and args.grid > 23 else None
     if size > 1:
         # every rank draws an eighth (1/size) of the edge list and the edges travel to the owners of their rows
+        if args.rmat_partition == "hashed":
+            new_of_old, _, starts = rmat_relabeling(args, size)
+            return matgen.rmat_laplacian_distributed(args.grid, starts, rank, dist, progress=progress, relabel=new_of_old)
         starts = matgen.balanced_row_blocks(matgen.rmat_row_weights(args.grid), size, args.rmat_row_weight)
         return matgen.rmat_laplacian_distributed(args.grid, starts, rank, dist, progress=progress)
     return matgen.rmat_laplacian(args.grid, row0=row0, row1=row1, progress=progress)
@@ -331,6 +359,14 @@ def main():
         h[max(0, 0 - row0):max(0, 2 - row0)] = 1.0
         v0.set_values(h)
         eps.set_initial_space([v0])
+    if args.workload == "rmat" and size > 1 and args.rmat_partition == "hashed":
+        # the relabelled problem started from the relabelled default start vector: the one-rank iteration
+        # up to rounding (the solver's own default hashes the new labels)
+        from slepc_amd import matgen
+        v0 = A.create_vecs()
+        v0.set_values(matgen.hashed_start_vector(rmat_relabeling(args, size)[1][row0:row1]))
+        eps.set_initial_space([v0])
+        _RELABEL.clear()
 
     marks = {}
     # Profiler markers: a 3-element k_vec_set (one workgroup) is launched right before

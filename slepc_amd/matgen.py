@@ -220,7 +220,7 @@ def _rmat_csr_from_keys(pieces, N, row0, row1, progress=None):
 
 
 def rmat_laplacian(scale, edge_factor=8, a=0.57, b=0.19, c=0.19, seed=0x5EED, row0=0, row1=None,
-                   chunk=1 << 24, progress=None):
+                   chunk=1 << 24, progress=None, relabel=None):
     """Graph Laplacian D - A of a symmetrised R-MAT graph with 2**scale vertices:
     power-law row lengths, unit weights, duplicates and self-loops removed.
     `progress(text)` is called every few seconds of work (large scales take minutes)."""
@@ -234,6 +234,8 @@ def rmat_laplacian(scale, edge_factor=8, a=0.57, b=0.19, c=0.19, seed=0x5EED, ro
 
     def chunk_keys(k):
         src, dst = rmat_chunk_edges(scale, k, edge_factor, a, b, c, seed, chunk)
+        if relabel is not None:
+            src, dst = relabel[src], relabel[dst]
         s2 = np.concatenate((src, dst))
         d2 = np.concatenate((dst, src))
         if row0 != 0 or row1 != N:
@@ -249,7 +251,7 @@ def rmat_laplacian(scale, edge_factor=8, a=0.57, b=0.19, c=0.19, seed=0x5EED, ro
 
 
 def rmat_laplacian_distributed(scale, starts, rank, dist, edge_factor=8, a=0.57, b=0.19, c=0.19, seed=0x5EED,
-                               chunk=1 << 24, progress=None):
+                               chunk=1 << 24, progress=None, relabel=None):
     """The rows starts[rank] .. starts[rank+1] of `rmat_laplacian(scale)` when all ranks of the
     torch.distributed group `dist` call this together: every rank draws a share of the chunks of
     the edge list (chunk k on rank k mod P), sorts its edges by the rank that owns their row and
@@ -264,6 +266,8 @@ def rmat_laplacian_distributed(scale, starts, rank, dist, edge_factor=8, a=0.57,
 
     def draw(k):                                            # chunk k, its keys sorted by the rank that owns their row
         src, dst = rmat_chunk_edges(scale, k, edge_factor, a, b, c, seed, chunk)
+        if relabel is not None:
+            src, dst = relabel[src], relabel[dst]
         s2 = np.concatenate((src, dst))
         d2 = np.concatenate((dst, src))
         owner = (np.searchsorted(bounds, s2, side="right") - 1).astype(np.uint16)     # small integers: a radix sort
@@ -304,6 +308,42 @@ def rmat_laplacian_distributed(scale, starts, rank, dist, edge_factor=8, a=0.57,
         pieces = list(ex.map(lambda x: _rmat_split_keys(x, edges), recv))
     del recv
     return _rmat_csr_from_keys(pieces, N, row0, row1, progress)
+
+
+def _splitmix64(z):
+    z = z + np.uint64(0x9E3779B97F4A7C15)
+    z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+    z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+    return z ^ (z >> np.uint64(31))
+
+
+def hashed_start_vector(rows, seed=0x12345678):
+    """The solver's default start vector at the global rows `rows`: 2 u - 1 with u the top 53 bits of
+    splitmix64(row ^ seed) (what `ksg_vec_fill_hash` puts there; EPSGetStartVector's random vector,
+    epssolve.c:675-710, made a function of the global row so that it does not depend on the partition)."""
+    with np.errstate(over="ignore"):
+        z = _splitmix64(np.asarray(rows, dtype=np.uint64) ^ np.uint64(seed))
+    return 2.0 * ((z >> np.uint64(11)).astype(np.float64) * (1.0 / 9007199254740992.0)) - 1.0
+
+
+def hashed_relabeling(N, nranks, seed=0x0B1A5ED):
+    """A relabelling of the N vertices of a graph that deals them to `nranks` ranks by a hash of their
+    number and keeps each rank's vertices in their original order: (new label of every vertex, the
+    vertex behind every new label, the ranks' first new labels).  Contiguous blocks of the relabelled
+    operator P A P^T then hold about the same number of rows AND of entries whatever the degree
+    distribution (contiguous blocks of a power-law graph in its natural order cannot have both: the
+    hubs sit together), while within a rank's share the hub columns stay together, which the binned
+    product needs."""
+    with np.errstate(over="ignore"):
+        h = _splitmix64(np.arange(N, dtype=np.uint64) ^ np.uint64(seed))
+    owner = (h % np.uint64(nranks)).astype(np.uint8 if nranks <= 256 else np.uint16)
+    del h
+    old_of_new = np.argsort(owner, kind="stable")           # small integers: a radix sort
+    starts = np.concatenate(([0], np.cumsum(np.bincount(owner, minlength=nranks)))).astype(np.int64)
+    del owner
+    new_of_old = np.empty(N, dtype=np.int64)
+    new_of_old[old_of_new] = np.arange(N, dtype=np.int64)
+    return new_of_old, old_of_new, starts
 
 
 def slab_rows(dims, nranks, rank):

@@ -213,6 +213,11 @@ def rmat_gen_main(out, rank, size, dist):
         got = mg.rmat_laplacian_distributed(scale, starts, rank, dist, chunk=chunk)
         want = mg.rmat_laplacian(scale, row0=starts[rank], row1=starts[rank + 1], chunk=chunk)
         same &= int(all(np.array_equal(a, b) and a.dtype == b.dtype for a, b in zip(got, want)))
+    # the hashed partition: the relabelled graph P A P^T, each rank its block of it
+    new_of_old, old_of_new, hstarts = mg.hashed_relabeling(1 << scale, size)
+    got_h = mg.rmat_laplacian_distributed(scale, hstarts, rank, dist, relabel=new_of_old)
+    want_h = mg.rmat_laplacian(scale, row0=int(hstarts[rank]), row1=int(hstarts[rank + 1]), relabel=new_of_old)
+    same &= int(all(np.array_equal(a, b) and a.dtype == b.dtype for a, b in zip(got_h, want_h)))
     whole = mg.rmat_laplacian(scale)                       # the chunk size does not change the matrix either
     a, b = starts[rank], starts[rank + 1]
     same &= int(np.array_equal(got[0], whole[0][a:b + 1] - whole[0][a]) and np.array_equal(got[1], whole[1][whole[0][a]:whole[0][b]]))

@@ -97,3 +97,34 @@ def test_launcher_reports_a_failing_rank():
     assert r.returncode != 0
     assert b"stopping the other ranks" in r.stderr or b"exited with status" in r.stderr
     assert not [l for l in r.stdout.decode().splitlines() if l.strip().startswith("{")]
+
+
+@pytest.mark.parametrize("scale,ranks", [(14, 3), (16, 8)])
+def test_rmat_hashed_partition_is_a_relabelling_and_balances_rows_and_entries(scale, ranks):
+    """`bench.py --workload rmat --gpus N` (default partition): the vertices are dealt to the ranks by a
+    hash of their number and relabelled rank by rank in their original order.  The generated operator is
+    P A P^T of the natural one bit for bit, every rank has N/ranks rows to a percent and its share of the
+    entries to a few percent (contiguous blocks of the natural order balance one of the two only), and
+    the start vector of the relabelled problem is the default one permuted."""
+    from scipy.sparse import csr_matrix
+    N = 1 << scale
+    new_of_old, old_of_new, starts = mg.hashed_relabeling(N, ranks)
+    assert np.array_equal(np.sort(new_of_old), np.arange(N)) and np.array_equal(new_of_old[old_of_new], np.arange(N))
+    assert starts[0] == 0 and starts[-1] == N and len(starts) == ranks + 1
+    for r in range(ranks):                                   # a rank's vertices keep their order
+        assert np.all(np.diff(old_of_new[starts[r]:starts[r + 1]]) > 0)
+    rp, ci, va = mg.rmat_laplacian(scale)
+    A = csr_matrix((va, ci, rp), shape=(N, N))
+    B = A[old_of_new][:, old_of_new].tocsr()
+    B.sort_indices()
+    rp2, ci2, va2 = mg.rmat_laplacian(scale, relabel=new_of_old)
+    assert np.array_equal(B.indptr, rp2) and np.array_equal(B.indices, ci2) and np.array_equal(B.data, va2)
+    rows = np.diff(starts)
+    ent = np.array([rp2[starts[r + 1]] - rp2[starts[r]] for r in range(ranks)])
+    assert rows.max() <= 1.02 * N / ranks and rows.min() >= 0.98 * N / ranks
+    assert ent.max() <= 1.12 * ent.mean(), ent                # the largest hub row alone is 1-2 % of a share at these scales
+    cont = mg.balanced_row_blocks(mg.rmat_row_weights(scale), ranks, 0.0)
+    assert np.diff(cont).max() > 2.0 * N / ranks               # what balancing the entries of the natural order does to the rows
+    # the default start vector of the natural numbering, permuted
+    v_nat = mg.hashed_start_vector(np.arange(N))
+    assert np.array_equal(mg.hashed_start_vector(old_of_new), v_nat[old_of_new])
