@@ -260,35 +260,39 @@ int ksg_comm_exchange(ksg_ctx c, ksg_mat A) {
   return exchange_device(c, A->d_send, A->sendoff.data(), A->d_ghost, A->recvoff.data(), c->comm_stream);
 }
 
-/* The halo exchange of one multiply in rounds: in round r every rank sends to rank + r and receives
- * from rank - r (one matched pair per rank and round, the same order on all ranks), and the event of
- * the source is recorded behind the round, so that work on that rank's share of the ghost buffer can
- * start while the later rounds are still under way (MatMult_MPIAIJ's scatter-begin / diagonal /
- * scatter-end / off-diagonal pattern behind src/sys/classes/st/impls/shift/shift.c:38, one step finer).
- * Transports that deliver everything in one call record all events after it. */
+/* The halo exchange of one multiply in rounds: every source's share of the ghost buffer is cut into
+ * A->halo_rounds pieces, and round s moves piece s between every pair of ranks in one group -- on a
+ * node whose GPUs are linked pairwise every link is busy in every round, and the whole exchange takes
+ * what a single grouped one takes -- with an event recorded behind every round, so that the work on the
+ * pieces that have arrived runs while the later ones travel (MatMult_MPIAIJ's scatter-begin / diagonal
+ * / scatter-end / off-diagonal pattern behind src/sys/classes/st/impls/shift/shift.c:38, made finer).
+ * (One source per round instead would use one link at a time.)  Piece s of a share of len entries is
+ * [len*s/R, len*(s+1)/R): the same cut on the sending and on the receiving side.  Transports that
+ * deliver everything in one call record all events after it. */
 int ksg_comm_exchange_rounds(ksg_ctx c, ksg_mat A) {
-  const int P = c->nranks, me = c->rank;
+  const int P = c->nranks, me = c->rank, R = A->halo_rounds;
   if (P <= 1) return KSG_OK;
-  while ((int)c->ev_peer.size() < P) {
+  while ((int)c->ev_peer.size() < R) {
     hipEvent_t e;
     KSG_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     c->ev_peer.push_back(e);
   }
   if (c->comm_kind != KSG_COMM_RCCL) {
     KSG_CHK(ksg_comm_exchange(c, A));
-    for (int p = 0; p < P; p++) if (p != me) KSG_HIP(hipEventRecord(c->ev_peer[(size_t)p], c->comm_stream));
+    for (int s = 0; s < R; s++) KSG_HIP(hipEventRecord(c->ev_peer[(size_t)s], c->comm_stream));
     return KSG_OK;
   }
-  for (int r = 1; r < P; r++) {
-    const int to = (me + r) % P, from = (me - r + P) % P;
-    const int64_t ns = A->sendoff[(size_t)to + 1] - A->sendoff[(size_t)to], nr = A->recvoff[(size_t)from + 1] - A->recvoff[(size_t)from];
-    if (ns > 0 || nr > 0) {
-      KSG_NCCL(g_rccl.GroupStart());
-      if (ns > 0) KSG_NCCL(g_rccl.Send(A->d_send + A->sendoff[(size_t)to], (size_t)ns, k_ncclDouble, to, c->rccl_comm, c->comm_stream));
-      if (nr > 0) KSG_NCCL(g_rccl.Recv(A->d_ghost + A->recvoff[(size_t)from], (size_t)nr, k_ncclDouble, from, c->rccl_comm, c->comm_stream));
-      KSG_NCCL(g_rccl.GroupEnd());
+  for (int s = 0; s < R; s++) {
+    KSG_NCCL(g_rccl.GroupStart());
+    for (int p = 0; p < P; p++) {
+      if (p == me) continue;
+      const int64_t ls = A->sendoff[(size_t)p + 1] - A->sendoff[(size_t)p], lr = A->recvoff[(size_t)p + 1] - A->recvoff[(size_t)p];
+      const int64_t s0 = ls * s / R, s1 = ls * (s + 1) / R, r0 = lr * s / R, r1 = lr * (s + 1) / R;
+      if (s1 > s0) KSG_NCCL(g_rccl.Send(A->d_send + A->sendoff[(size_t)p] + s0, (size_t)(s1 - s0), k_ncclDouble, p, c->rccl_comm, c->comm_stream));
+      if (r1 > r0) KSG_NCCL(g_rccl.Recv(A->d_ghost + A->recvoff[(size_t)p] + r0, (size_t)(r1 - r0), k_ncclDouble, p, c->rccl_comm, c->comm_stream));
     }
-    KSG_HIP(hipEventRecord(c->ev_peer[(size_t)from], c->comm_stream));
+    KSG_NCCL(g_rccl.GroupEnd());
+    KSG_HIP(hipEventRecord(c->ev_peer[(size_t)s], c->comm_stream));
   }
   return KSG_OK;
 }

@@ -152,7 +152,7 @@ struct ksg_ctx_s {
   hipStream_t stream;        /* compute */
   hipStream_t comm_stream;   /* halo pack + exchange */
   hipEvent_t ev_x_ready, ev_halo_done;
-  std::vector<hipEvent_t> ev_peer;   /* one per rank: that rank's share of a halo has arrived (exchange in rounds) */
+  std::vector<hipEvent_t> ev_peer;   /* one per round of a halo exchange in rounds: that round's pieces have arrived */
   double *d_red;             /* device reduction buffer, KSG_RED_MAX doubles */
   double *h_red;             /* pinned host mirror */
   double *d_partial;         /* per-workgroup partial sums */
@@ -307,7 +307,7 @@ struct ksg_mat_s {
   double *h_ghost, *h_send;  /* pinned host staging (callback transport)       */
   int32_t *d_send_idx;       /* local indices to gather into d_send            */
   std::vector<int64_t> sendoff, recvoff;   /* nranks+1 each                    */
-  int halo_rounds;           /* the halo travels in rounds and the ghost block's expand tasks start as their sources arrive */
+  int halo_rounds;           /* rounds the halo travels in (0: one exchange); the ghost block's expand tasks start as their pieces arrive */
 };
 
 /* statistics / timing brackets */
@@ -321,9 +321,9 @@ int ksg_op_end(ksg_ctx ctx, int ev, double bytes, double flops);
 /* communicator primitives (ksg_comm.hip) */
 int ksg_comm_allreduce(ksg_ctx ctx, double *d_buf, double *h_out, int count, int op);
 int ksg_comm_exchange(ksg_ctx ctx, ksg_mat A);
-/* the same exchange in rounds, one source rank per round; ev_peer[source] is recorded on the
- * communication stream when that rank's share of the ghost buffer has arrived.  Source of round r
- * (1 .. nranks-1): (rank - r + nranks) % nranks. */
+/* the same exchange in A->halo_rounds rounds, piece s of every source's share of the ghost buffer in
+ * round s (all pairs of ranks at once); ev_peer[s] is recorded on the communication stream when
+ * round s has arrived */
 int ksg_comm_exchange_rounds(ksg_ctx ctx, ksg_mat A);
 int ksg_comm_allreduce_host(ksg_ctx ctx, double *h_buf, int count, int op);
 int ksg_comm_exchange_host(ksg_ctx ctx, const double *send, const int64_t *sendoff,

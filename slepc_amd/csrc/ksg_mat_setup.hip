@@ -693,16 +693,23 @@ static int mat_create(ksg_ctx c, int64_t n, int64_t N, int64_t row0, int64_t nc,
     std::vector<int32_t> lrows, lci;
     std::vector<int64_t> lrp;
     std::vector<double> lva;
-    /* the slots of the ghost buffer arrive source by source (ksg_comm_exchange_rounds): source s in
-     * round (rank - s) mod P, which is the stage of its columns (KSG_HALO_ROUNDS=0: one exchange, one stage) */
+    /* the ghost buffer arrives in rounds (ksg_comm_exchange_rounds): piece s of every source's share in
+     * round s, which is the stage of its columns (KSG_HALO_ROUNDS: the number of rounds, 4 unless set;
+     * 0 or 1: one exchange, one stage) */
     ksg_colstages cst;
     const char *hr = getenv("KSG_HALO_ROUNDS");
-    A->halo_rounds = !(hr && hr[0] == '0') && P > 2;
+    A->halo_rounds = hr && hr[0] ? atoi(hr) : 4;
+    if (A->halo_rounds < 2 || P < 2) A->halo_rounds = 0;
+    if (A->halo_rounds > 64) A->halo_rounds = 64;
     if (A->halo_rounds) {
-      cst.nstages = P - 1;
+      const int R = A->halo_rounds;
+      cst.nstages = R;
       for (int p = 0; p < P; p++) {
-        cst.bound.push_back(A->recvoff[(size_t)p]);
-        cst.stage.push_back(p == c->rank ? 0 : (c->rank - p + P) % P - 1);
+        const int64_t lr = A->recvoff[(size_t)p + 1] - A->recvoff[(size_t)p];
+        for (int st = 0; st < R; st++) {
+          cst.bound.push_back(A->recvoff[(size_t)p] + lr * st / R);
+          cst.stage.push_back(st);
+        }
       }
       cst.bound.push_back(A->recvoff[(size_t)P]);
     }

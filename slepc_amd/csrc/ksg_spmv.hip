@@ -540,14 +540,14 @@ static int mat_mult_raw(ksg_mat A, const double *x, double *y) {
   }
   KSG_HIP(hipGetLastError());
   if (halo && A->halo_rounds && A->gbins.nent) {
-    /* a ghost block that outweighs the local one (power-law operators): the halo travels in rounds,
-     * one source rank per round, and the expand tasks whose slices of the ghost buffer are complete
-     * start behind their round while the later rounds are still under way; the sums wait for all */
+    /* a ghost block that outweighs the local one (power-law operators): the halo travels in rounds, a
+     * piece of every source's share per round, and the expand tasks whose slices of the ghost buffer
+     * are complete start behind their round while the later rounds are still under way; the sums wait
+     * for all */
     KSG_CHK(ksg_comm_exchange_rounds(c, A));
-    for (int r = 1; r < c->nranks; r++) {
-      const int from = (c->rank - r + c->nranks) % c->nranks;
-      KSG_HIP(hipStreamWaitEvent(c->stream, c->ev_peer[(size_t)from], 0));
-      KSG_CHK(ksg_bins_expand(&A->gbins, A->d_ghost, A->nghost, c->stream, r - 1));
+    for (int st = 0; st < A->halo_rounds; st++) {
+      KSG_HIP(hipStreamWaitEvent(c->stream, c->ev_peer[(size_t)st], 0));
+      KSG_CHK(ksg_bins_expand(&A->gbins, A->d_ghost, A->nghost, c->stream, st));
     }
     KSG_CHK(ksg_bins_finish(&A->gbins, A->d_ghost, y, c->stream, A->o_rows));
     for (const ksg_rest &cg : A->grest) {
@@ -645,7 +645,7 @@ extern "C" int ksg_mat_describe(ksg_mat A, char *buf, size_t len) {
     snprintf(buf + k, len - (size_t)k, "; ghost block: %lld entries in %lld rows, %lld of them binned (LDS slices of the ghost buffer, %lld runs, %lld row blocks), "
              "%lld remaining entries in %lld rows through the tile kernel%s", (long long)A->o_nnz, (long long)A->no_rows, (long long)A->gbins.nreal,
              (long long)A->gbins.nseg, (long long)A->gbins.nbins, ent, rows,
-             A->halo_rounds ? "; halo in rounds by source rank, the expand tasks of a source start when its share has arrived" : "");
+             A->halo_rounds ? "; halo in rounds, a piece of every source's share per round, the expand tasks of a piece start when it has arrived" : "");
   } else if (A->ctx->nranks > 1 && k > 0 && (size_t)k < len)
     snprintf(buf + k, len - (size_t)k, "; ghost block: %lld entries in %lld rows through the same tile kernel (%lld/%lld/%lld tiles, %lld packed)",
              (long long)A->o_nnz, (long long)A->no_rows, (long long)A->ghost.n_stream, (long long)A->ghost.n_group, (long long)A->ghost.n_long,

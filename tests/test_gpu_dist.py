@@ -111,13 +111,13 @@ def test_rmat_binned_blocks_match_single(ranks):
 
 
 def test_halo_in_rounds_gives_the_same_bits():
-    """A binned ghost block on three or more ranks gets its halo in rounds, one source rank per round, and
-    starts the expand tasks of a source when that source's share of the ghost buffer has arrived; the sums
-    are formed afterwards as ever, so the product and the solve are bit for bit those of the single
-    exchange (KSG_HALO_ROUNDS=0)."""
+    """A binned ghost block gets its halo in rounds -- piece s of every source's share of the ghost buffer
+    in round s, all pairs of ranks at once -- and starts the expand tasks of a piece when it has arrived;
+    the sums are formed afterwards as ever, so the product and the solve are bit for bit those of the
+    single exchange (KSG_HALO_ROUNDS=0), for the default number of rounds and for an odd one."""
     env = {"KSG_SPMV_BINS": "2", "KSG_BINS_W": "512", "KSG_BINS_H": "128", "KSG_BINS_E": "1024", "KSG_BINS_T": "2"}
-    for ranks in (3, 8):
-        a = run_ranks("gpu", "rmat_nnz", ranks, extra_env=env)
+    for ranks, rounds in ((2, None), (3, "7"), (8, None)):
+        a = run_ranks("gpu", "rmat_nnz", ranks, extra_env=dict(env, KSG_HALO_ROUNDS=rounds) if rounds else env)
         b = run_ranks("gpu", "rmat_nnz", ranks, extra_env=dict(env, KSG_HALO_ROUNDS="0"))
         assert any("halo in rounds" in d for d in a["variant"]), a["variant"]
         assert not any("halo in rounds" in d for d in b["variant"])
