@@ -295,7 +295,7 @@ def main():
         # a rank that hangs in a collective (a peer died, a communicator that never comes up) must
         # not hold the launcher for ever: after the limit the process ends with SIGALRM's status
         import signal
-        signal.alarm(int(os.environ.get("KSG_BENCH_WATCHDOG_S", "1500")))
+        signal.alarm(int(os.environ.get("KSG_BENCH_WATCHDOG_S", "3000" if args.to_convergence else "540")))
     dist = kdist.init_process_group() if size > 1 else None
 
     ctx = ksgpu.Context(0 if args.share_device else local_rank)
