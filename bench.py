@@ -46,7 +46,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0
-DEFAULT_GRID = {"ex2": 4096, "lap3d": 512, "markov": 3000, "rmat": 26}
+DEFAULT_GRID = {"ex2": 4096, "lap3d": 512, "markov": 3000, "rmat": 26, "ex1": 100000}
 
 
 def parse_args(argv=None):
@@ -54,11 +54,11 @@ def parse_args(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default=None, choices=["ex2", "lap3d", "markov", "rmat"],
+    ap.add_argument("--workload", default=None, choices=["ex2", "lap3d", "markov", "rmat", "ex1"],
                     help="default: ex2 on one GPU, lap3d (512^3, strong scaling) on several")
     ap.add_argument("--grid", type=int, default=0,
                     help="ex2/lap3d: grid points per side; markov: m of ex5; rmat: the R-MAT scale "
-                         "(defaults: 4096, 512, 3000, 26)")
+                         "(defaults: 4096, 512, 3000, 26; ex1: 100000 rows)")
     ap.add_argument("--weak", action="store_true",
                     help="ex2/lap3d on several GPUs: every GPU owns grid^2 / grid^3 rows (the slowest grid "
                          "dimension grows with N) instead of a share of one fixed grid")
@@ -104,7 +104,8 @@ def parse_args(argv=None):
     if not args.grid:
         args.grid = DEFAULT_GRID[args.workload]
     if not args.nev:
-        args.nev = 16 if args.workload == "markov" else 32
+        args.nev = 16 if args.workload == "markov" else 10 if args.workload == "ex1" else 32
+    args.ncv = 32 if args.workload == "ex1" else 0          # configuration 1 fixes ncv = 32; the others take the default
     return args
 
 
@@ -163,6 +164,9 @@ def workload_rows(args, size, rank):
         name = ("ex2 2-D 5-point Laplacian %s (%d rows)" if d == 2 else "3-D 7-point Laplacian %s (%d rows)") % (shape, N)
         part = "slabs of %s, %d rank(s)" % ("grid lines" if d == 2 else "grid planes", size)
         return name, N, row0, row1, dims, part
+    if args.workload == "ex1":
+        row0, row1 = matgen.split_rows(g, size, rank)
+        return "ex1 1-D Laplacian (%d rows)" % g, g, row0, row1, None, "equal row blocks, %d rank(s)" % size
     if args.workload == "markov":
         N = g * (g + 1) // 2
         row0, row1 = matgen.split_rows(N, size, rank)
@@ -204,6 +208,8 @@ def generate(args, N, row0, row1, dims, rank, size=1, dist=None):
         return matgen.laplacian2d(dims[0], dims[1], row0, row1)
     if args.workload == "lap3d":
         return matgen.laplacian3d(dims[0], dims[1], dims[2], row0, row1)
+    if args.workload == "ex1":
+        return matgen.laplacian1d(args.grid, row0, row1)
     if args.workload == "markov":
         return matgen.markov(args.grid, row0, row1)
     progress = (lambda t: print(t, file=sys.stderr, flush=True)) if rank == 0 and args.grid > 23 else None
@@ -265,7 +271,7 @@ def cpu_baseline(args, csr, nev, restarts, threads):
     if not herm:
         v0 = np.zeros(n)
         v0[:2] = 1.0
-    e = oeps.EPS(A.mult, n, hermitian=herm, nev=nev, max_it=1 + restarts, monitor=monitor, v0=v0,
+    e = oeps.EPS(A.mult, n, hermitian=herm, nev=nev, ncv=args.ncv, max_it=1 + restarts, monitor=monitor, v0=v0,
                  which="largest_real" if not herm else None, bv_factory=K.bv)
     e.solve()
     (t0, b0), (t1, b1) = marks[0], marks[-1]
@@ -346,8 +352,8 @@ def main():
         eps.set_problem_type(K.EPS_HEP)
     if args.eps_type != "krylovschur":
         eps.set_type(args.eps_type)
-    eps.set_dimensions(args.nev)
-    ncv = eps.dimensions()[1] or max(2 * args.nev, args.nev + 15)
+    eps.set_dimensions(args.nev, args.ncv)
+    ncv = args.ncv or eps.dimensions()[1] or max(2 * args.nev, args.nev + 15)
     W, Ksteps = args.warmup, args.steps
     if args.to_convergence:
         W, Ksteps = 0, args.max_restarts or max(100, 2 * N // ncv)
@@ -536,7 +542,12 @@ def main():
             "ranks": per_rank,
         }
         if args.to_convergence:
-            out["time_to_convergence_s"] = round(dt, 3)
+            if eps.reason > 0:
+                out["time_to_convergence_s"] = round(dt, 3)
+            else:
+                # the reference's restart cap (krylovschur.c:89) ended the solve before nev pairs had converged
+                out["time_to_convergence_s"] = None
+                out["stopped_unconverged_after_s"] = round(dt, 3)
             out["max_relative_residual"] = max_res
             out["max_eigenvalue_error_vs_analytic"] = eig_err
             out["nconv_history"] = marks["nconv_history"]
